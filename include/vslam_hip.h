@@ -1,0 +1,225 @@
+/*
+ * vslam_hip.h -- C-ABI of libvslam_hip.so: the MI355X (gfx950) build of the stereo-VO hot path of
+ * shangzhouye/stereo-visual-slam (front-end ORB/ANMS/rBRIEF, cross-checked Hamming matching, stereo
+ * triangulation, motion-only pose refinement, 10-keyframe local bundle adjustment).
+ *
+ * The reference has no FFI/plugin layer: its seam is the public C++ surface of visual_odometry.hpp,
+ * optimization.hpp and map.hpp.  Each entry point below replaces the arithmetic behind
+ * ONE reference method; `file:line` citations are into /root/reference.  The C++ host mirror that keeps the
+ * reference's method names on top of this ABI lives in stereo-visual-slam_amd/host/ (see INTEGRATION.md for the
+ * binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes, POD structs, no C++/torch types; every call returns an int status
+ *     (0 = ok, <0 = error, never throws, never reads out of bounds on bad indices -- quirk Q7);
+ *   - `vslam_*`      : HOST buffers in/out, synchronous, one call per reference method (drop-in granularity);
+ *   - `vslam_*_dev`  : DEVICE-resident, batched over B independent items (stereo pairs / frames / windows),
+ *                      asynchronous on the context's stream -- the throughput path bench.py measures;
+ *   - SE3 poses are 7 doubles: unit quaternion (x,y,z,w) then translation (Sophus::SE3d memory order);
+ *   - camera = {fx, fy, cx, cy, baseline}; K4 = {fx, fy, cx, cy}.
+ *   - a context is thread-compatible, not thread-safe; one context per GPU per thread.
+ */
+#ifndef VSLAM_HIP_H
+#define VSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSLAM_OK 0
+#define VSLAM_ERR_ARG (-1)       /* null pointer / bad size / index out of range */
+#define VSLAM_ERR_HIP (-2)       /* a HIP runtime call failed; see vslam_last_error() */
+#define VSLAM_ERR_CAPACITY (-3)  /* an internal or caller capacity was exceeded (results truncated) */
+#define VSLAM_ERR_NO_DEVICE (-4) /* no gfx950-class GPU visible */
+
+#define VSLAM_ORB_NLEVELS 8
+#define VSLAM_MAX_KF 12          /* keyframes per optimisation window (reference: Map::num_keyframes_ = 10, map.hpp:22) */
+#define VSLAM_LM_MAX_ITERS 32
+
+/* layout-compatible with cv::KeyPoint (28 B) -- types_def.hpp:23 `cv::KeyPoint keypoint_` */
+typedef struct vslam_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} vslam_keypoint;
+
+/* layout-compatible with cv::DMatch (16 B) -- visual_odometry.hpp:117 */
+typedef struct vslam_dmatch {
+    int32_t queryIdx, trainIdx, imgIdx;
+    float distance;
+} vslam_dmatch;
+
+/* every hard-coded constant of the reference's hot path (SURVEY.md section 5 "Config / flags") */
+typedef struct vslam_params {
+    int32_t img_w, img_h;          /* 1241 x 376 (KITTI-00)                                         */
+    int32_t max_batch;             /* largest B the context is sized for                            */
+    int32_t orb_nfeatures;         /* 3000  visual_odometry.cpp:22                                  */
+    int32_t anms_num;              /* 500   visual_odometry.cpp:82 (BASELINE config 2 uses 1500)    */
+    int32_t fast_threshold;        /* 20    cv::ORB default                                         */
+    int32_t kp_capacity;           /* per-image capacity of keypoint/descriptor outputs (>= 4096)   */
+    double cam[5];                 /* fx fy cx cy b: 718.856 718.856 607.1928 185.2157 0.573  types_def.hpp:53-54 */
+    double depth_min, depth_max;   /* 10, 400   visual_odometry.cpp:194                             */
+    double depth_reliable;         /* 40        visual_odometry.cpp:201                             */
+    double match_ratio;            /* 2.0       visual_odometry.cpp:242                             */
+    double match_gap_thr;          /* 30.0      visual_odometry.cpp:242                             */
+    double huber_delta;            /* 5.991     optimization.cpp:154,205                            */
+    double pnp_reproj_thr;         /* 4.0 px    visual_odometry.cpp:277                             */
+} vslam_params;
+
+typedef struct vslam_lm_stats {
+    int32_t iterations, total_trials;
+    double chi2_init, chi2_final, lambda_final;
+    double chi2_iter[VSLAM_LM_MAX_ITERS];
+    double lambda_iter[VSLAM_LM_MAX_ITERS];
+    int32_t trials_iter[VSLAM_LM_MAX_ITERS];
+} vslam_lm_stats;
+
+typedef struct vslam_ctx vslam_ctx;
+
+/* ------------------------------------------------------------------ context --------------------------- */
+void vslam_default_params(vslam_params* p);
+/* stream: a hipStream_t (as void*) to run on, or NULL to create a private one. */
+int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out);
+void vslam_destroy(vslam_ctx* ctx);
+const char* vslam_last_error(void);
+const char* vslam_version(void);
+int vslam_sync(vslam_ctx* ctx);
+/* bytes of device memory the context holds */
+size_t vslam_device_bytes(const vslam_ctx* ctx);
+/* name of the GPU kernel families, for profiling cross-reference (NUL separated list not needed: static string) */
+const char* vslam_kernel_names(void);
+
+/* ------------------------------------------------------------------ A1+A2+A3: VO::feature_detection --- */
+/* Replaces the body of VO::feature_detection (visual_odometry.cpp:70-94) minus the GUI calls:
+ * cv::ORB(3000)::detect (:80) -> VO::adaptive_non_maximal_suppresion(kps, anms_num) (:82, :96-157)
+ * -> cv::ORB::compute (:85).  img: h rows of `stride` bytes (host).  kps/desc: caller buffers of `cap`
+ * entries (desc: cap x 32 bytes).  *n_out = number of keypoints written. */
+int vslam_feature_detection(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                            vslam_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* The three stages individually, for parity tests (same citations). */
+int vslam_orb_detect(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stride, vslam_keypoint* kps, int cap, int* n_out);
+int vslam_anms(vslam_ctx* ctx, vslam_keypoint* kps /*in/out*/, int n, int num, int* n_out);
+int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                      vslam_keypoint* kps /*in/out: filtered + regrouped by octave*/, int n, uint8_t* desc, int* n_out);
+
+/* Batched, device-resident: d_imgs = B images, each h x pitch bytes, image b at d_imgs + b*img_bytes.
+ * d_kps: B x kp_capacity keypoints; d_desc: B x kp_capacity x 32; d_count: B int32. */
+int vslam_feature_detection_dev(vslam_ctx* ctx, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B,
+                                vslam_keypoint* d_kps, uint8_t* d_desc, int32_t* d_count);
+
+/* ------------------------------------------------------------------ A5: VO::feature_matching ---------- */
+/* Replaces VO::feature_matching (visual_odometry.cpp:219-251): BFMatcher(NORM_HAMMING, crossCheck=true)::match
+ * (:225) + the distance gate d <= max(match_ratio*d_min, match_gap_thr*frame_gap) (:229-246).
+ * q: nq x 32 (descriptors_1 = last frame), t: nt x 32 (descriptors_2 = current frame). out: >= nq entries.
+ * gate = 0 returns the raw cross-check matches.  An empty match set yields *n_out = 0 (reference: UB, Q7). */
+int vslam_feature_matching(vslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double frame_gap,
+                           int gate, vslam_dmatch* out, int* n_out);
+
+/* Batched, device-resident: item b matches d_q + b*q_stride_bytes (d_nq[b] rows) against d_t + b*t_stride_bytes
+ * (d_nt[b] rows); writes d_out + b*out_capacity (ascending queryIdx) and d_nout[b].  d_gap: per-item frame gap. */
+int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stride_bytes, const int32_t* d_nq,
+                               const uint8_t* d_t, size_t t_stride_bytes, const int32_t* d_nt,
+                               const double* d_gap, int gate, int B, int max_rows,
+                               vslam_dmatch* d_out, int out_capacity, int32_t* d_nout);
+
+/* ------------------------------------------------------------------ A7: depth -> landmarks ------------ */
+/* Replaces Frame::find_3d (types_def.cpp:9-18) + the gating of VO::set_ref_3d_position
+ * (visual_odometry.cpp:176-217) for a disparity map (h x w f32, row stride in elements).  No compaction:
+ * valid[i]/reliable[i] per keypoint, xyz_w[3i..] world point (f32, cv::Point3f).  *n_valid optional. */
+int vslam_find_3d_disparity(vslam_ctx* ctx, const vslam_keypoint* kps, int n, const float* disparity, int w, int h,
+                            int dstride, const double T_c_w[7], float* xyz_w, uint8_t* valid, uint8_t* reliable, int* n_valid);
+
+/* north_star stage K8: the same contract from matched left/right pixels (uvL, uvR: n x 2 f32) through the
+ * rectified-stereo inhomogeneous DLT instead of an SGBM disparity map. */
+int vslam_triangulate(vslam_ctx* ctx, const float* uvL, const float* uvR, int n, const double T_c_w[7],
+                      float* xyz_w, uint8_t* valid, uint8_t* reliable, int* n_valid);
+
+/* Batched, device-resident: item b has d_n[b] pairs at offset b*capacity; pose d_T_c_w + 7*b. */
+int vslam_triangulate_dev(vslam_ctx* ctx, const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B,
+                          const double* d_T_c_w, float* d_xyz_w, uint8_t* d_valid, uint8_t* d_reliable);
+
+/* Gather matched keypoint coordinates (device glue between matcher and triangulation / PnP):
+ * uvQ[b][i] = kpsQ[b][match.queryIdx].pt, uvT[b][i] = kpsT[b][match.trainIdx].pt */
+int vslam_gather_matched_uv_dev(vslam_ctx* ctx, const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT, int kp_capacity,
+                                const vslam_dmatch* d_matches, const int32_t* d_nmatch, int match_capacity, int B,
+                                float* d_uvQ, float* d_uvT);
+
+/* ------------------------------------------------------------------ A8/A10: VO::motion_estimation ----- */
+/* north_star stage K9, standing in for cv::solvePnPRansac (visual_odometry.cpp:277): motion-only LM on one
+ * pose with PoseOnlyEdgeProjection's residual/Jacobian (optimization.cpp:75-101), g2o LM schedule, Huber
+ * delta; inlier[i] = reprojection error <= pnp_reproj_thr at the estimate.  T_c_w in: guess, out: estimate. */
+int vslam_pnp_motion_only(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int iters,
+                          uint8_t* inlier, int* n_inliers, vslam_lm_stats* stats);
+
+/* Batched, device-resident: problem b has d_n[b] points at offset b*capacity; poses d_T + 7*b (in/out). */
+int vslam_pnp_motion_only_dev(vslam_ctx* ctx, const float* d_xyz_w, const float* d_uv, const int32_t* d_n, int capacity, int B,
+                              double* d_T_c_w, int iters, uint8_t* d_inlier, int32_t* d_n_inliers);
+
+/* VO::check_motion_estimation (visual_odometry.cpp:316-346); host arithmetic (scalar). returns 1/0. */
+int vslam_check_motion(int num_inliers, const double T_c_l[7], double frame_gap);
+
+/* ------------------------------------------------------------------ A12: optimize_map ----------------- */
+/* Replaces the optimiser of optimize_map (optimization.cpp:103-288) on the graph the caller built from the map
+ * containers (:127-214): n_kf poses (none fixed), n_lm landmarks (f32 at rest, Q4), n_edge EdgeProjection
+ * edges {kf_idx, lm_idx, uv}; any edge order.  g2o LM + Schur + Huber(huber_delta), `iters` iterations.
+ * flag_lm[e]: landmark whose is_inlier flag edge e writes (reference: feat.landmark_id_, :258-264; quirk Q1),
+ * or NULL for flag_lm = lm_idx.  lm_inlier: n_lm flags, in/out (:224-266, edges visited in ascending index).
+ * update_poses / update_lms: if_update_map / if_update_landmark (:272-287).  chi2_out (n_edge) optional. */
+int vslam_local_ba(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, float* xyz, int n_edge,
+                   const int32_t* kf_idx, const int32_t* lm_idx, const float* uv, const int32_t* flag_lm,
+                   int iters, int update_poses, int update_lms, uint8_t* lm_inlier, double* chi2_out,
+                   double* chi2_threshold_out, vslam_lm_stats* stats);
+
+/* ------------------------------------------------------------------ A13: optimize_pose_only ----------- */
+/* Replaces optimize_pose_only (optimization.cpp:290-436): unary PoseOnlyEdgeProjection edges, landmarks constant,
+ * dense per-pose solve with one shared lambda, same chi2 classification, pose write-back (:429-435). */
+int vslam_pose_only_window(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, const float* xyz, int n_edge,
+                           const int32_t* kf_idx, const int32_t* lm_idx, const float* uv, const int32_t* flag_lm,
+                           int iters, int update_poses, uint8_t* lm_inlier, double* chi2_out,
+                           double* chi2_threshold_out, vslam_lm_stats* stats);
+
+/* Batched, device-resident windows (throughput mode).  All windows share n_kf.
+ * Window w owns landmarks [lm_off[w], lm_off[w+1]) and edges [edge_off[w], edge_off[w+1]) of the concatenated
+ * arrays; edges MUST be sorted by landmark inside a window (lm_idx ascending) with lm_idx/kf_idx window-local.
+ * One call runs the reference's per-keyframe schedule (run_vslam.cpp:58-71) when schedule = 1:
+ *   optimize_map(5 its, no write) x2, optimize_map(10 its, poses written), optimize_pose_only(10 its, written),
+ * each followed by the chi2 classification that feeds the next pass's landmark filter; schedule = 0 runs a
+ * single optimize_map(iters) (mode 0) or optimize_pose_only(iters) (mode 1) pass with update flags. */
+typedef struct vslam_ba_batch {
+    int32_t n_windows, n_kf;
+    const int32_t* d_lm_off;      /* n_windows + 1 */
+    const int32_t* d_edge_off;    /* n_windows + 1 */
+    double* d_T_c_w;              /* n_windows x n_kf x 7, in/out */
+    float* d_xyz;                 /* total_lm x 3, in/out (only with update_lms) */
+    const uint8_t* d_reliable;    /* total_lm: Landmark::reliable_depth_ (optimize_map filter :160); NULL = all 1 */
+    uint8_t* d_lm_inlier;         /* total_lm, in/out */
+    const int32_t* d_kf_idx;      /* total_edge */
+    const int32_t* d_lm_idx;      /* total_edge, window-local */
+    const float* d_uv;            /* total_edge x 2 */
+    double* d_chi2;               /* total_edge, out (last pass) */
+    vslam_lm_stats* d_stats;      /* n_windows (last pass) or NULL */
+    int32_t total_lm, total_edge;
+} vslam_ba_batch;
+int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* batch, int schedule, int mode, int iters,
+                       int update_poses, int update_lms);
+
+/* per-window status of the most recent window launch on this process (VSLAM_OK or VSLAM_ERR_ARG per window) */
+int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status);
+/* per-image ORB capacity flags of the most recent ORB launch (0 = ok) */
+int vslam_orb_status_dev(vslam_ctx* ctx, int B, int32_t* h_status);
+
+/* ------------------------------------------------------------------ raw device memory helpers ---------- */
+/* For hosts without their own device allocator (the C++ mirror in host/); bench.py passes torch tensors. */
+int vslam_dev_alloc(void** p, size_t bytes);
+int vslam_dev_free(void* p);
+int vslam_dev_upload(vslam_ctx* ctx, void* d, const void* h, size_t bytes);
+int vslam_dev_download(vslam_ctx* ctx, void* h, const void* d, size_t bytes);
+int vslam_dev_memset(vslam_ctx* ctx, void* d, int value, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLAM_HIP_H */

@@ -1,0 +1,306 @@
+"""stereo-visual-slam_amd -- MI355X (gfx950) build of the stereo-VO hot path of shangzhouye/stereo-visual-slam.
+
+This Python layer is plumbing: a ctypes binding of the C-ABI in include/vslam_hip.h (libvslam_hip.so, hand-written
+HIP kernels) whose method names mirror the reference's C++ surface (visual_odometry.hpp, optimization.hpp) so that
+the parity tests read like calls into the reference.  There is NO CPU fallback: if libvslam_hip.so is missing or no
+GPU is visible, every compute call raises.
+
+Import name: `stereo_visual_slam_amd` (the repo-root shim maps it to this hyphenated directory).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvslam_hip.so")
+
+VSLAM_OK, VSLAM_ERR_ARG, VSLAM_ERR_HIP, VSLAM_ERR_CAPACITY, VSLAM_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+MAX_KF = 12
+MAX_ROWS = 4096
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+
+class Params(C.Structure):
+    _fields_ = [("img_w", C.c_int32), ("img_h", C.c_int32), ("max_batch", C.c_int32), ("orb_nfeatures", C.c_int32),
+                ("anms_num", C.c_int32), ("fast_threshold", C.c_int32), ("kp_capacity", C.c_int32),
+                ("cam", C.c_double * 5), ("depth_min", C.c_double), ("depth_max", C.c_double),
+                ("depth_reliable", C.c_double), ("match_ratio", C.c_double), ("match_gap_thr", C.c_double),
+                ("huber_delta", C.c_double), ("pnp_reproj_thr", C.c_double)]
+
+
+class LmStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("total_trials", C.c_int32), ("chi2_init", C.c_double),
+                ("chi2_final", C.c_double), ("lambda_final", C.c_double), ("chi2_iter", C.c_double * 32),
+                ("lambda_iter", C.c_double * 32), ("trials_iter", C.c_int32 * 32)]
+
+    def as_dict(self):
+        n = min(self.iterations, 32)
+        return dict(iterations=self.iterations, total_trials=self.total_trials, chi2_init=self.chi2_init,
+                    chi2_final=self.chi2_final, lambda_final=self.lambda_final, chi2_iter=list(self.chi2_iter)[:n],
+                    lambda_iter=list(self.lambda_iter)[:n], trials_iter=list(self.trials_iter)[:n])
+
+
+class BaBatch(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("n_kf", C.c_int32), ("d_lm_off", C.c_void_p), ("d_edge_off", C.c_void_p),
+                ("d_T_c_w", C.c_void_p), ("d_xyz", C.c_void_p), ("d_reliable", C.c_void_p), ("d_lm_inlier", C.c_void_p),
+                ("d_kf_idx", C.c_void_p), ("d_lm_idx", C.c_void_p), ("d_uv", C.c_void_p), ("d_chi2", C.c_void_p),
+                ("d_stats", C.c_void_p), ("total_lm", C.c_int32), ("total_edge", C.c_int32)]
+
+
+# every symbol include/vslam_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "vslam_default_params", "vslam_create", "vslam_destroy", "vslam_last_error", "vslam_version", "vslam_sync",
+    "vslam_device_bytes", "vslam_kernel_names", "vslam_feature_detection", "vslam_orb_detect", "vslam_anms",
+    "vslam_orb_compute", "vslam_feature_detection_dev", "vslam_feature_matching", "vslam_feature_matching_dev",
+    "vslam_find_3d_disparity", "vslam_triangulate", "vslam_triangulate_dev", "vslam_gather_matched_uv_dev",
+    "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
+    "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
+    "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset",
+]
+
+
+class VslamError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """compile libvslam_hip.so for gfx950 (hipcc cross-compiles without a GPU)"""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j8", "-s"]
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean", "-s"])
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_lib = None
+
+
+def load_library():
+    """load libvslam_hip.so; raises (loudly) when it has not been built"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise VslamError("libvslam_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(_SO)
+    lib.vslam_last_error.restype = C.c_char_p
+    lib.vslam_version.restype = C.c_char_p
+    lib.vslam_kernel_names.restype = C.c_char_p
+    lib.vslam_device_bytes.restype = C.c_size_t
+    lib.vslam_device_bytes.argtypes = [C.c_void_p]
+    lib.vslam_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.vslam_destroy.argtypes = [C.c_void_p]
+    lib.vslam_sync.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def default_params(**kw):
+    p = Params()
+    load_library().vslam_default_params(C.byref(p))
+    for k, v in kw.items():
+        if k == "cam":
+            for i in range(5):
+                p.cam[i] = float(v[i])
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _desc(d):
+    d = np.ascontiguousarray(d, np.uint8)
+    if d.size == 0:
+        d = d.reshape(0, 32)
+    assert d.ndim == 2 and d.shape[1] == 32, d.shape
+    return d
+
+
+class VO:
+    """Device context + the reference's VO / optimisation method names over the C-ABI.
+
+    Host-buffer methods take and return numpy arrays (one call per reference method); `*_dev` methods take raw
+    device pointers (ints, e.g. torch.Tensor.data_ptr()) and run batched + asynchronously on the context stream.
+    """
+
+    def __init__(self, params=None, device=0, stream=None, **kw):
+        self.lib = load_library()
+        self.params = params if params is not None else default_params(**kw)
+        h = C.c_void_p()
+        rc = self.lib.vslam_create(C.byref(self.params), int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != VSLAM_OK:
+            raise VslamError("vslam_create failed (%d): %s" % (rc, self.lib.vslam_last_error().decode()))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vslam_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != VSLAM_OK:
+            raise VslamError("%s failed (%d): %s" % (what, rc, self.lib.vslam_last_error().decode()))
+
+    def sync(self):
+        self._chk(self.lib.vslam_sync(self.h), "vslam_sync")
+
+    @property
+    def device_bytes(self):
+        return int(self.lib.vslam_device_bytes(self.h))
+
+    # ------------------------------------------------------------ VO::feature_detection (visual_odometry.cpp:70-94)
+    def _img(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.ndim == 2
+        return img
+
+    def feature_detection(self, img):
+        img = self._img(img)
+        cap = self.params.kp_capacity
+        kps = np.zeros(cap, KEYPOINT_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+        self._chk(self.lib.vslam_feature_detection(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps),
+                                                   _p(desc), cap, C.byref(n)), "vslam_feature_detection")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def orb_detect(self, img):
+        img = self._img(img)
+        cap = self.params.kp_capacity
+        kps = np.zeros(cap, KEYPOINT_DTYPE); n = C.c_int()
+        self._chk(self.lib.vslam_orb_detect(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), cap,
+                                            C.byref(n)), "vslam_orb_detect")
+        return kps[:n.value].copy()
+
+    def adaptive_non_maximal_suppresion(self, kps, num=500):
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+        buf = np.zeros(max(len(kps), 1), KEYPOINT_DTYPE); buf[:len(kps)] = kps
+        n = C.c_int()
+        self._chk(self.lib.vslam_anms(self.h, _p(buf), len(kps), int(num), C.byref(n)), "vslam_anms")
+        return buf[:n.value].copy()
+
+    def orb_compute(self, img, kps):
+        img = self._img(img)
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+        buf = np.zeros(max(len(kps), 1), KEYPOINT_DTYPE); buf[:len(kps)] = kps
+        desc = np.zeros((max(len(kps), 1), 32), np.uint8); n = C.c_int()
+        self._chk(self.lib.vslam_orb_compute(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(buf), len(kps),
+                                             _p(desc), C.byref(n)), "vslam_orb_compute")
+        return buf[:n.value].copy(), desc[:n.value].copy()
+
+    def feature_detection_dev(self, d_imgs, img_bytes, pitch, B, d_kps, d_desc, d_count):
+        self._chk(self.lib.vslam_feature_detection_dev(self.h, _p(d_imgs), C.c_size_t(img_bytes), int(pitch), int(B), _p(d_kps),
+                                                       _p(d_desc), _p(d_count)), "vslam_feature_detection_dev")
+
+    def orb_status(self, B):
+        st = np.zeros(B, np.int32)
+        self._chk(self.lib.vslam_orb_status_dev(self.h, int(B), _p(st)), "vslam_orb_status_dev")
+        return st
+
+    # ------------------------------------------------------------ VO::feature_matching (visual_odometry.cpp:219-251)
+    def feature_matching(self, descriptors_1, descriptors_2, frame_gap=1.0, gate=True):
+        q, t = _desc(descriptors_1), _desc(descriptors_2)
+        out = np.zeros(max(len(q), 1), DMATCH_DTYPE); n = C.c_int()
+        self._chk(self.lib.vslam_feature_matching(self.h, _p(q), len(q), _p(t), len(t), C.c_double(frame_gap), int(gate),
+                                                  _p(out), C.byref(n)), "vslam_feature_matching")
+        return out[:n.value].copy()
+
+    def feature_matching_dev(self, d_q, q_stride, d_nq, d_t, t_stride, d_nt, d_gap, gate, B, max_rows, d_out, out_cap, d_nout):
+        self._chk(self.lib.vslam_feature_matching_dev(self.h, _p(d_q), C.c_size_t(q_stride), _p(d_nq), _p(d_t), C.c_size_t(t_stride),
+                                                      _p(d_nt), _p(d_gap), int(gate), int(B), int(max_rows), _p(d_out), int(out_cap),
+                                                      _p(d_nout)), "vslam_feature_matching_dev")
+
+    # ------------------------------------------------------------ Frame::find_3d / VO::set_ref_3d_position
+    def find_3d_disparity(self, kps, disparity, T_c_w):
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); disparity = np.ascontiguousarray(disparity, np.float32)
+        T = np.ascontiguousarray(T_c_w, np.float64); n = len(kps)
+        xyz = np.zeros((max(n, 1), 3), np.float32); valid = np.zeros(max(n, 1), np.uint8); rel = np.zeros(max(n, 1), np.uint8)
+        self._chk(self.lib.vslam_find_3d_disparity(self.h, _p(kps), n, _p(disparity), disparity.shape[1], disparity.shape[0],
+                                                   disparity.shape[1], _p(T), _p(xyz), _p(valid), _p(rel), None), "vslam_find_3d_disparity")
+        return xyz[:n], valid[:n], rel[:n]
+
+    def triangulate(self, uvL, uvR, T_c_w):
+        uvL = np.ascontiguousarray(uvL, np.float32).reshape(-1, 2); uvR = np.ascontiguousarray(uvR, np.float32).reshape(-1, 2)
+        T = np.ascontiguousarray(T_c_w, np.float64); n = len(uvL)
+        xyz = np.zeros((max(n, 1), 3), np.float32); valid = np.zeros(max(n, 1), np.uint8); rel = np.zeros(max(n, 1), np.uint8)
+        self._chk(self.lib.vslam_triangulate(self.h, _p(uvL), _p(uvR), n, _p(T), _p(xyz), _p(valid), _p(rel), None), "vslam_triangulate")
+        return xyz[:n], valid[:n], rel[:n]
+
+    def triangulate_dev(self, d_uvL, d_uvR, d_n, capacity, B, d_T, d_xyz, d_valid, d_rel):
+        self._chk(self.lib.vslam_triangulate_dev(self.h, _p(d_uvL), _p(d_uvR), _p(d_n), int(capacity), int(B), _p(d_T), _p(d_xyz),
+                                                 _p(d_valid), _p(d_rel)), "vslam_triangulate_dev")
+
+    def gather_matched_uv_dev(self, d_kpsQ, d_kpsT, kp_cap, d_matches, d_nmatch, match_cap, B, d_uvQ, d_uvT):
+        self._chk(self.lib.vslam_gather_matched_uv_dev(self.h, _p(d_kpsQ), _p(d_kpsT), int(kp_cap), _p(d_matches), _p(d_nmatch),
+                                                       int(match_cap), int(B), _p(d_uvQ), _p(d_uvT)), "vslam_gather_matched_uv_dev")
+
+    # ------------------------------------------------------------ VO::motion_estimation (north_star motion-only stage)
+    def motion_estimation(self, xyz_w, uv, T_guess, iters=10):
+        xyz = np.ascontiguousarray(xyz_w, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        T = np.ascontiguousarray(T_guess, np.float64).copy(); n = len(xyz)
+        inl = np.zeros(max(n, 1), np.uint8); ni = C.c_int(); st = LmStats()
+        self._chk(self.lib.vslam_pnp_motion_only(self.h, _p(xyz), _p(uv), n, _p(T), int(iters), _p(inl), C.byref(ni), C.byref(st)),
+                  "vslam_pnp_motion_only")
+        return T, inl[:n], ni.value, st.as_dict()
+
+    def motion_estimation_dev(self, d_xyz, d_uv, d_n, capacity, B, d_T, iters, d_inlier, d_ninl):
+        self._chk(self.lib.vslam_pnp_motion_only_dev(self.h, _p(d_xyz), _p(d_uv), _p(d_n), int(capacity), int(B), _p(d_T), int(iters),
+                                                     _p(d_inlier), _p(d_ninl)), "vslam_pnp_motion_only_dev")
+
+    def check_motion_estimation(self, num_inliers, T_c_l, frame_gap):
+        T = np.ascontiguousarray(T_c_l, np.float64)
+        return bool(self.lib.vslam_check_motion(int(num_inliers), _p(T), C.c_double(frame_gap)))
+
+    # ------------------------------------------------------------ optimize_map / optimize_pose_only (optimization.cpp)
+    def _window(self, fn, name, T, xyz, kf_idx, lm_idx, uv, flag_lm, iters, update_poses, update_lms, lm_inlier, with_lms):
+        T = np.ascontiguousarray(T, np.float64).reshape(-1, 7).copy()
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3).copy()
+        kf_idx = np.ascontiguousarray(kf_idx, np.int32); lm_idx = np.ascontiguousarray(lm_idx, np.int32)
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        fl = None if flag_lm is None else np.ascontiguousarray(flag_lm, np.int32)
+        inl = np.ones(len(xyz), np.uint8) if lm_inlier is None else np.ascontiguousarray(lm_inlier, np.uint8).copy()
+        chi2 = np.zeros(len(kf_idx)); thr = C.c_double(); st = LmStats()
+        if with_lms:
+            rc = fn(self.h, len(T), _p(T), len(xyz), _p(xyz), len(kf_idx), _p(kf_idx), _p(lm_idx), _p(uv), _p(fl), int(iters),
+                    int(update_poses), int(update_lms), _p(inl), _p(chi2), C.byref(thr), C.byref(st))
+        else:
+            rc = fn(self.h, len(T), _p(T), len(xyz), _p(xyz), len(kf_idx), _p(kf_idx), _p(lm_idx), _p(uv), _p(fl), int(iters),
+                    int(update_poses), _p(inl), _p(chi2), C.byref(thr), C.byref(st))
+        self._chk(rc, name)
+        return dict(T=T, xyz=xyz, chi2=chi2, threshold=thr.value, lm_inlier=inl, stats=st.as_dict())
+
+    def optimize_map(self, T, xyz, kf_idx, lm_idx, uv, if_update_map=True, if_update_landmark=False, num_ite=10, flag_lm=None,
+                     lm_inlier=None):
+        return self._window(self.lib.vslam_local_ba, "vslam_local_ba", T, xyz, kf_idx, lm_idx, uv, flag_lm, num_ite, if_update_map,
+                            if_update_landmark, lm_inlier, True)
+
+    def optimize_pose_only(self, T, xyz, kf_idx, lm_idx, uv, if_update_map=True, num_ite=10, flag_lm=None, lm_inlier=None):
+        return self._window(self.lib.vslam_pose_only_window, "vslam_pose_only_window", T, xyz, kf_idx, lm_idx, uv, flag_lm, num_ite,
+                            if_update_map, False, lm_inlier, False)
+
+    def ba_batch_dev(self, batch, schedule=1, mode=0, iters=10, update_poses=1, update_lms=0):
+        self._chk(self.lib.vslam_ba_batch_dev(self.h, C.byref(batch), int(schedule), int(mode), int(iters), int(update_poses),
+                                              int(update_lms)), "vslam_ba_batch_dev")
+
+    def ba_status(self, n_windows):
+        st = np.zeros(n_windows, np.int32)
+        self._chk(self.lib.vslam_ba_status_dev(self.h, int(n_windows), _p(st)), "vslam_ba_status_dev")
+        return st

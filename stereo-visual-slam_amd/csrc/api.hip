@@ -1,0 +1,609 @@
+// api.hip -- the C-ABI of libvslam_hip.so (declared in include/vslam_hip.h).
+// Host-buffer entry points (`vslam_*`) stage through a growable device arena and call the same launches as the
+// device-resident batched entry points (`vslam_*_dev`).  No CPU fallback anywhere: without a HIP device every
+// compute call fails with VSLAM_ERR_HIP / VSLAM_ERR_NO_DEVICE.
+#include <stdarg.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "se3_device.h"
+#include "vslam_internal.h"
+
+namespace vslam {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// simple bump arena over one growable device allocation (host-buffer API only)
+struct Arena {
+    Ctx* c; size_t off;
+    explicit Arena(Ctx* ctx) : c(ctx), off(0) {}
+};
+static int arena_reserve(Ctx* c, size_t bytes) {
+    if (c->stage_bytes >= bytes) return VSLAM_OK;
+    VS_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_stage) { hipFree(c->d_stage); c->dev_bytes -= c->stage_bytes; }
+    c->d_stage = nullptr; c->stage_bytes = 0;
+    const size_t want = std::max(bytes, (size_t)1 << 20);
+    VS_HIP(hipMalloc((void**)&c->d_stage, want));
+    c->stage_bytes = want; c->dev_bytes += want;
+    return VSLAM_OK;
+}
+template <typename T>
+static T* arena_take(Arena& a, size_t n) {
+    a.off = (a.off + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(a.c->d_stage + a.off);
+    a.off += n * sizeof(T);
+    return p;
+}
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static CamParams cam_of(const Ctx* c) {
+    CamParams cam;
+    cam.fx = c->p.cam[0]; cam.fy = c->p.cam[1]; cam.cx = c->p.cam[2]; cam.cy = c->p.cam[3]; cam.b = c->p.cam[4];
+    cam.dmin = c->p.depth_min; cam.dmax = c->p.depth_max; cam.drel = c->p.depth_reliable;
+    return cam;
+}
+
+template <typename T>
+static int dev_alloc(Ctx* c, T** p, size_t n) {
+    VS_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    c->dev_bytes += n * sizeof(T);
+    return VSLAM_OK;
+}
+
+static int orb_status_check(Ctx* c, int B) {
+    std::vector<int32_t> st(B);
+    VS_HIP(hipMemcpyAsync(st.data(), c->orb.d_status, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < B; ++b)
+        if (st[b]) { set_error("ORB capacity exceeded on image %d (status bits 0x%x)", b, st[b]); return VSLAM_ERR_CAPACITY; }
+    return VSLAM_OK;
+}
+
+// detect + (ANMS) + (describe) on device-resident images
+static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, int anms_num, int regroup, bool describe,
+                        vslam_keypoint* d_kps, uint8_t* d_desc, int32_t* d_count) {
+    if (B <= 0) return VSLAM_OK;
+    if (B > c->p.max_batch) { set_error("batch %d exceeds context max_batch %d", B, c->p.max_batch); return VSLAM_ERR_ARG; }
+    int rc;
+    if ((rc = launch_orb_pyramid(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->stream))) return rc;
+    if ((rc = launch_orb_fast(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->p.fast_threshold, c->orb.d_corners,
+                              c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
+    if ((rc = launch_orb_select(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel,
+                                c->orb.d_sel_cnt, c->orb.d_status, c->stream))) return rc;
+    if ((rc = launch_orb_anms(c->plan, B, c->orb.d_sel, c->orb.d_sel_cnt, c->plan.sel_cap, anms_num, regroup, d_kps, c->p.kp_capacity,
+                              d_count, c->orb.d_status, c->stream))) return rc;
+    if (describe)
+        if ((rc = launch_orb_describe(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, d_kps, c->p.kp_capacity, d_count, d_desc, c->stream)))
+            return rc;
+    return VSLAM_OK;
+}
+
+static int check_img(Ctx* c, const void* img, int w, int h, int stride) {
+    if (!c || !img) { set_error("null context or image"); return VSLAM_ERR_ARG; }
+    if (w != c->p.img_w || h != c->p.img_h || stride < w) { set_error("image %dx%d (stride %d) does not match the context's %dx%d", w, h, stride, c->p.img_w, c->p.img_h); return VSLAM_ERR_ARG; }
+    return VSLAM_OK;
+}
+
+} // namespace vslam
+
+using namespace vslam;
+
+extern "C" {
+
+void vslam_default_params(vslam_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->img_w = 1241; p->img_h = 376; p->max_batch = 1;
+    p->orb_nfeatures = 3000; p->anms_num = 500; p->fast_threshold = 20; p->kp_capacity = 4096;
+    p->cam[0] = 718.856; p->cam[1] = 718.856; p->cam[2] = 607.1928; p->cam[3] = 185.2157; p->cam[4] = 0.573;
+    p->depth_min = 10; p->depth_max = 400; p->depth_reliable = 40;
+    p->match_ratio = 2.0; p->match_gap_thr = 30.0; p->huber_delta = 5.991; p->pnp_reproj_thr = 4.0;
+}
+
+const char* vslam_last_error(void) { return g_err; }
+const char* vslam_version(void) { return "vslam_hip 0.1 (gfx950)"; }
+const char* vslam_kernel_names(void) {
+    return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_describe_kernel match_train_nearest_kernel "
+           "match_finalize_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel";
+}
+
+int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
+    if (!p || !out) { set_error("null argument"); return VSLAM_ERR_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libvslam_hip has no CPU path)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return VSLAM_ERR_ARG; }
+    if (p->max_batch <= 0 || p->kp_capacity < 64 || p->kp_capacity > kMaxRows || p->orb_nfeatures <= 0) { set_error("bad params (max_batch>0, 64<=kp_capacity<=%d)", kMaxRows); return VSLAM_ERR_ARG; }
+    VS_HIP(hipSetDevice(device));
+    Ctx* c = new Ctx();
+    memset(c, 0, sizeof(*c));
+    c->p = *p; c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return VSLAM_ERR_HIP; }
+        c->own_stream = true;
+    }
+    int rc = orb_plan_init(&c->plan, p->img_w, p->img_h, p->orb_nfeatures, p->kp_capacity);
+    if (rc == VSLAM_OK) rc = orb_tables_init(&c->plan, &c->tab);
+    const size_t B = (size_t)p->max_batch;
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_pyr, B * c->plan.pyr_bytes);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_corners, B * c->plan.corner_total);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_corner_cnt, B * kNLevels);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_sel, B * kNLevels * c->plan.sel_cap);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_sel_cnt, B * kNLevels);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_status, B);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->match.d_train_best, B * kMaxRows);
+    if (rc != VSLAM_OK) { vslam_destroy(reinterpret_cast<vslam_ctx*>(c)); return rc; }
+    *out = reinterpret_cast<vslam_ctx*>(c);
+    return VSLAM_OK;
+}
+
+void vslam_destroy(vslam_ctx* ctx) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    orb_tables_free(&c->tab);
+    void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det,
+                    c->match.d_train_best, c->d_stage};
+    for (void* q : ptrs) if (q) hipFree(q);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vslam_sync(vslam_ctx* ctx) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return VSLAM_ERR_ARG;
+    VS_HIP(hipStreamSynchronize(c->stream));
+    return VSLAM_OK;
+}
+
+size_t vslam_device_bytes(const vslam_ctx* ctx) { return ctx ? reinterpret_cast<const Ctx*>(ctx)->dev_bytes : 0; }
+
+// ---------------------------------------------------------------------------------------------- ORB, host buffers
+static int upload_image(Ctx* c, Arena& ar, const uint8_t* img, int w, int h, int stride, uint8_t** d_img, int* pitch) {
+    *pitch = (w + 63) & ~63;
+    *d_img = arena_take<uint8_t>(ar, (size_t)*pitch * h);
+    VS_HIP(hipMemcpy2DAsync(*d_img, *pitch, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    return VSLAM_OK;
+}
+
+static int orb_host_call(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stride, int anms_num, int regroup, bool describe,
+                         vslam_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    int rc = check_img(c, img, w, h, stride);
+    if (rc) return rc;
+    if (!kps || !n_out || cap <= 0 || (describe && !desc)) { set_error("null output"); return VSLAM_ERR_ARG; }
+    VS_HIP(hipSetDevice(c->device));
+    const int kc = c->p.kp_capacity;
+    const size_t pitch = (w + 63) & ~63;
+    if ((rc = arena_reserve(c, al256(pitch * h) + al256(sizeof(vslam_keypoint) * kc) + al256((size_t)kc * 32) + 1024))) return rc;
+    Arena ar(c);
+    uint8_t* d_img; int dp;
+    if ((rc = upload_image(c, ar, img, w, h, stride, &d_img, &dp))) return rc;
+    vslam_keypoint* d_kps = arena_take<vslam_keypoint>(ar, kc);
+    uint8_t* d_desc = arena_take<uint8_t>(ar, (size_t)kc * 32);
+    int32_t* d_cnt = arena_take<int32_t>(ar, 1);
+    if ((rc = orb_pipeline(c, d_img, (size_t)dp * h, dp, 1, anms_num, regroup, describe, d_kps, d_desc, d_cnt))) return rc;
+    int32_t n = 0;
+    VS_HIP(hipMemcpyAsync(&n, d_cnt, sizeof(n), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = orb_status_check(c, 1))) return rc;
+    if (n > cap) { *n_out = 0; set_error("caller capacity %d < %d keypoints", cap, n); return VSLAM_ERR_CAPACITY; }
+    VS_HIP(hipMemcpyAsync(kps, d_kps, sizeof(vslam_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
+    if (describe) VS_HIP(hipMemcpyAsync(desc, d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    *n_out = n;
+    return VSLAM_OK;
+}
+
+int vslam_feature_detection(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stride, vslam_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) { set_error("null context"); return VSLAM_ERR_ARG; }
+    return orb_host_call(ctx, img, w, h, stride, c->p.anms_num, 1, true, kps, desc, cap, n_out);
+}
+
+int vslam_orb_detect(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stride, vslam_keypoint* kps, int cap, int* n_out) {
+    return orb_host_call(ctx, img, w, h, stride, 0, 0, false, kps, nullptr, cap, n_out);
+}
+
+int vslam_anms(vslam_ctx* ctx, vslam_keypoint* kps, int n, int num, int* n_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !kps || !n_out || n < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if (n > kMaxRows) { set_error("ANMS input %d > %d", n, kMaxRows); return VSLAM_ERR_CAPACITY; }
+    if (n == 0) { *n_out = 0; return VSLAM_OK; }
+    VS_HIP(hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reserve(c, 2 * al256(sizeof(vslam_keypoint) * kMaxRows) + 1024))) return rc;
+    Arena ar(c);
+    vslam_keypoint* d_in = arena_take<vslam_keypoint>(ar, kMaxRows);
+    vslam_keypoint* d_out = arena_take<vslam_keypoint>(ar, kMaxRows);
+    int32_t* d_n = arena_take<int32_t>(ar, 1);
+    int32_t* d_cnt = arena_take<int32_t>(ar, 1);
+    int32_t nn = n;
+    VS_HIP(hipMemcpyAsync(d_in, kps, sizeof(vslam_keypoint) * n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
+    if ((rc = launch_anms_flat(1, d_in, d_n, kMaxRows, num, 0, c->p.img_w, c->p.img_h, d_out, kMaxRows, d_cnt, c->orb.d_status, c->stream))) return rc;
+    int32_t m = 0;
+    VS_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(m), hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    VS_HIP(hipMemcpy(kps, d_out, sizeof(vslam_keypoint) * m, hipMemcpyDeviceToHost));
+    *n_out = m;
+    return VSLAM_OK;
+}
+
+int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stride, vslam_keypoint* kps, int n, uint8_t* desc, int* n_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    int rc = check_img(c, img, w, h, stride);
+    if (rc) return rc;
+    if (!kps || !desc || !n_out || n < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if (n > c->p.kp_capacity) { set_error("compute input %d > kp_capacity %d", n, c->p.kp_capacity); return VSLAM_ERR_CAPACITY; }
+    if (n == 0) { *n_out = 0; return VSLAM_OK; }
+    for (int i = 0; i < n; ++i)
+        if (kps[i].octave < 0 || kps[i].octave >= kNLevels) { set_error("keypoint %d: octave %d out of range", i, kps[i].octave); return VSLAM_ERR_ARG; }
+    VS_HIP(hipSetDevice(c->device));
+    const int kc = c->p.kp_capacity;
+    const size_t pitch = (w + 63) & ~63;
+    if ((rc = arena_reserve(c, al256(pitch * h) + 2 * al256(sizeof(vslam_keypoint) * kc) + al256((size_t)kc * 32) + 1024))) return rc;
+    Arena ar(c);
+    uint8_t* d_img; int dp;
+    if ((rc = upload_image(c, ar, img, w, h, stride, &d_img, &dp))) return rc;
+    vslam_keypoint* d_in = arena_take<vslam_keypoint>(ar, kc);
+    vslam_keypoint* d_kps = arena_take<vslam_keypoint>(ar, kc);
+    uint8_t* d_desc = arena_take<uint8_t>(ar, (size_t)kc * 32);
+    int32_t* d_n = arena_take<int32_t>(ar, 1);
+    int32_t* d_cnt = arena_take<int32_t>(ar, 1);
+    int32_t nn = n;
+    VS_HIP(hipMemcpyAsync(d_in, kps, sizeof(vslam_keypoint) * n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
+    if ((rc = launch_orb_pyramid(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->stream))) return rc;
+    if ((rc = launch_anms_flat(1, d_in, d_n, kc, 0, 1, w, h, d_kps, kc, d_cnt, c->orb.d_status, c->stream))) return rc;
+    if ((rc = launch_orb_describe(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, d_kps, kc, d_cnt, d_desc, c->stream))) return rc;
+    int32_t m = 0;
+    VS_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(m), hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    VS_HIP(hipMemcpy(kps, d_kps, sizeof(vslam_keypoint) * m, hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpy(desc, d_desc, (size_t)m * 32, hipMemcpyDeviceToHost));
+    *n_out = m;
+    return VSLAM_OK;
+}
+
+int vslam_feature_detection_dev(vslam_ctx* ctx, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, vslam_keypoint* d_kps,
+                                uint8_t* d_desc, int32_t* d_count) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_imgs || !d_kps || !d_desc || !d_count || pitch < c->p.img_w || img_bytes < (size_t)pitch * c->p.img_h) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    return orb_pipeline(c, d_imgs, img_bytes, pitch, B, c->p.anms_num, 1, true, d_kps, d_desc, d_count);
+}
+
+int vslam_orb_status_dev(vslam_ctx* ctx, int B, int32_t* h_status) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !h_status || B <= 0 || B > c->p.max_batch) return VSLAM_ERR_ARG;
+    VS_HIP(hipMemcpyAsync(h_status, c->orb.d_status, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    return VSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- matcher
+int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stride_bytes, const int32_t* d_nq, const uint8_t* d_t,
+                               size_t t_stride_bytes, const int32_t* d_nt, const double* d_gap, int gate, int B, int max_rows,
+                               vslam_dmatch* d_out, int out_capacity, int32_t* d_nout) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_q || !d_t || !d_nq || !d_nt || !d_gap || !d_out || !d_nout || out_capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if (B > c->p.max_batch) { set_error("batch %d exceeds context max_batch %d", B, c->p.max_batch); return VSLAM_ERR_ARG; }
+    return launch_match(d_q, q_stride_bytes, d_nq, d_t, t_stride_bytes, d_nt, d_gap, gate, c->p.match_ratio, c->p.match_gap_thr, B, max_rows,
+                        c->match.d_train_best, d_out, out_capacity, d_nout, c->stream);
+}
+
+int vslam_feature_matching(vslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double frame_gap, int gate,
+                           vslam_dmatch* out, int* n_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !n_out || nq < 0 || nt < 0 || (nq > 0 && (!q || !out)) || (nt > 0 && !t)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if (nq > kMaxRows || nt > kMaxRows) { set_error("matcher supports at most %d rows per side", kMaxRows); return VSLAM_ERR_CAPACITY; }
+    *n_out = 0;
+    if (nq == 0 || nt == 0) return VSLAM_OK; // empty set: no matches (reference: UB, quirk Q7)
+    VS_HIP(hipSetDevice(c->device));
+    int rc;
+    const int rows = std::max(nq, nt);
+    if ((rc = arena_reserve(c, 2 * al256((size_t)rows * 32) + al256(sizeof(vslam_dmatch) * nq) + 2048))) return rc;
+    Arena ar(c);
+    uint8_t* d_q = arena_take<uint8_t>(ar, (size_t)nq * 32);
+    uint8_t* d_t = arena_take<uint8_t>(ar, (size_t)nt * 32);
+    vslam_dmatch* d_out = arena_take<vslam_dmatch>(ar, nq);
+    int32_t* d_n = arena_take<int32_t>(ar, 4);
+    double* d_gap = arena_take<double>(ar, 1);
+    int32_t hn[3] = {nq, nt, 0};
+    VS_HIP(hipMemcpyAsync(d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_n, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_gap, &frame_gap, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_match(d_q, 0, d_n, d_t, 0, d_n + 1, d_gap, gate, c->p.match_ratio, c->p.match_gap_thr, 1, rows, c->match.d_train_best,
+                           d_out, nq, d_n + 2, c->stream))) return rc;
+    int32_t m = 0;
+    VS_HIP(hipMemcpyAsync(&m, d_n + 2, sizeof(m), hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    if (m > 0) VS_HIP(hipMemcpy(out, d_out, sizeof(vslam_dmatch) * m, hipMemcpyDeviceToHost));
+    *n_out = m;
+    return VSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- geometry
+int vslam_find_3d_disparity(vslam_ctx* ctx, const vslam_keypoint* kps, int n, const float* disparity, int w, int h, int dstride,
+                            const double T_c_w[7], float* xyz_w, uint8_t* valid, uint8_t* reliable, int* n_valid) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || n < 0 || !disparity || !T_c_w || w <= 0 || h <= 0 || dstride < w || (n > 0 && (!kps || !xyz_w || !valid || !reliable))) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if (n_valid) *n_valid = 0;
+    if (n == 0) return VSLAM_OK;
+    VS_HIP(hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reserve(c, al256(sizeof(vslam_keypoint) * n) + al256(sizeof(float) * (size_t)dstride * h) + al256(12 * (size_t)n) + 2 * al256(n) + 1024))) return rc;
+    Arena ar(c);
+    vslam_keypoint* d_k = arena_take<vslam_keypoint>(ar, n);
+    float* d_d = arena_take<float>(ar, (size_t)dstride * h);
+    double* d_T = arena_take<double>(ar, 7);
+    float* d_x = arena_take<float>(ar, 3 * (size_t)n);
+    uint8_t* d_v = arena_take<uint8_t>(ar, n);
+    uint8_t* d_r = arena_take<uint8_t>(ar, n);
+    VS_HIP(hipMemcpyAsync(d_k, kps, sizeof(vslam_keypoint) * n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_d, disparity, sizeof(float) * (size_t)dstride * h, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_T, T_c_w, sizeof(double) * 7, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_find3d_disparity(d_k, n, d_d, w, h, dstride, d_T, cam_of(c), d_x, d_v, d_r, c->stream))) return rc;
+    VS_HIP(hipMemcpyAsync(xyz_w, d_x, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(valid, d_v, n, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(reliable, d_r, n, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    if (n_valid) { int k = 0; for (int i = 0; i < n; ++i) k += valid[i] != 0; *n_valid = k; }
+    return VSLAM_OK;
+}
+
+int vslam_triangulate_dev(vslam_ctx* ctx, const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B,
+                          const double* d_T_c_w, float* d_xyz_w, uint8_t* d_valid, uint8_t* d_reliable) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_uvL || !d_uvR || !d_n || !d_T_c_w || !d_xyz_w || !d_valid || !d_reliable || capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    return launch_triangulate(d_uvL, d_uvR, d_n, capacity, B, d_T_c_w, cam_of(c), d_xyz_w, d_valid, d_reliable, c->stream);
+}
+
+int vslam_triangulate(vslam_ctx* ctx, const float* uvL, const float* uvR, int n, const double T_c_w[7], float* xyz_w, uint8_t* valid,
+                      uint8_t* reliable, int* n_valid) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || n < 0 || !T_c_w || (n > 0 && (!uvL || !uvR || !xyz_w || !valid || !reliable))) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if (n_valid) *n_valid = 0;
+    if (n == 0) return VSLAM_OK;
+    VS_HIP(hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reserve(c, 2 * al256(8 * (size_t)n) + al256(12 * (size_t)n) + 2 * al256(n) + 2048))) return rc;
+    Arena ar(c);
+    float* d_l = arena_take<float>(ar, 2 * (size_t)n);
+    float* d_r = arena_take<float>(ar, 2 * (size_t)n);
+    double* d_T = arena_take<double>(ar, 7);
+    int32_t* d_n = arena_take<int32_t>(ar, 1);
+    float* d_x = arena_take<float>(ar, 3 * (size_t)n);
+    uint8_t* d_v = arena_take<uint8_t>(ar, n);
+    uint8_t* d_rel = arena_take<uint8_t>(ar, n);
+    int32_t nn = n;
+    VS_HIP(hipMemcpyAsync(d_l, uvL, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_r, uvR, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_T, T_c_w, 56, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_n, &nn, 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_triangulate(d_l, d_r, d_n, n, 1, d_T, cam_of(c), d_x, d_v, d_rel, c->stream))) return rc;
+    VS_HIP(hipMemcpyAsync(xyz_w, d_x, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(valid, d_v, n, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(reliable, d_rel, n, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    if (n_valid) { int k = 0; for (int i = 0; i < n; ++i) k += valid[i] != 0; *n_valid = k; }
+    return VSLAM_OK;
+}
+
+int vslam_gather_matched_uv_dev(vslam_ctx* ctx, const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT, int kp_capacity,
+                                const vslam_dmatch* d_matches, const int32_t* d_nmatch, int match_capacity, int B, float* d_uvQ, float* d_uvT) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_kpsQ || !d_kpsT || !d_matches || !d_nmatch || !d_uvQ || !d_uvT || kp_capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    return launch_gather_uv(d_kpsQ, d_kpsT, kp_capacity, d_matches, d_nmatch, match_capacity, B, d_uvQ, d_uvT, c->stream);
+}
+
+int vslam_check_motion(int num_inliers, const double T_c_l[7], double frame_gap) {
+    if (!T_c_l) return 0;
+    if (num_inliers < 10) return 0; // visual_odometry.cpp:319
+    double xi[6];
+    se3::log(T_c_l, xi);            // :327
+    double s = 0;
+    for (int i = 0; i < 6; ++i) s += xi[i] * xi[i];
+    return std::sqrt(s) > 5.0 * frame_gap ? 0 : 1; // :329
+}
+
+// ---------------------------------------------------------------------------------------------- motion-only pose
+static void fill_K(const Ctx* c, double K[4]) { K[0] = c->p.cam[0]; K[1] = c->p.cam[1]; K[2] = c->p.cam[2]; K[3] = c->p.cam[3]; }
+
+int vslam_pnp_motion_only_dev(vslam_ctx* ctx, const float* d_xyz_w, const float* d_uv, const int32_t* d_n, int capacity, int B,
+                              double* d_T_c_w, int iters, uint8_t* d_inlier, int32_t* d_n_inliers) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_xyz_w || !d_uv || !d_n || !d_T_c_w || capacity <= 0 || iters < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    PnpArgs p;
+    memset(&p, 0, sizeof(p));
+    p.xyz = d_xyz_w; p.uv = d_uv; p.n = d_n; p.capacity = capacity; p.B = B; p.T = d_T_c_w; p.iters = iters;
+    fill_K(c, p.K); p.huber_delta = c->p.huber_delta; p.reproj_thr = c->p.pnp_reproj_thr;
+    p.inlier = d_inlier; p.n_inliers = d_n_inliers; p.stats = nullptr;
+    return launch_pnp(p, c->stream);
+}
+
+int vslam_pnp_motion_only(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int iters, uint8_t* inlier,
+                          int* n_inliers, vslam_lm_stats* stats) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !xyz_w || !uv || n <= 0 || !T_c_w || iters < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_HIP(hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reserve(c, al256(12 * (size_t)n) + al256(8 * (size_t)n) + al256(n) + al256(sizeof(vslam_lm_stats)) + 2048))) return rc;
+    Arena ar(c);
+    float* d_x = arena_take<float>(ar, 3 * (size_t)n);
+    float* d_u = arena_take<float>(ar, 2 * (size_t)n);
+    double* d_T = arena_take<double>(ar, 7);
+    int32_t* d_n = arena_take<int32_t>(ar, 2);
+    uint8_t* d_in = arena_take<uint8_t>(ar, n);
+    vslam_lm_stats* d_st = arena_take<vslam_lm_stats>(ar, 1);
+    int32_t nn = n;
+    VS_HIP(hipMemcpyAsync(d_x, xyz_w, 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_u, uv, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_T, T_c_w, 56, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_n, &nn, 4, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemsetAsync(d_st, 0, sizeof(vslam_lm_stats), c->stream));
+    PnpArgs p;
+    memset(&p, 0, sizeof(p));
+    p.xyz = d_x; p.uv = d_u; p.n = d_n; p.capacity = n; p.B = 1; p.T = d_T; p.iters = iters;
+    fill_K(c, p.K); p.huber_delta = c->p.huber_delta; p.reproj_thr = c->p.pnp_reproj_thr;
+    p.inlier = d_in; p.n_inliers = d_n + 1; p.stats = d_st;
+    if ((rc = launch_pnp(p, c->stream))) return rc;
+    int32_t ni = 0;
+    VS_HIP(hipMemcpyAsync(T_c_w, d_T, 56, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(&ni, d_n + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    if (inlier) VS_HIP(hipMemcpyAsync(inlier, d_in, n, hipMemcpyDeviceToHost, c->stream));
+    if (stats) VS_HIP(hipMemcpyAsync(stats, d_st, sizeof(vslam_lm_stats), hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    if (n_inliers) *n_inliers = ni;
+    return VSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- window optimisation
+// Shared host wrapper of optimize_map / optimize_pose_only: stable-sorts the caller's edges by landmark (the
+// kernel's CSR contract), runs one pass on the GPU, un-permutes chi2 and applies the chi2 classification of
+// optimization.cpp:224-266 on the host with the caller's flag_lm (quirk Q1 lives in the caller's edge list).
+static int window_host(vslam_ctx* ctx, int mode, int n_kf, double* T_c_w, int n_lm, float* xyz, int n_edge, const int32_t* kf_idx,
+                       const int32_t* lm_idx, const float* uv, const int32_t* flag_lm, int iters, int update_poses, int update_lms,
+                       uint8_t* lm_inlier, double* chi2_out, double* thr_out, vslam_lm_stats* stats) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || n_kf <= 0 || n_kf > VSLAM_MAX_KF || !T_c_w || n_lm <= 0 || !xyz || n_edge <= 0 || !kf_idx || !lm_idx || !uv || iters < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    for (int e = 0; e < n_edge; ++e)
+        if (kf_idx[e] < 0 || kf_idx[e] >= n_kf || lm_idx[e] < 0 || lm_idx[e] >= n_lm || (flag_lm && (flag_lm[e] < -1 || flag_lm[e] >= n_lm))) { set_error("edge %d: index out of range", e); return VSLAM_ERR_ARG; }
+    // counting sort by landmark (stable)
+    std::vector<int32_t> ptr(n_lm + 1, 0), perm(n_edge), skf(n_edge), slm(n_edge);
+    std::vector<float> suv(2 * (size_t)n_edge);
+    for (int e = 0; e < n_edge; ++e) ptr[lm_idx[e] + 1]++;
+    for (int l = 0; l < n_lm; ++l) ptr[l + 1] += ptr[l];
+    { std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1); for (int e = 0; e < n_edge; ++e) perm[fill[lm_idx[e]]++] = e; }
+    for (int j = 0; j < n_edge; ++j) { const int e = perm[j]; skf[j] = kf_idx[e]; slm[j] = lm_idx[e]; suv[2 * j] = uv[2 * e]; suv[2 * j + 1] = uv[2 * e + 1]; }
+    VS_HIP(hipSetDevice(c->device));
+    int rc;
+    const size_t need = al256(56 * (size_t)n_kf) + al256(12 * (size_t)n_lm) + al256(n_lm) + 3 * al256(4 * (size_t)n_edge) + al256(8 * (size_t)n_edge) * 2 +
+                        al256(sizeof(vslam_lm_stats)) + 4096;
+    if ((rc = arena_reserve(c, need))) return rc;
+    Arena ar(c);
+    double* d_T = arena_take<double>(ar, 7 * (size_t)n_kf);
+    float* d_xyz = arena_take<float>(ar, 3 * (size_t)n_lm);
+    uint8_t* d_inl = arena_take<uint8_t>(ar, n_lm);
+    int32_t* d_kf = arena_take<int32_t>(ar, n_edge);
+    int32_t* d_lm = arena_take<int32_t>(ar, n_edge);
+    float* d_uv = arena_take<float>(ar, 2 * (size_t)n_edge);
+    double* d_chi = arena_take<double>(ar, n_edge);
+    int32_t* d_off = arena_take<int32_t>(ar, 4);
+    vslam_lm_stats* d_st = arena_take<vslam_lm_stats>(ar, 1);
+    double* d_thr = arena_take<double>(ar, 1);
+    const int32_t off[4] = {0, n_lm, 0, n_edge};
+    VS_HIP(hipMemcpyAsync(d_T, T_c_w, 56 * (size_t)n_kf, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_xyz, xyz, 12 * (size_t)n_lm, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemsetAsync(d_inl, 1, n_lm, c->stream)); // the caller already filtered the graph (optimization.cpp:160 / :334)
+    VS_HIP(hipMemcpyAsync(d_kf, skf.data(), 4 * (size_t)n_edge, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_lm, slm.data(), 4 * (size_t)n_edge, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_uv, suv.data(), 8 * (size_t)n_edge, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_off, off, sizeof(off), hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemsetAsync(d_st, 0, sizeof(vslam_lm_stats), c->stream));
+    VS_HIP(hipMemsetAsync(d_chi, 0, 8 * (size_t)n_edge, c->stream));
+    LmWindowArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_windows = 1; a.n_kf = n_kf; a.lm_off = d_off; a.edge_off = d_off + 2; a.T = d_T; a.xyz = d_xyz; a.reliable = nullptr;
+    a.lm_inlier = d_inl; a.kf_idx = d_kf; a.lm_idx = d_lm; a.uv = d_uv; a.chi2 = d_chi; a.stats = d_st; a.chi2_thr = d_thr;
+    fill_K(c, a.K); a.huber_delta = c->p.huber_delta; a.total_lm = n_lm; a.total_edge = n_edge;
+    if ((rc = launch_lm_windows(a, 0, mode, iters, update_poses, update_lms, c->stream))) return rc;
+    int32_t status = 0;
+    if ((rc = lm_fetch_status(1, &status, c->stream))) return rc;
+    if (status != VSLAM_OK) { set_error("window optimisation rejected the graph (duplicate (keyframe, landmark) edge or bad index)"); return status; }
+    std::vector<double> chi(n_edge), chi_sorted(n_edge);
+    VS_HIP(hipMemcpy(chi_sorted.data(), d_chi, 8 * (size_t)n_edge, hipMemcpyDeviceToHost));
+    for (int j = 0; j < n_edge; ++j) chi[perm[j]] = chi_sorted[j];
+    if (update_poses) VS_HIP(hipMemcpy(T_c_w, d_T, 56 * (size_t)n_kf, hipMemcpyDeviceToHost));
+    if (mode == 0 && update_lms) VS_HIP(hipMemcpy(xyz, d_xyz, 12 * (size_t)n_lm, hipMemcpyDeviceToHost));
+    if (stats) VS_HIP(hipMemcpy(stats, d_st, sizeof(vslam_lm_stats), hipMemcpyDeviceToHost));
+    if (chi2_out) memcpy(chi2_out, chi.data(), 8 * (size_t)n_edge);
+    // adaptive threshold + flags (optimization.cpp:224-266), caller's edge order
+    double th = 5.991;
+    for (int iteration = 0; iteration < 5; ++iteration) {
+        int out = 0, in = 0;
+        for (int e = 0; e < n_edge; ++e) { if (chi[e] > th) ++out; else ++in; }
+        if (in / double(in + out) > 0.5) break;
+        th *= 2;
+    }
+    if (lm_inlier)
+        for (int e = 0; e < n_edge; ++e) {
+            const int l = flag_lm ? flag_lm[e] : lm_idx[e];
+            if (l >= 0) lm_inlier[l] = !(chi[e] > th);
+        }
+    if (thr_out) *thr_out = th;
+    return VSLAM_OK;
+}
+
+int vslam_local_ba(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, float* xyz, int n_edge, const int32_t* kf_idx, const int32_t* lm_idx,
+                   const float* uv, const int32_t* flag_lm, int iters, int update_poses, int update_lms, uint8_t* lm_inlier, double* chi2_out,
+                   double* chi2_threshold_out, vslam_lm_stats* stats) {
+    return window_host(ctx, 0, n_kf, T_c_w, n_lm, xyz, n_edge, kf_idx, lm_idx, uv, flag_lm, iters, update_poses, update_lms, lm_inlier, chi2_out,
+                       chi2_threshold_out, stats);
+}
+
+int vslam_pose_only_window(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, const float* xyz, int n_edge, const int32_t* kf_idx,
+                           const int32_t* lm_idx, const float* uv, const int32_t* flag_lm, int iters, int update_poses, uint8_t* lm_inlier,
+                           double* chi2_out, double* chi2_threshold_out, vslam_lm_stats* stats) {
+    return window_host(ctx, 1, n_kf, T_c_w, n_lm, const_cast<float*>(xyz), n_edge, kf_idx, lm_idx, uv, flag_lm, iters, update_poses, 0, lm_inlier,
+                       chi2_out, chi2_threshold_out, stats);
+}
+
+int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* b, int schedule, int mode, int iters, int update_poses, int update_lms) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !b || b->n_windows <= 0 || !b->d_lm_off || !b->d_edge_off || !b->d_T_c_w || !b->d_xyz || !b->d_lm_inlier || !b->d_kf_idx ||
+        !b->d_lm_idx || !b->d_uv || b->total_lm <= 0 || b->total_edge <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    LmWindowArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_windows = b->n_windows; a.n_kf = b->n_kf; a.lm_off = b->d_lm_off; a.edge_off = b->d_edge_off; a.T = b->d_T_c_w; a.xyz = b->d_xyz;
+    a.reliable = b->d_reliable; a.lm_inlier = b->d_lm_inlier; a.kf_idx = b->d_kf_idx; a.lm_idx = b->d_lm_idx; a.uv = b->d_uv;
+    a.chi2 = b->d_chi2; a.stats = b->d_stats; a.chi2_thr = nullptr;
+    fill_K(c, a.K); a.huber_delta = c->p.huber_delta; a.total_lm = b->total_lm; a.total_edge = b->total_edge;
+    return launch_lm_windows(a, schedule, mode, iters, update_poses, update_lms, c->stream);
+}
+
+int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !h_status || n_windows <= 0) return VSLAM_ERR_ARG;
+    return lm_fetch_status(n_windows, h_status, c->stream);
+}
+
+// ---------------------------------------------------------------------------------------------- raw device memory helpers
+// (for hosts that do not bring their own allocator; bench.py uses torch tensors instead)
+int vslam_dev_alloc(void** p, size_t bytes) { if (!p) return VSLAM_ERR_ARG; VS_HIP(hipMalloc(p, bytes)); return VSLAM_OK; }
+int vslam_dev_free(void* p) { if (p) VS_HIP(hipFree(p)); return VSLAM_OK; }
+int vslam_dev_upload(vslam_ctx* ctx, void* d, const void* h, size_t bytes) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return VSLAM_ERR_ARG;
+    VS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    return VSLAM_OK;
+}
+int vslam_dev_download(vslam_ctx* ctx, void* h, const void* d, size_t bytes) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return VSLAM_ERR_ARG;
+    VS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    return VSLAM_OK;
+}
+int vslam_dev_memset(vslam_ctx* ctx, void* d, int value, size_t bytes) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return VSLAM_ERR_ARG;
+    VS_HIP(hipMemsetAsync(d, value, bytes, c->stream));
+    return VSLAM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,123 @@
+// geom_kernels.hip -- K8: keypoint depth -> world landmarks and the device glue around it.
+//
+//  * find3d_disparity_kernel : Frame::find_3d (/root/reference/src/stereo_visual_slam_main/types_def.cpp:9-18) +
+//                              the gates of VO::set_ref_3d_position (visual_odometry.cpp:176-217) on a disparity map.
+//  * triangulate_kernel      : north_star stage K8 -- rectified-stereo inhomogeneous DLT on matched (uL,vL),(uR,vR)
+//                              with the same gates/outputs (the reference gets depth from cv::StereoSGBM instead).
+//  * gather_uv_kernel        : matched keypoint coordinates -> SoA (coalesced 8-B stores).
+// All f64 math, f32 at rest (cv::Point3f, quirk Q4).  Elementwise, HBM-bound: 16 B in + 14 B out per match.
+#include "vslam_internal.h"
+
+#include "se3_device.h"
+
+namespace vslam {
+
+__device__ inline void gate_store(const double rel[3], const double Rinv[9], const double tinv[3], const CamParams& cam, size_t i,
+                                  float* xyz, uint8_t* valid, uint8_t* reliable) {
+    const double X = rel[0], Y = rel[1], Z = rel[2];
+    const double wx = Rinv[0] * X + Rinv[1] * Y + Rinv[2] * Z + tinv[0];
+    const double wy = Rinv[3] * X + Rinv[4] * Y + Rinv[5] * Z + tinv[1];
+    const double wz = Rinv[6] * X + Rinv[7] * Y + Rinv[8] * Z + tinv[2];
+    const bool ok = (Z > cam.dmin && Z < cam.dmax);  // visual_odometry.cpp:194
+    valid[i] = ok;
+    reliable[i] = ok && Z < cam.drel;                // :201
+    xyz[3 * i] = (float)wx; xyz[3 * i + 1] = (float)wy; xyz[3 * i + 2] = (float)wz;
+}
+
+__device__ inline void inverse_pose(const double* T, double Rinv[9], double tinv[3]) {
+    double R[9];
+    se3::rotmat(T, R);
+    // T^-1 = (R^T, -R^T t)
+    Rinv[0] = R[0]; Rinv[1] = R[3]; Rinv[2] = R[6];
+    Rinv[3] = R[1]; Rinv[4] = R[4]; Rinv[5] = R[7];
+    Rinv[6] = R[2]; Rinv[7] = R[5]; Rinv[8] = R[8];
+    for (int a = 0; a < 3; ++a) tinv[a] = -(Rinv[3 * a] * T[4] + Rinv[3 * a + 1] * T[5] + Rinv[3 * a + 2] * T[6]);
+}
+
+__global__ __launch_bounds__(256) void find3d_disparity_kernel(const vslam_keypoint* __restrict__ kps, int n, const float* __restrict__ disp,
+                                                              int w, int h, int dstride, const double* __restrict__ T, CamParams cam,
+                                                              float* __restrict__ xyz, uint8_t* __restrict__ valid, uint8_t* __restrict__ rel) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double Rinv[9], tinv[3];
+    inverse_pose(T, Rinv, tinv);
+    const float u = kps[i].x, v = kps[i].y;
+    const int r = (int)v, c = (int)u; // at<float>(kp.pt.y, kp.pt.x): float -> int truncation (quirk Q3)
+    if (r < 0 || r >= h || c < 0 || c >= w) { valid[i] = 0; rel[i] = 0; xyz[3 * i] = xyz[3 * i + 1] = xyz[3 * i + 2] = 0.f; return; }
+    const double x = ((double)u - cam.cx) / cam.fx, y = ((double)v - cam.cy) / cam.fy;
+    const double depth = cam.fx * cam.b / (double)disp[(size_t)r * dstride + c];
+    const double p[3] = {x * depth, y * depth, depth};
+    gate_store(p, Rinv, tinv, cam, i, xyz, valid, rel);
+}
+
+__global__ __launch_bounds__(256) void triangulate_kernel(const float* __restrict__ uvL, const float* __restrict__ uvR,
+                                                         const int32_t* __restrict__ d_n, int capacity, const double* __restrict__ d_T,
+                                                         CamParams cam, float* __restrict__ xyz, uint8_t* __restrict__ valid,
+                                                         uint8_t* __restrict__ rel) {
+    const int b = blockIdx.y;
+    const int n = min(d_n[b], capacity);
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const size_t i = (size_t)b * capacity + k;
+    double Rinv[9], tinv[3];
+    inverse_pose(d_T + 7 * b, Rinv, tinv);
+    const float2 l = reinterpret_cast<const float2*>(uvL)[i], r = reinterpret_cast<const float2*>(uvR)[i];
+    const double fx = cam.fx, fy = cam.fy, bl = cam.b;
+    const double aL = (double)l.x - cam.cx, bL = (double)l.y - cam.cy, aR = (double)r.x - cam.cx, bR = (double)r.y - cam.cy;
+    // rows: [fx 0 -aL | 0], [0 fy -bL | 0], [fx 0 -aR | fx b], [0 fy -bR | 0]  -> normal equations, X and Y eliminated
+    const double n00 = 2 * fx * fx, n11 = 2 * fy * fy;
+    const double n02 = -fx * (aL + aR), n12 = -fy * (bL + bR);
+    const double n22 = aL * aL + bL * bL + aR * aR + bR * bR;
+    const double r0 = fx * fx * bl, r2 = -aR * fx * bl;
+    const double s22 = n22 - n02 * n02 / n00 - n12 * n12 / n11;
+    const double s2 = r2 - n02 * r0 / n00;
+    const double Z = s2 / s22;
+    double p[3] = {(r0 - n02 * Z) / n00, (0.0 - n12 * Z) / n11, Z};
+    if (!(s22 > 0) || !isfinite(Z)) { p[0] = p[1] = 0; p[2] = -1; }
+    gate_store(p, Rinv, tinv, cam, i, xyz, valid, rel);
+}
+
+__global__ __launch_bounds__(256) void gather_uv_kernel(const vslam_keypoint* __restrict__ kpsQ, const vslam_keypoint* __restrict__ kpsT,
+                                                       int kp_capacity, const vslam_dmatch* __restrict__ m, const int32_t* __restrict__ nm,
+                                                       int match_capacity, float* __restrict__ uvQ, float* __restrict__ uvT) {
+    const int b = blockIdx.y;
+    const int n = min(nm[b], match_capacity);
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const size_t i = (size_t)b * match_capacity + k;
+    const vslam_dmatch mm = m[i];
+    const int qi = min(max(mm.queryIdx, 0), kp_capacity - 1), ti = min(max(mm.trainIdx, 0), kp_capacity - 1);
+    const vslam_keypoint* q = kpsQ + (size_t)b * kp_capacity + qi;
+    const vslam_keypoint* t = kpsT + (size_t)b * kp_capacity + ti;
+    reinterpret_cast<float2*>(uvQ)[i] = make_float2(q->x, q->y);
+    reinterpret_cast<float2*>(uvT)[i] = make_float2(t->x, t->y);
+}
+
+int launch_find3d_disparity(const vslam_keypoint* d_kps, int n, const float* d_disp, int w, int h, int dstride, const double* d_T,
+                            CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream) {
+    if (n <= 0) return VSLAM_OK;
+    hipLaunchKernelGGL(find3d_disparity_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_kps, n, d_disp, w, h, dstride, d_T, cam,
+                       d_xyz, d_valid, d_rel);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+int launch_triangulate(const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B, const double* d_T, CamParams cam,
+                       float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream) {
+    if (B <= 0 || capacity <= 0) return VSLAM_OK;
+    hipLaunchKernelGGL(triangulate_kernel, dim3((capacity + 255) / 256, B), dim3(256), 0, stream, d_uvL, d_uvR, d_n, capacity, d_T, cam,
+                       d_xyz, d_valid, d_rel);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+int launch_gather_uv(const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT, int kp_capacity, const vslam_dmatch* d_m,
+                     const int32_t* d_nm, int match_capacity, int B, float* d_uvQ, float* d_uvT, hipStream_t stream) {
+    if (B <= 0 || match_capacity <= 0) return VSLAM_OK;
+    hipLaunchKernelGGL(gather_uv_kernel, dim3((match_capacity + 255) / 256, B), dim3(256), 0, stream, d_kpsQ, d_kpsT, kp_capacity, d_m,
+                       d_nm, match_capacity, d_uvQ, d_uvT);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+} // namespace vslam

@@ -1,0 +1,781 @@
+// lm_kernels.hip -- K9..K12: Levenberg-Marquardt back-end on the GPU.
+//
+// Replaces the g2o optimiser inside optimize_map and optimize_pose_only
+// (/root/reference/src/stereo_visual_slam_main/optimization.cpp:103-288, :290-436) and serves the north_star
+// motion-only pose stage that stands in for cv::solvePnPRansac (visual_odometry.cpp:277).
+//   residuals / Jacobians   : EdgeProjection (optimization.cpp:41-73), PoseOnlyEdgeProjection (:75-101)
+//   vertex updates          : T <- exp(d) * T (:26-32), p <- p + d (:34-39)
+//   optimiser               : g2o Levenberg (lambda0 = 1e-5 max diag H, accept: lambda *= max(1/3, min(2/3, 1-(2rho-1)^3)),
+//                             reject: lambda *= ni, ni *= 2, <= 10 trials), Huber kernel (delta = 5.991), Schur
+//                             complement on the landmarks, Cholesky on the reduced (6 n_kf)^2 system.
+//
+// gfx950 mapping: ONE WORKGROUP PER WINDOW runs the whole LM loop persistently (no host round trips; a batch of
+// windows fills the 256 CUs).  All sums are f64 with a FIXED order (no floating-point atomics):
+//   - per-landmark blocks (Hll, b_l, Dinv)      : one lane per landmark over its CSR edge range
+//   - per-pose blocks (Hpp, b_p, W*db)          : one wave per pose over a by-pose edge list, butterfly reduce
+//   - Schur blocks S[k1][k2]                    : one wave per keyframe pair over a precomputed hit list
+//                                                 (edge pairs sharing a landmark), butterfly reduce, single owner
+//   - reduced system                            : right-looking Cholesky in LDS by the whole workgroup
+// Landmarks and pixels are f32 at rest (quirk Q4); poses, accumulators and the LM state are f64.
+// No MFMA: the largest dense object is the 72x72 reduced system; the path is latency/f64-VALU bound.
+#include "vslam_internal.h"
+
+#include "se3_device.h"
+
+namespace vslam {
+
+constexpr int kLmBlock = 256;
+constexpr int kLmWaves = kLmBlock / 64;
+constexpr int kMaxKf = VSLAM_MAX_KF;
+constexpr int kMaxNp = 6 * kMaxKf;
+constexpr int kMaxPairs = kMaxKf * (kMaxKf + 1) / 2;
+constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
+
+size_t lm_hits_per_edge() { return kHitsPerEdge; }
+
+struct LmShared {
+    double S[kMaxNp * kMaxNp];
+    double Hpp[kMaxKf * 36];
+    double bp[kMaxNp], bs[kMaxNp], xp[kMaxNp];
+    double Rt[kMaxKf * 12], RtTrial[kMaxKf * 12];
+    double T[kMaxKf * 7], TTrial[kMaxKf * 7];
+    double red[kLmWaves * 2];
+    double sc[8];
+    int cnt[kMaxPairs + 2];
+    int flag[8];
+};
+
+struct LmKernelArgs {
+    LmWindowArgs a;
+    // implicit single-pose problems (PnP): edge e <-> point e, keyframe 0
+    const int32_t* pnp_n;
+    int capacity;
+    uint8_t* act;     // total_lm
+    uint8_t* eo;      // total_lm x kMaxKf
+    int32_t* status;  // n_windows
+};
+
+__device__ inline double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// deterministic block sum: per-thread partial -> wave butterfly -> waves summed in order
+__device__ inline double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0;
+    for (int w = 0; w < kLmWaves; ++w) s += red[w];
+    return s;
+}
+__device__ inline double block_max(double v, double* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+    for (int w = 1; w < kLmWaves; ++w) s = fmax(s, red[w]);
+    return s;
+}
+
+__device__ inline void expand_pose(const double* T, double* Rt) {
+    se3::rotmat(T, Rt);
+    Rt[9] = T[4]; Rt[10] = T[5]; Rt[11] = T[6];
+}
+
+__device__ inline void huber(double e, double delta, double& rho, double& w) {
+    const double dsqr = delta * delta;
+    if (e <= dsqr) { rho = e; w = 1.0; }
+    else { const double s = sqrt(e); rho = 2 * s * delta - dsqr; w = delta / s; }
+}
+
+// 2x6 pose Jacobian of the reprojection error; mode 0: EdgeProjection (Zinv = 1/(Z+1e-18)), mode 1: PoseOnlyEdgeProjection
+__device__ inline void jac_pose(const double* K, double X, double Y, double Z, int mode, double A[12]) {
+    const double fx = K[0], fy = K[1];
+    if (mode == 0) {
+        const double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;
+        A[0] = -fx * Zinv; A[1] = 0; A[2] = fx * X * Zinv2; A[3] = fx * X * Y * Zinv2; A[4] = -fx - fx * X * X * Zinv2; A[5] = fx * Y * Zinv;
+        A[6] = 0; A[7] = -fy * Zinv; A[8] = fy * Y * Zinv2; A[9] = fy + fy * Y * Y * Zinv2; A[10] = -fy * X * Y * Zinv2; A[11] = -fy * X * Zinv;
+    } else {
+        const double Z2 = Z * Z;
+        A[0] = -fx / Z; A[1] = 0; A[2] = fx * X / Z2; A[3] = fx * X * Y / Z2; A[4] = -fx - fx * X * X / Z2; A[5] = fx * Y / Z;
+        A[6] = 0; A[7] = -fy / Z; A[8] = fy * Y / (Z * Z); A[9] = fy + fy * Y * Y / Z2; A[10] = -fy * X * Y / Z2; A[11] = -fy * X / Z;
+    }
+}
+// 2x3 landmark Jacobian = A[:, 0:3] * R
+__device__ inline void jac_point(const double A[12], const double* R, double B[6]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) B[r * 3 + c] = A[r * 6] * R[c] + A[r * 6 + 1] * R[3 + c] + A[r * 6 + 2] * R[6 + c];
+}
+
+__device__ inline void project_err(const double* Rt, const double* K, double px, double py, double pz, float u, float v, double& X,
+                                   double& Y, double& Z, double& ex, double& ey) {
+    X = Rt[0] * px + Rt[1] * py + Rt[2] * pz + Rt[9];
+    Y = Rt[3] * px + Rt[4] * py + Rt[5] * pz + Rt[10];
+    Z = Rt[6] * px + Rt[7] * py + Rt[8] * pz + Rt[11];
+    const double qx = K[0] * X + K[2] * Z, qy = K[1] * Y + K[3] * Z;
+    ex = (double)u - qx / Z;
+    ey = (double)v - qy / Z;
+}
+
+__device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double Di[6]) {
+    // symmetric [[a b c],[b d e],[c e f]] -> unique entries of the inverse (00 01 02 11 12 22)
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double id = 1.0 / det;
+    Di[0] = c00 * id; Di[1] = c01 * id; Di[2] = c02 * id;
+    Di[3] = (a * f - c * c) * id; Di[4] = (b * c - a * e) * id; Di[5] = (a * d - b * b) * id;
+    return isfinite(id);
+}
+
+// 6x6 SPD solve by one thread (pose-only mode); returns false if not positive definite
+__device__ inline bool chol6_solve(const double* H, double lambda, const double* b, double* x) {
+    double L[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) L[i] = H[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) L[7 * i] += lambda;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = L[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(d > 0.0) || !isfinite(d)) ok = false;
+        d = sqrt(d);
+        L[j * 6 + j] = d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (i > j) {
+                double s = L[i * 6 + j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (k < j) s -= L[i * 6 + k] * L[j * 6 + k];
+                L[i * 6 + j] = s / d;
+            }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < i) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k > i) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    return ok;
+}
+
+template <bool IMPL>
+__global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, int mode, int iters, int update_poses, int update_lms,
+                                                            int classify) {
+    const LmWindowArgs& a = ka.a;
+    __shared__ LmShared sm;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nk = a.n_kf, np = 6 * nk;
+    int lm0, nl, e0, ne;
+    if (IMPL) { nl = min(max(ka.pnp_n[w], 0), ka.capacity); lm0 = w * ka.capacity; e0 = lm0; ne = nl; }
+    else { lm0 = a.lm_off[w]; nl = a.lm_off[w + 1] - lm0; e0 = a.edge_off[w]; ne = a.edge_off[w + 1] - e0; }
+    const float* xyz = a.xyz + 3 * (size_t)lm0;
+    const float* uv = a.uv + 2 * (size_t)e0;
+    const int32_t* kfi = IMPL ? nullptr : a.kf_idx + e0;
+    const int32_t* lmi = IMPL ? nullptr : a.lm_idx + e0;
+    double* P = a.P + 3 * (size_t)lm0;
+    double* Pt = a.Ptrial + 3 * (size_t)lm0;
+    double* Hll = a.Hll + 6 * (size_t)lm0;
+    double* bl = a.bl + 3 * (size_t)lm0;
+    double* Dinv = a.Dinv + 6 * (size_t)lm0;
+    double* db = a.db + 3 * (size_t)lm0;
+    double* lin = a.lin + 6 * (size_t)e0;
+    double* chi2 = a.chi2 + e0;
+    int32_t* lm_ptr = a.lm_ptr + lm0 + w;
+    int32_t* kf_ptr = a.kf_ptr + (size_t)w * (kMaxKf + 1);
+    int32_t* kf_edges = a.kf_edges + e0;
+    int32_t* pair_ptr = a.pair_ptr + (size_t)w * (kMaxPairs + 1);
+    int32_t* hits = a.pair_hits + 2 * (size_t)e0 * kHitsPerEdge;
+    uint8_t* act = ka.act + lm0;
+    uint8_t* eo = ka.eo + (size_t)lm0 * kMaxKf;
+    const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
+    const double delta = a.huber_delta;
+    const bool with_lm = (mode == 0);
+    auto EKF = [&](int e) -> int { return IMPL ? 0 : kfi[e]; };
+    auto ELM = [&](int e) -> int { return IMPL ? e : lmi[e]; };
+
+    // ------------------------------------------------------------------ setup
+    if (tid < 8) sm.flag[tid] = 0;
+    for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = a.T[(size_t)w * nk * 7 + i];
+    __syncthreads();
+    if (tid < nk) expand_pose(&sm.T[7 * tid], &sm.Rt[12 * tid]);
+    for (int l = tid; l < nl; l += kLmBlock) {
+        P[3 * l] = (double)xyz[3 * l]; P[3 * l + 1] = (double)xyz[3 * l + 1]; P[3 * l + 2] = (double)xyz[3 * l + 2];
+    }
+    if (!IMPL) {
+        // CSR by landmark from the sorted lm_idx; bad indices / unsorted input -> error flag
+        for (int e = tid; e < ne; e += kLmBlock) {
+            const int l = lmi[e], lp = e > 0 ? lmi[e - 1] : -1, k = kfi[e];
+            if (l < lp || l < 0 || l >= nl || k < 0 || k >= nk) { sm.flag[7] = 1; continue; }
+            for (int x = lp + 1; x <= l; ++x) lm_ptr[x] = e;
+            if (e == ne - 1) for (int x = l + 1; x <= nl; ++x) lm_ptr[x] = ne;
+        }
+        if (ne == 0) for (int x = tid; x <= nl; x += kLmBlock) lm_ptr[x] = 0;
+    }
+    __syncthreads();
+    if (sm.flag[7]) { // uniform
+        if (tid == 0) ka.status[w] = VSLAM_ERR_ARG;
+        return;
+    }
+    for (int l = tid; l < nl; l += kLmBlock) {
+        bool on = true;
+        if (!IMPL) {
+            on = lm_ptr[l + 1] > lm_ptr[l] && a.lm_inlier[lm0 + l] != 0;
+            if (with_lm && a.reliable) on = on && a.reliable[lm0 + l] != 0;
+        }
+        act[l] = on;
+    }
+    __syncthreads();
+    if (!IMPL) {
+        // by-pose edge lists (ascending edge id inside a pose): wave per keyframe, ballot-ordered append
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int k = wave; k < nk; k += kLmWaves) {
+                int base = pass ? kf_ptr[k] : 0;
+                for (int c = 0; c < ne; c += 64) {
+                    const int e = c + lane;
+                    const bool hit = e < ne && kfi[e] == k && act[lmi[e]];
+                    const unsigned long long m = __ballot(hit);
+                    if (pass && hit) kf_edges[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+                    base += __popcll(m);
+                }
+                if (!pass && lane == 0) sm.cnt[k] = base;
+            }
+            __syncthreads();
+            if (!pass) {
+                if (tid == 0) { int acc = 0; for (int k = 0; k < nk; ++k) { kf_ptr[k] = acc; acc += sm.cnt[k]; } kf_ptr[nk] = acc; }
+                __syncthreads();
+            }
+        }
+        if (with_lm) {
+            // per-landmark edge offset table, then the Schur hit lists per keyframe pair
+            for (int l = tid; l < nl; l += kLmBlock) {
+                for (int k = 0; k < nk; ++k) eo[(size_t)l * kMaxKf + k] = 0xFF;
+                if (act[l]) {
+                    const int b0 = lm_ptr[l], b1 = lm_ptr[l + 1];
+                    for (int e = b0; e < b1; ++e) {
+                        const int k = kfi[e];
+                        if (eo[(size_t)l * kMaxKf + k] != 0xFF || e - b0 >= 0xFF) sm.flag[7] = 2; // duplicate (kf, landmark) edge
+                        eo[(size_t)l * kMaxKf + k] = (uint8_t)(e - b0);
+                    }
+                }
+            }
+            __syncthreads();
+            if (sm.flag[7]) { if (tid == 0) ka.status[w] = VSLAM_ERR_ARG; return; }
+            const int npairs = nk * (nk + 1) / 2;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int p = wave; p < npairs; p += kLmWaves) {
+                    int k1 = 0, rem = p;
+                    while (rem >= nk - k1) { rem -= nk - k1; ++k1; }
+                    const int k2 = k1 + rem;
+                    int base = pass ? pair_ptr[p] : 0;
+                    for (int c = 0; c < nl; c += 64) {
+                        const int l = c + lane;
+                        uint8_t o1 = 0xFF, o2 = 0xFF;
+                        if (l < nl) { o1 = eo[(size_t)l * kMaxKf + k1]; o2 = eo[(size_t)l * kMaxKf + k2]; }
+                        const bool hit = o1 != 0xFF && o2 != 0xFF;
+                        const unsigned long long m = __ballot(hit);
+                        if (pass && hit) {
+                            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                            hits[2 * slot] = lm_ptr[l] + o1;
+                            hits[2 * slot + 1] = lm_ptr[l] + o2;
+                        }
+                        base += __popcll(m);
+                    }
+                    if (!pass && lane == 0) sm.cnt[p] = base;
+                }
+                __syncthreads();
+                if (!pass) {
+                    if (tid == 0) { int acc = 0; for (int p = 0; p < npairs; ++p) { pair_ptr[p] = acc; acc += sm.cnt[p]; } pair_ptr[npairs] = acc; }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ LM iterations
+    double lambda = 0, ni = 2, currentChi = 0;
+    int it = 0, total_trials = 0;
+    vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
+
+    // error evaluation at (Rt, Pcur); STORE_LIN also records the linearisation point
+    auto eval = [&](const double* Rt, const double* Pcur, bool store_lin) -> double {
+        double part = 0;
+        for (int e = tid; e < ne; e += kLmBlock) {
+            const int l = ELM(e);
+            if (!act[l]) continue;
+            const int k = EKF(e);
+            double X, Y, Z, ex, ey;
+            project_err(&Rt[12 * k], K, Pcur[3 * l], Pcur[3 * l + 1], Pcur[3 * l + 2], uv[2 * e], uv[2 * e + 1], X, Y, Z, ex, ey);
+            const double c = ex * ex + ey * ey;
+            chi2[e] = c;
+            double rho, wgt;
+            huber(c, delta, rho, wgt);
+            part += rho;
+            if (store_lin) { double* q = lin + 6 * (size_t)e; q[0] = X; q[1] = Y; q[2] = Z; q[3] = wgt; q[4] = ex; q[5] = ey; }
+        }
+        return block_sum(part, sm.red);
+    };
+
+    for (it = 0; it < iters; ++it) {
+        currentChi = eval(sm.Rt, P, true);
+        if (it == 0 && st && tid == 0) st->chi2_init = currentChi;
+        // ---- buildSystem: landmark blocks
+        double maxdiag = 0;
+        if (with_lm) {
+            for (int l = tid; l < nl; l += kLmBlock) {
+                if (!act[l]) continue;
+                double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+                for (int e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
+                    const double* q = lin + 6 * (size_t)e;
+                    double A[12], B[6];
+                    jac_pose(K, q[0], q[1], q[2], 0, A);
+                    jac_point(A, &sm.Rt[12 * EKF(e)], B);
+                    const double wg = q[3];
+                    h[0] += wg * (B[0] * B[0] + B[3] * B[3]); h[1] += wg * (B[0] * B[1] + B[3] * B[4]); h[2] += wg * (B[0] * B[2] + B[3] * B[5]);
+                    h[3] += wg * (B[1] * B[1] + B[4] * B[4]); h[4] += wg * (B[1] * B[2] + B[4] * B[5]); h[5] += wg * (B[2] * B[2] + B[5] * B[5]);
+                    g[0] -= wg * (B[0] * q[4] + B[3] * q[5]); g[1] -= wg * (B[1] * q[4] + B[4] * q[5]); g[2] -= wg * (B[2] * q[4] + B[5] * q[5]);
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Hll[6 * (size_t)l + i] = h[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) bl[3 * (size_t)l + i] = g[i];
+                maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
+            }
+        }
+        // ---- buildSystem: pose blocks (wave per pose)
+        for (int k = wave; k < nk; k += kLmWaves) {
+            double acc[27];
+#pragma unroll
+            for (int i = 0; i < 27; ++i) acc[i] = 0;
+            const int b0 = IMPL ? 0 : kf_ptr[k], b1 = IMPL ? ne : kf_ptr[k + 1];
+            for (int j = b0 + lane; j < b1; j += 64) {
+                const int e = IMPL ? j : kf_edges[j];
+                const double* q = lin + 6 * (size_t)e;
+                double A[12];
+                jac_pose(K, q[0], q[1], q[2], mode, A);
+                const double wg = q[3];
+                int idx = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c) acc[idx++] += wg * (A[r] * A[c] + A[6 + r] * A[6 + c]);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) acc[21 + r] -= wg * (A[r] * q[4] + A[6 + r] * q[5]);
+            }
+#pragma unroll
+            for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+            if (lane == 0) {
+                int idx = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c) { sm.Hpp[36 * k + 6 * r + c] = acc[idx]; sm.Hpp[36 * k + 6 * c + r] = acc[idx]; ++idx; }
+#pragma unroll
+                for (int r = 0; r < 6; ++r) sm.bp[6 * k + r] = acc[21 + r];
+            }
+        }
+        __syncthreads();
+        if (it == 0) { // computeLambdaInit: tau * max |H_jj| over every vertex
+            if (tid < np) maxdiag = fmax(maxdiag, fabs(sm.Hpp[36 * (tid / 6) + 7 * (tid % 6)]));
+            lambda = 1e-5 * block_max(maxdiag, sm.red);
+            ni = 2;
+        }
+        // ---- trial loop
+        double rho_gain = 0;
+        int qmax = 0;
+        bool again = true;
+        while (again) {
+            bool ok2 = true;
+            if (with_lm) {
+                // Dinv, db per landmark
+                int bad = 0;
+                for (int l = tid; l < nl; l += kLmBlock) {
+                    if (!act[l]) continue;
+                    const double* h = Hll + 6 * (size_t)l;
+                    double Di[6];
+                    if (!inv3_sym(h[0] + lambda, h[1], h[2], h[3] + lambda, h[4], h[5] + lambda, Di)) bad = 1;
+                    const double* g = bl + 3 * (size_t)l;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) Dinv[6 * (size_t)l + i] = Di[i];
+                    db[3 * (size_t)l] = Di[0] * g[0] + Di[1] * g[1] + Di[2] * g[2];
+                    db[3 * (size_t)l + 1] = Di[1] * g[0] + Di[3] * g[1] + Di[4] * g[2];
+                    db[3 * (size_t)l + 2] = Di[2] * g[0] + Di[4] * g[1] + Di[5] * g[2];
+                }
+                if (bad) sm.flag[1] = 1;
+                for (int i = tid; i < np * np; i += kLmBlock) sm.S[i] = 0;
+                __syncthreads(); // Dinv/db visible (global, same workgroup) + S zeroed
+                // bs[k] = bp[k] - sum_e W_e db_l   (wave per pose)
+                for (int k = wave; k < nk; k += kLmWaves) {
+                    double acc[6] = {0, 0, 0, 0, 0, 0};
+                    for (int j = kf_ptr[k] + lane; j < kf_ptr[k + 1]; j += 64) {
+                        const int e = kf_edges[j], l = lmi[e];
+                        const double* q = lin + 6 * (size_t)e;
+                        double A[12], B[6];
+                        jac_pose(K, q[0], q[1], q[2], 0, A);
+                        jac_point(A, &sm.Rt[12 * k], B);
+                        const double* d3 = db + 3 * (size_t)l;
+                        const double m0 = q[3] * (B[0] * d3[0] + B[1] * d3[1] + B[2] * d3[2]);
+                        const double m1 = q[3] * (B[3] * d3[0] + B[4] * d3[1] + B[5] * d3[2]);
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) acc[r] += A[r] * m0 + A[6 + r] * m1;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
+                    if (lane == 0)
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) sm.bs[6 * k + r] = sm.bp[6 * k + r] - acc[r];
+                }
+                // Schur blocks: S[k1][k2] = [k1==k2](Hpp + lambda I) - sum_hits W1 Dinv W2^T   (wave per pair)
+                const int npairs = nk * (nk + 1) / 2;
+                for (int p = wave; p < npairs; p += kLmWaves) {
+                    int k1 = 0, rem = p;
+                    while (rem >= nk - k1) { rem -= nk - k1; ++k1; }
+                    const int k2 = k1 + rem;
+                    double acc[36];
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) acc[i] = 0;
+                    for (int j = pair_ptr[p] + lane; j < pair_ptr[p + 1]; j += 64) {
+                        const int ea = hits[2 * j], eb = hits[2 * j + 1], l = lmi[ea];
+                        const double* qa = lin + 6 * (size_t)ea;
+                        const double* qb = lin + 6 * (size_t)eb;
+                        const double* Di = Dinv + 6 * (size_t)l;
+                        double A1[12], B1[6], A2[12], B2[6];
+                        jac_pose(K, qa[0], qa[1], qa[2], 0, A1);
+                        jac_point(A1, &sm.Rt[12 * k1], B1);
+                        jac_pose(K, qb[0], qb[1], qb[2], 0, A2);
+                        jac_point(A2, &sm.Rt[12 * k2], B2);
+                        // M (2x2) = (w1 B1) Dinv (w2 B2)^T
+                        double BD[6];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            BD[3 * r] = B1[3 * r] * Di[0] + B1[3 * r + 1] * Di[1] + B1[3 * r + 2] * Di[2];
+                            BD[3 * r + 1] = B1[3 * r] * Di[1] + B1[3 * r + 1] * Di[3] + B1[3 * r + 2] * Di[4];
+                            BD[3 * r + 2] = B1[3 * r] * Di[2] + B1[3 * r + 1] * Di[4] + B1[3 * r + 2] * Di[5];
+                        }
+                        const double ww = qa[3] * qb[3];
+                        double M[4];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) M[2 * r + c] = ww * (BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]);
+                        // C = A1^T M A2
+                        double AM[12]; // 6x2
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) { AM[2 * r] = A1[r] * M[0] + A1[6 + r] * M[2]; AM[2 * r + 1] = A1[r] * M[1] + A1[6 + r] * M[3]; }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) acc[6 * r + c] += AM[2 * r] * A2[c] + AM[2 * r + 1] * A2[6 + c];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) acc[i] = wave_sum(acc[i]);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int r = 0; r < 6; ++r)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) {
+                                double v = -acc[6 * r + c];
+                                if (k1 == k2) v += sm.Hpp[36 * k1 + 6 * r + c] + (r == c ? lambda : 0.0);
+                                sm.S[(6 * k1 + r) * np + 6 * k2 + c] = v;
+                                if (k1 != k2) sm.S[(6 * k2 + c) * np + 6 * k1 + r] = v;
+                            }
+                    }
+                }
+                __syncthreads();
+                // Cholesky (right-looking, lower) on S, whole workgroup
+                for (int j = 0; j < np; ++j) {
+                    const double d = sm.S[j * np + j];
+                    if (!(d > 0.0) || !isfinite(d)) { ok2 = false; break; } // uniform: every thread reads the same LDS word
+                    const double ljj = sqrt(d);
+                    __syncthreads();
+                    for (int i = j + 1 + tid; i < np; i += kLmBlock) sm.S[i * np + j] /= ljj;
+                    if (tid == 0) sm.S[j * np + j] = ljj;
+                    __syncthreads();
+                    const int rem = np - j - 1;
+                    for (int t = tid; t < rem * rem; t += kLmBlock) {
+                        const int i = j + 1 + t / rem, c = j + 1 + t % rem;
+                        if (c <= i) sm.S[i * np + c] -= sm.S[i * np + j] * sm.S[c * np + j];
+                    }
+                    __syncthreads();
+                }
+                if (sm.flag[1]) ok2 = false;
+                __syncthreads();
+                if (tid == 0) sm.flag[1] = 0;
+                if (ok2) {
+                    // forward / backward substitution by wave 0 (column-oriented, no reductions)
+                    if (wave == 0) {
+                        for (int i = lane; i < np; i += 64) sm.xp[i] = sm.bs[i];
+                        for (int j = 0; j < np; ++j) {
+                            __builtin_amdgcn_wave_barrier();
+                            const double yj = sm.xp[j] / sm.S[j * np + j];
+                            __builtin_amdgcn_wave_barrier();
+                            for (int i = lane; i < np; i += 64) {
+                                if (i == j) sm.xp[i] = yj;
+                                else if (i > j) sm.xp[i] -= sm.S[i * np + j] * yj;
+                            }
+                        }
+                        for (int j = np - 1; j >= 0; --j) {
+                            __builtin_amdgcn_wave_barrier();
+                            const double xj = sm.xp[j] / sm.S[j * np + j];
+                            __builtin_amdgcn_wave_barrier();
+                            for (int i = lane; i < np; i += 64) {
+                                if (i == j) sm.xp[i] = xj;
+                                else if (i < j) sm.xp[i] -= sm.S[j * np + i] * xj;
+                            }
+                        }
+                    }
+                } else {
+                    for (int i = tid; i < np; i += kLmBlock) sm.xp[i] = 0;
+                }
+                __syncthreads();
+            } else {
+                // pose-only: block-diagonal system, one thread per pose
+                if (tid < nk) {
+                    double x[6];
+                    const bool ok = chol6_solve(&sm.Hpp[36 * tid], lambda, &sm.bp[6 * tid], x);
+                    if (!ok) sm.flag[1] = 1;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) sm.xp[6 * tid + r] = x[r];
+                }
+                __syncthreads();
+                if (sm.flag[1]) { ok2 = false; }
+                __syncthreads();
+                if (!ok2) { for (int i = tid; i < np; i += kLmBlock) sm.xp[i] = 0; if (tid == 0) sm.flag[1] = 0; }
+                __syncthreads();
+            }
+            // ---- update: landmarks (back-substitution) and poses; computeScale
+            double scale_part = 0;
+            if (with_lm) {
+                for (int l = tid; l < nl; l += kLmBlock) {
+                    if (!act[l]) { Pt[3 * l] = P[3 * l]; Pt[3 * l + 1] = P[3 * l + 1]; Pt[3 * l + 2] = P[3 * l + 2]; continue; }
+                    const double* g = bl + 3 * (size_t)l;
+                    double c0 = g[0], c1 = g[1], c2 = g[2];
+                    for (int e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
+                        const int k = kfi[e];
+                        const double* q = lin + 6 * (size_t)e;
+                        double A[12], B[6];
+                        jac_pose(K, q[0], q[1], q[2], 0, A);
+                        jac_point(A, &sm.Rt[12 * k], B);
+                        // W^T xp = w B^T (A xp_k)
+                        double a0 = 0, a1 = 0;
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) { a0 += A[r] * sm.xp[6 * k + r]; a1 += A[6 + r] * sm.xp[6 * k + r]; }
+                        a0 *= q[3]; a1 *= q[3];
+                        c0 -= B[0] * a0 + B[3] * a1; c1 -= B[1] * a0 + B[4] * a1; c2 -= B[2] * a0 + B[5] * a1;
+                    }
+                    const double* Di = Dinv + 6 * (size_t)l;
+                    double x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
+                    double x1 = Di[1] * c0 + Di[3] * c1 + Di[4] * c2;
+                    double x2 = Di[2] * c0 + Di[4] * c1 + Di[5] * c2;
+                    Pt[3 * l] = P[3 * l] + x0; Pt[3 * l + 1] = P[3 * l + 1] + x1; Pt[3 * l + 2] = P[3 * l + 2] + x2;
+                    scale_part += x0 * (lambda * x0 + g[0]) + x1 * (lambda * x1 + g[1]) + x2 * (lambda * x2 + g[2]);
+                }
+            }
+            if (tid < np) scale_part += sm.xp[tid] * (lambda * sm.xp[tid] + sm.bp[tid]);
+            if (tid < nk) {
+                double E[7];
+                se3::exp(&sm.xp[6 * tid], E);
+                se3::mul(E, &sm.T[7 * tid], &sm.TTrial[7 * tid]);
+                expand_pose(&sm.TTrial[7 * tid], &sm.RtTrial[12 * tid]);
+            }
+            const double scale = block_sum(scale_part, sm.red) + 1e-3;
+            double tempChi = eval(sm.RtTrial, with_lm ? Pt : P, false);
+            if (!ok2) tempChi = 1.7976931348623157e308;
+            rho_gain = (currentChi - tempChi) / scale;
+            const bool accept = rho_gain > 0 && isfinite(tempChi); // uniform: all inputs are block-uniform
+            if (accept) {
+                double alpha = 1. - pow(2 * rho_gain - 1, 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                __syncthreads();
+                for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = sm.TTrial[i];
+                for (int i = tid; i < nk * 12; i += kLmBlock) sm.Rt[i] = sm.RtTrial[i];
+                if (with_lm) { double* t = P; P = Pt; Pt = t; }
+                __syncthreads();
+            } else {
+                lambda *= ni;
+                ni *= 2;
+            }
+            ++qmax;
+            again = (rho_gain < 0) && qmax < 10;
+        }
+        total_trials += qmax;
+        if (st && tid == 0 && it < VSLAM_LM_MAX_ITERS) { st->chi2_iter[it] = currentChi; st->lambda_iter[it] = lambda; st->trials_iter[it] = qmax; }
+        if (qmax == 10 || rho_gain == 0) { ++it; break; }
+    }
+    if (st && tid == 0) { st->iterations = it; st->total_trials = total_trials; st->chi2_final = currentChi; st->lambda_final = lambda; }
+
+    // ------------------------------------------------------------------ chi2 classification (optimization.cpp:224-266)
+    if (classify && !IMPL) {
+        double th = 5.991;
+        for (int iteration = 0; iteration < 5; ++iteration) {
+            double out = 0, in = 0;
+            for (int e = tid; e < ne; e += kLmBlock) {
+                if (!act[lmi[e]]) continue;
+                if (chi2[e] > th) out += 1; else in += 1;
+            }
+            out = block_sum(out, sm.red);
+            in = block_sum(in, sm.red);
+            const double ratio = in / (in + out);
+            if (ratio > 0.5) break;
+            th *= 2;
+        }
+        for (int l = tid; l < nl; l += kLmBlock)
+            if (act[l]) a.lm_inlier[lm0 + l] = !(chi2[lm_ptr[l + 1] - 1] > th); // last edge of the landmark wins (ascending edge order)
+        if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
+    }
+    // ------------------------------------------------------------------ write-back (:272-287, :429-435)
+    __syncthreads();
+    if (update_poses) for (int i = tid; i < nk * 7; i += kLmBlock) a.T[(size_t)w * nk * 7 + i] = sm.T[i];
+    if (with_lm && update_lms)
+        for (int l = tid; l < nl; l += kLmBlock)
+            if (act[l]) { a.xyz[3 * ((size_t)lm0 + l)] = (float)P[3 * l]; a.xyz[3 * ((size_t)lm0 + l) + 1] = (float)P[3 * l + 1]; a.xyz[3 * ((size_t)lm0 + l) + 2] = (float)P[3 * l + 2]; }
+    if (tid == 0) ka.status[w] = VSLAM_OK;
+}
+
+// reprojection-error inlier test of the motion-only stage (solvePnPRansac's reprojectionError contract)
+__global__ __launch_bounds__(256) void pnp_inlier_kernel(const float* __restrict__ xyz, const float* __restrict__ uv, const int32_t* __restrict__ d_n,
+                                                        int capacity, const double* __restrict__ d_T, const double K0, const double K1,
+                                                        const double K2, const double K3, double thr2, uint8_t* __restrict__ inlier,
+                                                        int32_t* __restrict__ n_inl) {
+    const int b = blockIdx.x;
+    const int n = min(max(d_n[b], 0), capacity);
+    __shared__ double Rt[12];
+    __shared__ int cnt;
+    if (threadIdx.x == 0) { expand_pose(d_T + 7 * b, Rt); cnt = 0; }
+    __syncthreads();
+    const double K[4] = {K0, K1, K2, K3};
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const size_t g = (size_t)b * capacity + i;
+        double X, Y, Z, ex, ey;
+        project_err(Rt, K, (double)xyz[3 * g], (double)xyz[3 * g + 1], (double)xyz[3 * g + 2], uv[2 * g], uv[2 * g + 1], X, Y, Z, ex, ey);
+        const double c = ex * ex + ey * ey;
+        const bool ok = isfinite(c) && c <= thr2;
+        if (inlier) inlier[g] = ok;
+        mine += ok;
+    }
+    atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && n_inl) n_inl[b] = cnt;
+}
+
+// scratch owned by the launch wrappers (grown on demand, per process)
+struct LmScratch {
+    void* buf = nullptr; size_t bytes = 0;
+    int32_t* status = nullptr; int status_n = 0;
+};
+static LmScratch g_lm;
+
+static int ensure(void** p, size_t* have, size_t need) {
+    if (*have >= need) return VSLAM_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr; *have = 0;
+    if (hipMalloc(p, need) != hipSuccess) { set_error("LM scratch hipMalloc(%zu) failed", need); return VSLAM_ERR_HIP; }
+    *have = need;
+    return VSLAM_OK;
+}
+
+static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_windows, bool with_lm, hipStream_t stream) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t need = 0;
+    const size_t o_P = need; need += al(total_lm * 3 * 8);
+    const size_t o_Pt = need; need += al(total_lm * 3 * 8);
+    const size_t o_Hll = need; need += al(total_lm * 6 * 8);
+    const size_t o_bl = need; need += al(total_lm * 3 * 8);
+    const size_t o_Di = need; need += al(total_lm * 6 * 8);
+    const size_t o_db = need; need += al(total_lm * 3 * 8);
+    const size_t o_lin = need; need += al(total_edge * 6 * 8);
+    const size_t o_lmptr = need; need += al((total_lm + n_windows + 1) * 4);
+    const size_t o_kfptr = need; need += al((size_t)n_windows * (kMaxKf + 1) * 4);
+    const size_t o_kfe = need; need += al(total_edge * 4);
+    const size_t o_pp = need; need += al((size_t)n_windows * (kMaxPairs + 1) * 4);
+    const size_t o_hits = need; need += with_lm ? al(total_edge * kHitsPerEdge * 8) : 256;
+    const size_t o_act = need; need += al(total_lm);
+    const size_t o_eo = need; need += with_lm ? al(total_lm * kMaxKf) : 256;
+    const size_t o_st = need; need += al((size_t)n_windows * 4);
+    const size_t o_chi = need; need += al(total_edge * 8);
+    // hipFree/hipMalloc are synchronising; growth only happens on the first call of a given size
+    if (g_lm.bytes < need) { hipStreamSynchronize(stream); int rc = ensure(&g_lm.buf, &g_lm.bytes, need); if (rc) return rc; }
+    uint8_t* base = (uint8_t*)g_lm.buf;
+    ka.a.P = (double*)(base + o_P); ka.a.Ptrial = (double*)(base + o_Pt); ka.a.Hll = (double*)(base + o_Hll);
+    ka.a.bl = (double*)(base + o_bl); ka.a.Dinv = (double*)(base + o_Di); ka.a.db = (double*)(base + o_db);
+    ka.a.lin = (double*)(base + o_lin); ka.a.lm_ptr = (int32_t*)(base + o_lmptr); ka.a.kf_ptr = (int32_t*)(base + o_kfptr);
+    ka.a.kf_edges = (int32_t*)(base + o_kfe); ka.a.pair_ptr = (int32_t*)(base + o_pp); ka.a.pair_hits = (int32_t*)(base + o_hits);
+    ka.act = base + o_act; ka.eo = base + o_eo; ka.status = (int32_t*)(base + o_st);
+    g_lm.status = ka.status; g_lm.status_n = n_windows;
+    if (!ka.a.chi2) ka.a.chi2 = (double*)(base + o_chi);
+    return VSLAM_OK;
+}
+
+int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms, hipStream_t stream) {
+    const size_t total_lm = a.total_lm, total_edge = a.total_edge;
+    if (a.n_windows <= 0) return VSLAM_OK;
+    if (a.n_kf <= 0 || a.n_kf > kMaxKf) { set_error("n_kf %d out of range (1..%d)", a.n_kf, kMaxKf); return VSLAM_ERR_ARG; }
+    LmKernelArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.a = a;
+    int rc = carve(ka, total_lm, total_edge, a.n_windows, true, stream);
+    if (rc) return rc;
+    if (schedule) {
+        // run_vslam.cpp:58-71: optimize_map(5) x2 without write-back, optimize_map(10) writing poses, optimize_pose_only(10)
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 0, 5, 0, 0, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 0, 5, 0, 0, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 0, 10, 1, 0, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 1, 10, 1, 0, 1);
+    } else {
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, mode, iters, update_poses, update_lms, 1);
+    }
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+int lm_fetch_status(int n_windows, int32_t* h_status, hipStream_t stream) {
+    if (!g_lm.buf || !h_status) return VSLAM_ERR_ARG;
+    // the status words of the most recent launch live at a fixed offset that carve() recorded
+    VS_HIP(hipMemcpyAsync(h_status, g_lm.status, sizeof(int32_t) * n_windows, hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    return VSLAM_OK;
+}
+
+int launch_pnp(const PnpArgs& p, hipStream_t stream) {
+    if (p.B <= 0) return VSLAM_OK;
+    LmKernelArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.a.n_windows = p.B; ka.a.n_kf = 1;
+    ka.a.T = p.T; ka.a.xyz = const_cast<float*>(p.xyz); ka.a.uv = p.uv; ka.a.stats = p.stats;
+    ka.a.K[0] = p.K[0]; ka.a.K[1] = p.K[1]; ka.a.K[2] = p.K[2]; ka.a.K[3] = p.K[3];
+    ka.a.huber_delta = p.huber_delta;
+    ka.pnp_n = p.n; ka.capacity = p.capacity;
+    const size_t tot = (size_t)p.B * p.capacity;
+    int rc = carve(ka, tot, tot, p.B, false, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0);
+    hipLaunchKernelGGL(pnp_inlier_kernel, dim3(p.B), dim3(256), 0, stream, p.xyz, p.uv, p.n, p.capacity, p.T, p.K[0], p.K[1], p.K[2], p.K[3],
+                       p.reproj_thr * p.reproj_thr, p.inlier, p.n_inliers);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+} // namespace vslam

@@ -1,0 +1,866 @@
+// orb_kernels.hip -- K1..K6: ORB detect (pyramid, FAST-9/16 + NMS, Harris, retainBest, IC angle), ANMS, rBRIEF.
+//
+// Replaces the arithmetic behind VO::feature_detection
+// (/root/reference/src/stereo_visual_slam_main/visual_odometry.cpp:70-94): cv::ORB::create(3000)->detect (:80),
+// VO::adaptive_non_maximal_suppresion (:96-157) and cv::ORB::create()->compute (:85).  SURVEY.md 8a rows A1-A3.
+//
+// Design (gfx950, wave64, batched over B images; everything integer except Harris/angle/rotation in f32):
+//   K1  orb_resize_kernel      level l from level l-1, 8-bit INTER_LINEAR in 11-bit fixed point; the coefficient
+//                              tables are computed once on the host (same arithmetic as the reference's library).
+//   K2  orb_fast_kernel        one launch for all 8 levels: 64x16-pixel tiles staged in LDS (72x24 with halo),
+//                              16-bit bright/dark ring masks + shift-AND contiguity test, corners queued in LDS and
+//                              scored with full lanes, 3x3 NMS on the LDS score tile, wave-aggregated append.
+//   K3  orb_select_kernel      one workgroup per (image, level): 256-bin histogram cut on the FAST score
+//                              (retainBest(2n) with ties), Harris 7x7, 4-pass radix select on the f32 response
+//                              (retainBest(n) with ties), raster-order bitonic sort in LDS, wave-per-keypoint
+//                              intensity-centroid angle.
+//   K5  orb_anms_kernel        one workgroup per image: bitonic sort by response, O(N^2) suppression radii from
+//                              LDS (exact f64 distance), radix-free select of the num-th radius by a second sort,
+//                              ordered compaction, cv::ORB::compute's border cull + stable regroup by octave.
+//   K6  orb_describe_kernel    one wave per keypoint: 43x43 patch staged in LDS, separable 7x7 fixed-point Gaussian
+//                              in LDS (only the pixels rBRIEF can touch are ever blurred), 256 rotated tests,
+//                              4 bits per lane, nibbles merged by a lane shuffle.
+// Float expressions that must round like the CPU (no FMA contraction) use explicit __f*_rn intrinsics; the file is
+// also compiled with -ffp-contract=off.
+#include "vslam_internal.h"
+
+#include <math.h>
+
+#include "orb_pattern.inc"
+
+namespace vslam {
+
+__device__ __constant__ signed char c_pattern[256 * 4];
+static bool g_pattern_uploaded[16] = {false};
+
+// status bits
+constexpr int kStCornerOverflow = 1, kStCandOverflow = 2, kStSelOverflow = 4, kStAnmsOverflow = 8, kStOutOverflow = 16;
+
+__device__ inline int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+struct LevelView {
+    const uint8_t* ptr;
+    int w, h, pitch;
+};
+
+struct LevelTable {
+    int w[kNLevels], h[kNLevels], pitch[kNLevels], pyr_off[kNLevels];
+    float scale[kNLevels];
+    int nfeat[kNLevels];
+    int corner_cap[kNLevels], corner_off[kNLevels];
+    int tiles_x[kNLevels], tile_off[kNLevels + 1];
+};
+
+__device__ inline LevelView level_view(const LevelTable& T, int l, const uint8_t* img, int pitch0, const uint8_t* pyr) {
+    LevelView v;
+    v.w = T.w[l]; v.h = T.h[l];
+    if (l == 0) { v.ptr = img; v.pitch = pitch0; }
+    else { v.ptr = pyr + T.pyr_off[l]; v.pitch = T.pitch[l]; }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------- host plan
+static inline int cv_round_host(double v) { return (int)lrint(v); }
+
+int orb_plan_init(OrbPlan* plan, int w, int h, int nfeatures, int kp_capacity) {
+    if (w < 64 || h < 64 || w > 4095 || h > 4095) { set_error("image size %dx%d unsupported (64..4095)", w, h); return VSLAM_ERR_ARG; }
+    memset(plan, 0, sizeof(*plan));
+    plan->w = w; plan->h = h;
+    const double scale_factor = (double)1.2f; // cv::ORB scaleFactor=1.2f held as double
+    float factor = (float)(1.0 / scale_factor);
+    float ndesired = (float)nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)kNLevels));
+    int sum = 0, pyr = 0, corners = 0, tiles = 0, tab = 0;
+    for (int l = 0; l < kNLevels; ++l) {
+        OrbLevel& L = plan->lv[l];
+        L.scale = (float)pow(scale_factor, (double)l);
+        L.w = cv_round_host((double)((float)w / L.scale));
+        L.h = cv_round_host((double)((float)h / L.scale));
+        if (l < kNLevels - 1) { L.nfeat = cv_round_host((double)ndesired); sum += L.nfeat; ndesired *= factor; }
+        else L.nfeat = nfeatures - sum > 0 ? nfeatures - sum : 0;
+        L.pyr_off = pyr;
+        if (l > 0) pyr += ((L.w + 63) & ~63) * L.h;
+        L.corner_cap = (L.w * L.h / 16 + 255) & ~255;
+        L.corner_off = corners; corners += L.corner_cap;
+        L.tiles_x = L.w > 62 ? (L.w - 62 + 63) / 64 : 0;
+        L.tiles_y = L.h > 62 ? (L.h - 62 + 15) / 16 : 0;
+        L.tile_off = tiles; tiles += L.tiles_x * L.tiles_y;
+        L.tab_off = tab; tab += L.w;
+    }
+    plan->pyr_bytes = (pyr + 255) & ~255;
+    plan->corner_total = corners;
+    plan->total_tiles = tiles;
+    plan->sel_cap = 1024;
+    (void)kp_capacity;
+    return VSLAM_OK;
+}
+
+static void fill_level_table(const OrbPlan& plan, LevelTable* T) {
+    for (int l = 0; l < kNLevels; ++l) {
+        const OrbLevel& L = plan.lv[l];
+        T->w[l] = L.w; T->h[l] = L.h; T->pitch[l] = (L.w + 63) & ~63; T->pyr_off[l] = L.pyr_off; T->scale[l] = L.scale;
+        T->nfeat[l] = L.nfeat; T->corner_cap[l] = L.corner_cap; T->corner_off[l] = L.corner_off;
+        T->tiles_x[l] = L.tiles_x; T->tile_off[l] = L.tile_off;
+    }
+    T->tile_off[kNLevels] = plan.total_tiles;
+}
+
+// resize coefficient tables: cv::resize(INTER_LINEAR, 8U) -- fx = (float)((dx+0.5)*scale - 0.5); floor; 11-bit coeffs
+int orb_tables_init(const OrbPlan* plan, OrbTables* t) {
+    memset(t, 0, sizeof(*t));
+    int nx = 0, ny = 0;
+    for (int l = 1; l < kNLevels; ++l) { t->x_off[l] = nx; nx += plan->lv[l].w; t->y_off[l] = ny; ny += plan->lv[l].h; }
+    int* xofs = new int[nx]; short* ialpha = new short[2 * nx]; int* yofs = new int[ny]; short* ibeta = new short[2 * ny];
+    for (int l = 1; l < kNLevels; ++l) {
+        const int sw = plan->lv[l - 1].w, sh = plan->lv[l - 1].h, dw = plan->lv[l].w, dh = plan->lv[l].h;
+        const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+        for (int dx = 0; dx < dw; ++dx) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= (float)sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            xofs[t->x_off[l] + dx] = sx;
+            ialpha[2 * (t->x_off[l] + dx)] = (short)lrintf((1.f - fx) * 2048.f);
+            ialpha[2 * (t->x_off[l] + dx) + 1] = (short)lrintf(fx * 2048.f);
+        }
+        for (int dy = 0; dy < dh; ++dy) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = (int)floorf(fy);
+            fy -= (float)sy;
+            yofs[t->y_off[l] + dy] = sy;
+            ibeta[2 * (t->y_off[l] + dy)] = (short)lrintf((1.f - fy) * 2048.f);
+            ibeta[2 * (t->y_off[l] + dy) + 1] = (short)lrintf(fy * 2048.f);
+        }
+    }
+    int rc = VSLAM_OK;
+    do {
+        if (hipMalloc(&t->d_xofs, sizeof(int) * nx) != hipSuccess || hipMalloc(&t->d_ialpha, sizeof(short) * 2 * nx) != hipSuccess ||
+            hipMalloc(&t->d_yofs, sizeof(int) * ny) != hipSuccess || hipMalloc(&t->d_ibeta, sizeof(short) * 2 * ny) != hipSuccess) {
+            set_error("orb_tables_init: hipMalloc failed"); rc = VSLAM_ERR_HIP; break;
+        }
+        hipMemcpy(t->d_xofs, xofs, sizeof(int) * nx, hipMemcpyHostToDevice);
+        hipMemcpy(t->d_ialpha, ialpha, sizeof(short) * 2 * nx, hipMemcpyHostToDevice);
+        hipMemcpy(t->d_yofs, yofs, sizeof(int) * ny, hipMemcpyHostToDevice);
+        hipMemcpy(t->d_ibeta, ibeta, sizeof(short) * 2 * ny, hipMemcpyHostToDevice);
+    } while (0);
+    delete[] xofs; delete[] ialpha; delete[] yofs; delete[] ibeta;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (rc == VSLAM_OK && dev < 16 && !g_pattern_uploaded[dev]) {
+        if (hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), k_orb_pattern, sizeof(k_orb_pattern)) != hipSuccess) {
+            set_error("orb pattern upload failed"); return VSLAM_ERR_HIP;
+        }
+        g_pattern_uploaded[dev] = true;
+    }
+    return rc;
+}
+
+void orb_tables_free(OrbTables* t) {
+    if (t->d_xofs) hipFree(t->d_xofs);
+    if (t->d_ialpha) hipFree(t->d_ialpha);
+    if (t->d_yofs) hipFree(t->d_yofs);
+    if (t->d_ibeta) hipFree(t->d_ibeta);
+    memset(t, 0, sizeof(*t));
+}
+
+// ------------------------------------------------------------------------------------------- K1 pyramid
+// each thread produces 4 consecutive output pixels of one row (one 32-bit store)
+__global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t* __restrict__ src_base, size_t src_img_stride, int spitch,
+                                                        int sw, int sh, uint8_t* __restrict__ dst_base, size_t dst_img_stride,
+                                                        int dpitch, int dw, int dh, const int* __restrict__ xofs,
+                                                        const short* __restrict__ ialpha, const int* __restrict__ yofs,
+                                                        const short* __restrict__ ibeta) {
+    const int b = blockIdx.z, dy = blockIdx.y;
+    const int dx0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (dx0 >= dw) return;
+    const uint8_t* src = src_base + (size_t)b * src_img_stride;
+    uint8_t* dst = dst_base + (size_t)b * dst_img_stride;
+    const int sy = yofs[dy];
+    const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    const uint8_t* S0 = src + (size_t)y0 * spitch;
+    const uint8_t* S1 = src + (size_t)y1 * spitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = dx0 + k;
+        if (dx < dw) {
+            const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
+            const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xFF) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + dx0) = packed; // dpitch is a multiple of 64
+}
+
+int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B,
+                       uint8_t* d_pyr, hipStream_t stream) {
+    for (int l = 1; l < kNLevels; ++l) {
+        const OrbLevel& S = plan.lv[l - 1];
+        const OrbLevel& D = plan.lv[l];
+        const uint8_t* src = l == 1 ? d_imgs : d_pyr + S.pyr_off;
+        const size_t sstride = l == 1 ? img_bytes : (size_t)plan.pyr_bytes;
+        const int spitch = l == 1 ? pitch : ((S.w + 63) & ~63);
+        const int dpitch = (D.w + 63) & ~63;
+        dim3 grid((D.w + 1023) / 1024, D.h, B);
+        hipLaunchKernelGGL(orb_resize_kernel, grid, dim3(256), 0, stream, src, sstride, spitch, S.w, S.h, d_pyr + D.pyr_off,
+                           (size_t)plan.pyr_bytes, dpitch, D.w, D.h, tab.d_xofs + tab.x_off[l], tab.d_ialpha + 2 * tab.x_off[l],
+                           tab.d_yofs + tab.y_off[l], tab.d_ibeta + 2 * tab.y_off[l]);
+    }
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------- K2 FAST
+constexpr int kTileW = 64, kTileH = 16;
+constexpr int kPixW = kTileW + 8, kPixH = kTileH + 8;  // 72 x 24 pixel tile (halo 4)
+constexpr int kScW = kTileW + 2, kScH = kTileH + 2;    // 66 x 18 score tile (halo 1)
+constexpr int kPixPitch = 76;                          // LDS row pitch (bytes)
+
+__device__ inline bool ring9(uint32_t m) {
+    const uint32_t x = m | (m << 16);
+    const uint32_t a = x & (x >> 1);
+    const uint32_t b = a & (a >> 2);
+    const uint32_t c = b & (b >> 4);
+    return ((c & (x >> 8)) & 0xFFFFu) != 0;
+}
+
+// ring offsets in the order of cv::FAST (pattern 16): (dx, dy)
+#define RING_LOAD(P, pitch)                                                                                   \
+    {(P)[0 + 3 * (pitch)],  (P)[1 + 3 * (pitch)],  (P)[2 + 2 * (pitch)],  (P)[3 + 1 * (pitch)],             \
+     (P)[3],                (P)[3 - 1 * (pitch)],  (P)[2 - 2 * (pitch)],  (P)[1 - 3 * (pitch)],             \
+     (P)[0 - 3 * (pitch)],  (P)[-1 - 3 * (pitch)], (P)[-2 - 2 * (pitch)], (P)[-3 - 1 * (pitch)],            \
+     (P)[-3],               (P)[-3 + 1 * (pitch)], (P)[-2 + 2 * (pitch)], (P)[-1 + 3 * (pitch)]}
+
+__device__ inline int fast_score(const uint8_t* p, int thr) {
+    const int v = p[0];
+    const int r[16] = RING_LOAD(p, kPixPitch);
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - r[k];
+    int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int a0 = thr, b0 = -0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        a0 = max(a0, mn9);
+        b0 = max(b0, -mx9);
+    }
+    return max(a0, b0) - 1;
+}
+
+__global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes, int pitch0,
+                                                      const uint8_t* __restrict__ d_pyr, size_t pyr_bytes, int total_tiles,
+                                                      int corner_total, int thr, uint32_t* __restrict__ d_corners,
+                                                      int32_t* __restrict__ d_corner_cnt, int32_t* __restrict__ d_status) {
+    const int b = blockIdx.y;
+    int tile = blockIdx.x, l = 0;
+#pragma unroll
+    for (int k = 1; k < kNLevels; ++k) if (tile >= T.tile_off[k]) l = k;
+    tile -= T.tile_off[l];
+    const LevelView V = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
+    const int tx = tile % T.tiles_x[l], ty = tile / T.tiles_x[l];
+    const int ox = kEdge + tx * kTileW, oy = kEdge + ty * kTileH; // first emitted pixel of this tile
+
+    __shared__ __attribute__((aligned(16))) uint8_t pix[kPixH * kPixPitch];
+    __shared__ uint8_t sc[kScH * kScW];
+    __shared__ uint16_t queue[kScH * kScW];
+    __shared__ int qcount;
+
+    if (threadIdx.x == 0) qcount = 0;
+    for (int i = threadIdx.x; i < kPixH * (kPixW / 4); i += 256) {
+        const int r = i / (kPixW / 4), c4 = (i % (kPixW / 4)) * 4;
+        const int y = min(oy - 4 + r, V.h - 1);
+        const uint8_t* row = V.ptr + (size_t)y * V.pitch;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v |= (uint32_t)row[min(ox - 4 + c4 + k, V.w - 1)] << (8 * k);
+        *reinterpret_cast<uint32_t*>(&pix[r * kPixPitch + c4]) = v;
+    }
+    for (int i = threadIdx.x; i < kScH * kScW; i += 256) sc[i] = 0;
+    __syncthreads();
+
+    // corner test on the 66 x 18 score region
+    for (int i = threadIdx.x; i < kScH * kScW; i += 256) {
+        const int sy = i / kScW, sx = i - sy * kScW;
+        const int x = ox - 1 + sx, y = oy - 1 + sy;
+        if (x >= V.w - 3 || y >= V.h - 3) continue; // outside cv::FAST's own range (left/top are always >= 30)
+        const uint8_t* p = &pix[(sy + 3) * kPixPitch + sx + 3];
+        const int v = p[0];
+        const int hi = v + thr, lo = v - thr;
+        const int r[16] = RING_LOAD(p, kPixPitch);
+        uint32_t bright = 0, dark = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { bright |= (uint32_t)(r[k] > hi) << k; dark |= (uint32_t)(r[k] < lo) << k; }
+        if (ring9(bright) || ring9(dark)) queue[atomicAdd(&qcount, 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int nq = qcount;
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        const int i = queue[q];
+        const int sy = i / kScW, sx = i - sy * kScW;
+        sc[i] = (uint8_t)fast_score(&pix[(sy + 3) * kPixPitch + sx + 3], thr);
+    }
+    __syncthreads();
+    // 3x3 non-max suppression + border cull (edgeThreshold 31) + append
+    uint32_t* corners = d_corners + (size_t)b * corner_total + T.corner_off[l];
+    int32_t* cnt = d_corner_cnt + b * kNLevels + l;
+    const int cap = T.corner_cap[l];
+    for (int i = threadIdx.x; i < kTileW * kTileH; i += 256) {
+        const int ey = i / kTileW, ex = i - ey * kTileW;
+        const int x = ox + ex, y = oy + ey;
+        const uint8_t* s = &sc[(ey + 1) * kScW + ex + 1];
+        const int v = s[0];
+        bool keep = v > 0 && x < V.w - kEdge && y < V.h - kEdge;
+        if (keep)
+            keep = v > s[-1] && v > s[1] && v > s[-kScW - 1] && v > s[-kScW] && v > s[-kScW + 1] && v > s[kScW - 1] && v > s[kScW] &&
+                   v > s[kScW + 1];
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(cnt, __popcll(m));
+            base = __shfl(base, leader);
+            if (keep) {
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < cap) corners[slot] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)v << 24);
+                else atomicOr(&d_status[b], kStCornerOverflow);
+            }
+        }
+    }
+}
+
+int launch_orb_fast(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, int fast_thr,
+                    uint32_t* d_corners, int32_t* d_corner_cnt, int32_t* d_status, hipStream_t stream) {
+    LevelTable T;
+    fill_level_table(plan, &T);
+    VS_HIP(hipMemsetAsync(d_corner_cnt, 0, sizeof(int32_t) * B * kNLevels, stream));
+    VS_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * B, stream));
+    if (plan.total_tiles > 0)
+        hipLaunchKernelGGL(orb_fast_kernel, dim3(plan.total_tiles, B), dim3(256), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
+                           (size_t)plan.pyr_bytes, plan.total_tiles, plan.corner_total, fast_thr, d_corners, d_corner_cnt, d_status);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------- sorting helper
+// in-LDS bitonic sort (ascending) of n (power of two) keys by the whole workgroup
+template <typename K>
+__device__ inline void bitonic_sort_lds(K* a, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < n / 2; t += blockDim.x) {
+                const int lo = ((t / j) * 2 * j) + (t % j);
+                const int hi = lo + j;
+                const bool up = (lo & k) == 0;
+                const K x = a[lo], y = a[hi];
+                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ inline uint32_t float_order_key(float f) { // monotone: larger float -> larger key; -0 == +0
+    f = f + 0.0f;
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float float_from_order_key(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+// ------------------------------------------------------------------------------------------- K3 select
+__device__ inline float harris_response_dev(const LevelView& V, int x0, int y0) {
+    const int step = V.pitch;
+    const uint8_t* ptr0 = V.ptr + (size_t)(y0 - 3) * step + (x0 - 3);
+    int a = 0, b = 0, c = 0;
+    for (int i = 0; i < 7; ++i) {
+        // three rows of 9 pixels around block row i
+        const uint8_t* r0 = ptr0 + (i - 1) * step - 1;
+        const uint8_t* r1 = r0 + step;
+        const uint8_t* r2 = r1 + step;
+        int p0[9], p1[9], p2[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { p0[k] = r0[k]; p1[k] = r1[k]; p2[k] = r2[k]; }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int Ix = (p1[j + 2] - p1[j]) * 2 + (p0[j + 2] - p0[j]) + (p2[j + 2] - p2[j]);
+            const int Iy = (p2[j + 1] - p0[j + 1]) * 2 + (p2[j] - p0[j]) + (p2[j + 2] - p0[j + 2]);
+            a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+        }
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float s2 = __fmul_rn(scale, scale);
+    const float s4 = __fmul_rn(__fmul_rn(s2, scale), scale);
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    const float ab = __fadd_rn(fa, fb);
+    const float t = __fsub_rn(__fsub_rn(__fmul_rn(fa, fb), __fmul_rn(fc, fc)), __fmul_rn(__fmul_rn(0.04f, ab), ab));
+    return __fmul_rn(t, s4);
+}
+
+__device__ inline float fast_atan2_dev(float y, float x) {
+    const float rad2deg = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * rad2deg, p3 = -0.3258083974640975f * rad2deg;
+    const float p5 = 0.1555786518463281f * rad2deg, p7 = -0.04432655554792128f * rad2deg;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// wave-cooperative intensity-centroid angle: lane = (v row 0..15) x (u quarter 0..3)
+__device__ inline float ic_angle_wave(const LevelView& V, int x, int y) {
+    const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    const int lane = threadIdx.x & 63;
+    const int v = lane >> 2, q = lane & 3;
+    int dmax = 15;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k == v) dmax = umax[k];
+    const int len = 2 * dmax + 1;
+    const int u0 = -dmax + (len * q) / 4, u1 = -dmax + (len * (q + 1)) / 4;
+    const uint8_t* c = V.ptr + (size_t)y * V.pitch + x;
+    int m10 = 0, vsum = 0;
+    if (v == 0) {
+        for (int u = u0; u < u1; ++u) m10 += u * c[u];
+    } else {
+        const uint8_t* cp = c + v * V.pitch;
+        const uint8_t* cm = c - v * V.pitch;
+        for (int u = u0; u < u1; ++u) {
+            const int vp = cp[u], vm = cm[u];
+            vsum += vp - vm;
+            m10 += u * (vp + vm);
+        }
+    }
+    int m01 = v * vsum;
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    return fast_atan2_dev((float)m01, (float)m10);
+}
+
+constexpr int kSelBlock = 512;
+constexpr int kCandCap = 8192;
+
+__global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes,
+                                                              int pitch0, const uint8_t* __restrict__ d_pyr, size_t pyr_bytes,
+                                                              int corner_total, const uint32_t* __restrict__ d_corners,
+                                                              const int32_t* __restrict__ d_corner_cnt, int sel_cap,
+                                                              vslam_keypoint* __restrict__ d_sel, int32_t* __restrict__ d_sel_cnt,
+                                                              int32_t* __restrict__ d_status) {
+    const int l = blockIdx.x, b = blockIdx.y;
+    const LevelView V = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
+    const uint32_t* corners = d_corners + (size_t)b * corner_total + T.corner_off[l];
+    const int n = min(d_corner_cnt[b * kNLevels + l], T.corner_cap[l]);
+    const int nfeat = T.nfeat[l];
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // kCandCap x u64: (harris order key << 32) | packed xy
+    unsigned long long* keep = cand + kCandCap;                             // kCandCap x u64 sort buffer
+    int* hist = reinterpret_cast<int*>(keep + kCandCap);                    // 256 bins
+    int& s_cut = hist[256]; int& s_ncand = hist[257]; int& s_rank = hist[258]; int& s_keep = hist[259];
+    uint32_t& s_prefix = reinterpret_cast<uint32_t*>(hist)[260];
+
+    // ---- retainBest(2 * nfeat) on the FAST score (ties at the cut are kept)
+    for (int i = threadIdx.x; i < 256; i += kSelBlock) hist[i] = 0;
+    if (threadIdx.x == 0) { s_ncand = 0; s_cut = 0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kSelBlock) atomicAdd(&hist[corners[i] >> 24], 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && n > 2 * nfeat && nfeat > 0) {
+        int acc = 0, s = 255;
+        for (; s > 0; --s) { acc += hist[s]; if (acc >= 2 * nfeat) break; }
+        s_cut = s;
+    }
+    __syncthreads();
+    const int cut = (nfeat > 0) ? s_cut : 256;
+    // ---- Harris response of every survivor
+    for (int i = threadIdx.x; i < n; i += kSelBlock) {
+        const uint32_t c = corners[i];
+        if ((int)(c >> 24) < cut) continue;
+        const int slot = atomicAdd(&s_ncand, 1);
+        if (slot < kCandCap) {
+            const float r = harris_response_dev(V, c & 0xFFF, (c >> 12) & 0xFFF);
+            cand[slot] = ((unsigned long long)float_order_key(r) << 32) | (c & 0xFFFFFFu);
+        }
+    }
+    __syncthreads();
+    int m = s_ncand;
+    if (m > kCandCap) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStCandOverflow); m = kCandCap; }
+    // ---- retainBest(nfeat) on the Harris response: radix select of the nfeat-th largest key
+    uint32_t cutkey = 0;
+    if (m > nfeat) {
+        if (threadIdx.x == 0) { s_prefix = 0; s_rank = nfeat; }
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = threadIdx.x; i < 256; i += kSelBlock) hist[i] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const uint32_t pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int i = threadIdx.x; i < m; i += kSelBlock) {
+                const uint32_t k = (uint32_t)(cand[i] >> 32);
+                if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFF], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int rank = s_rank, acc = 0, d = 255;
+                for (; d > 0; --d) { if (acc + hist[d] >= rank) break; acc += hist[d]; }
+                s_rank = rank - acc;
+                s_prefix = prefix | ((uint32_t)d << shift);
+            }
+            __syncthreads();
+        }
+        cutkey = s_prefix;
+    }
+    // ---- compact survivors (key >= cutkey), then raster sort by (y, x)
+    __syncthreads();
+    if (threadIdx.x == 0) s_keep = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += kSelBlock) {
+        const unsigned long long e = cand[i];
+        if ((uint32_t)(e >> 32) >= cutkey) {
+            const int slot = atomicAdd(&s_keep, 1);
+            const uint32_t xy = (uint32_t)e & 0xFFFFFFu;
+            const uint32_t raster = ((xy >> 12) << 12) | (xy & 0xFFF); // y major, x minor (already that layout)
+            keep[slot] = ((unsigned long long)raster << 32) | (uint32_t)(e >> 32);
+        }
+    }
+    __syncthreads();
+    const int nk = s_keep;
+    int np2 = 1;
+    while (np2 < nk) np2 <<= 1;
+    for (int i = nk + threadIdx.x; i < np2; i += kSelBlock) keep[i] = ~0ull;
+    __syncthreads();
+    if (np2 > 1) bitonic_sort_lds(keep, np2);
+    int nout = nk;
+    if (nout > sel_cap) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStSelOverflow); nout = sel_cap; }
+    // ---- orientation + output (wave per keypoint)
+    vslam_keypoint* out = d_sel + ((size_t)b * kNLevels + l) * sel_cap;
+    const int wave = threadIdx.x >> 6, nwaves = kSelBlock >> 6, lane = threadIdx.x & 63;
+    const float scale = T.scale[l];
+    for (int i = wave; i < nout; i += nwaves) {
+        const unsigned long long e = keep[i];
+        const uint32_t raster = (uint32_t)(e >> 32);
+        const int x = raster & 0xFFF, y = raster >> 12;
+        const float ang = ic_angle_wave(V, x, y);
+        if (lane == 0) {
+            vslam_keypoint kp;
+            kp.x = __fmul_rn((float)x, scale);
+            kp.y = __fmul_rn((float)y, scale);
+            kp.size = __fmul_rn(31.f, scale);
+            kp.angle = ang;
+            kp.response = float_from_order_key((uint32_t)e);
+            kp.octave = l;
+            kp.class_id = -1;
+            out[i] = kp;
+        }
+    }
+    if (threadIdx.x == 0) d_sel_cnt[b * kNLevels + l] = nout;
+}
+
+int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
+                      const uint32_t* d_corners, const int32_t* d_corner_cnt, vslam_keypoint* d_sel, int32_t* d_sel_cnt,
+                      int32_t* d_status, hipStream_t stream) {
+    LevelTable T;
+    fill_level_table(plan, &T);
+    const size_t smem = (size_t)kCandCap * 8 * 2 + 272 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(orb_select_kernel, dim3(kNLevels, B), dim3(kSelBlock), smem, stream, T, d_imgs, img_bytes, pitch, d_pyr,
+                       (size_t)plan.pyr_bytes, plan.corner_total, d_corners, d_corner_cnt, plan.sel_cap, d_sel, d_sel_cnt, d_status);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------- K5 ANMS
+constexpr int kAnmsBlock = 1024;
+
+__device__ inline int block_rank_1024(bool flag, int* s_wave_tot, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < kAnmsBlock / 64; ++w) {
+        const int c = s_wave_tot[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    total = tot;
+    return base + rank;
+}
+
+// Input: either 8 per-level lists (d_sel, d_sel_cnt; in_capacity = sel_cap) or one flat list (levels = 1).
+__global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoint* __restrict__ d_in, const int32_t* __restrict__ d_nin,
+                                                             int nlists, int in_capacity, int anms_num, int regroup, int img_w,
+                                                             int img_h, vslam_keypoint* __restrict__ d_kps, int kp_capacity,
+                                                             int32_t* __restrict__ d_count, int32_t* __restrict__ d_status) {
+    const int b = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem);                  // kMaxRows u64
+    float* sx = reinterpret_cast<float*>(smem + (size_t)kMaxRows * 8);                       // kMaxRows
+    float* sy = sx + kMaxRows;
+    float* sr = sy + kMaxRows;
+    double* srad = reinterpret_cast<double*>(smem + (size_t)kMaxRows * 8 + (size_t)kMaxRows * 12); // kMaxRows
+    uint16_t* sidx = reinterpret_cast<uint16_t*>(smem + (size_t)kMaxRows * 28);              // kMaxRows : source index per rank
+    uint16_t* sord = sidx + kMaxRows;                                                        // kMaxRows : output order
+    unsigned long long& s_final = *reinterpret_cast<unsigned long long*>(smem + (size_t)kMaxRows * 32);
+    int* s_wave_tot = reinterpret_cast<int*>(smem + (size_t)kMaxRows * 32 + 16);             // kAnmsBlock / 64
+    int* s_off = s_wave_tot + kAnmsBlock / 64;                                               // kNLevels + 1
+
+    // ---- gather (lists in order): flat index g -> (list, i)
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < nlists; ++k) { s_off[k] = acc; acc += min(max(d_nin[b * nlists + k], 0), in_capacity); }
+        s_off[nlists] = acc;
+    }
+    __syncthreads();
+    int N = s_off[nlists];
+    if (N > kMaxRows) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStAnmsOverflow); N = kMaxRows; }
+    const vslam_keypoint* in = d_in + (size_t)b * nlists * in_capacity;
+    auto src_ptr = [&](int g) -> const vslam_keypoint* {
+        int k = 0;
+        for (int t = 1; t < nlists; ++t) if (g >= s_off[t]) k = t;
+        return in + (size_t)k * in_capacity + (g - s_off[k]);
+    };
+    const bool do_anms = anms_num > 0 && N >= anms_num; // visual_odometry.cpp:100
+    int M = N; // count after ANMS
+    if (do_anms) {
+        // ---- sort by response, strongest first; ties by input index (stable)
+        int np2 = 1;
+        while (np2 < N) np2 <<= 1;
+        for (int g = threadIdx.x; g < np2; g += kAnmsBlock) {
+            unsigned long long k = ~0ull;
+            if (g < N) k = ((unsigned long long)(~float_order_key(src_ptr(g)->response)) << 32) | (uint32_t)g;
+            skey[g] = k;
+        }
+        __syncthreads();
+        bitonic_sort_lds(skey, np2);
+        for (int r = threadIdx.x; r < N; r += kAnmsBlock) {
+            const int g = (int)(skey[r] & 0xFFFFFFFFu);
+            const vslam_keypoint* kp = src_ptr(g);
+            sidx[r] = (uint16_t)g; sx[r] = kp->x; sy[r] = kp->y; sr[r] = kp->response;
+        }
+        __syncthreads();
+        // ---- suppression radius (visual_odometry.cpp:124-138)
+        for (int i = threadIdx.x; i < N; i += kAnmsBlock) {
+            const float thr = __fmul_rn(sr[i], 1.11f);
+            // first j in [0, i) with !(sr[j] > thr); sr is non-increasing
+            int lo = 0, hi = i;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (sr[mid] > thr) lo = mid + 1; else hi = mid; }
+            const float xi = sx[i], yi = sy[i];
+            double best = 1.7976931348623157e308;
+            bool any = false;
+            for (int j = 0; j < lo; ++j) {
+                const float dx = __fsub_rn(xi, sx[j]), dy = __fsub_rn(yi, sy[j]);
+                const double d2 = __dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy));
+                best = fmin(best, d2);
+                any = true;
+            }
+            srad[i] = any ? sqrt(best) : 1.7976931348623157e308;
+        }
+        __syncthreads();
+        // ---- the num-th largest radius (:141-146): sort the radii descending
+        for (int g = threadIdx.x; g < np2; g += kAnmsBlock) skey[g] = g < N ? ~(unsigned long long)__double_as_longlong(srad[g]) : ~0ull;
+        __syncthreads();
+        bitonic_sort_lds(skey, np2);
+        if (threadIdx.x == 0) s_final = ~skey[anms_num - 1];
+        __syncthreads();
+        const double final_radius = __longlong_as_double((long long)s_final);
+        // ---- keep rad >= final radius, in response order (:147-153)
+        int written = 0;
+        for (int base = 0; base < N; base += kAnmsBlock) {
+            const int i = base + threadIdx.x;
+            const bool keep = i < N && srad[i] >= final_radius;
+            int total;
+            const int r = block_rank_1024(keep, s_wave_tot, total);
+            if (keep) sord[written + r] = sidx[i];
+            written += total;
+        }
+        __syncthreads();
+        M = written;
+    } else {
+        for (int g = threadIdx.x; g < N; g += kAnmsBlock) sord[g] = (uint16_t)g;
+        __syncthreads();
+    }
+    // ---- cv::ORB::compute prologue: border cull in level-0 coordinates, stable regroup by octave
+    if (regroup) {
+        int np2 = 1;
+        while (np2 < M) np2 <<= 1;
+        uint32_t* k32 = reinterpret_cast<uint32_t*>(skey);
+        for (int r = threadIdx.x; r < np2; r += kAnmsBlock) {
+            uint32_t k = 0xFFFFFFFFu;
+            if (r < M) {
+                const vslam_keypoint* kp = src_ptr(sord[r]);
+                const bool inside = kp->x >= (float)kEdge && kp->x < (float)(img_w - kEdge) && kp->y >= (float)kEdge && kp->y < (float)(img_h - kEdge);
+                if (inside) k = ((uint32_t)min(max(kp->octave, 0), 15) << 16) | (uint32_t)r;
+            }
+            k32[r] = k;
+        }
+        __syncthreads();
+        if (np2 > 1) bitonic_sort_lds(k32, np2);
+        int cnt = 0;
+        // count survivors (keys != ~0): they are a prefix after sorting
+        int lo = 0, hi = M;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (k32[mid] != 0xFFFFFFFFu) lo = mid + 1; else hi = mid; }
+        cnt = lo;
+        if (cnt > kp_capacity) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStOutOverflow); cnt = kp_capacity; }
+        for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) d_kps[(size_t)b * kp_capacity + r] = *src_ptr(sord[k32[r] & 0xFFFFu]);
+        if (threadIdx.x == 0) d_count[b] = cnt;
+    } else {
+        int cnt = M;
+        if (cnt > kp_capacity) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStOutOverflow); cnt = kp_capacity; }
+        for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) d_kps[(size_t)b * kp_capacity + r] = *src_ptr(sord[r]);
+        if (threadIdx.x == 0) d_count[b] = cnt;
+    }
+}
+
+static int launch_anms_common(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int nlists, int in_capacity, int anms_num,
+                              int regroup, int img_w, int img_h, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count,
+                              int32_t* d_status, hipStream_t stream) {
+    const size_t smem = (size_t)kMaxRows * (8 + 12 + 8 + 2 + 2) + 16 + 4 * (kAnmsBlock / 64 + kNLevels + 1 + 3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_anms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(orb_anms_kernel, dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
+                       img_w, img_h, d_kps, kp_capacity, d_count, d_status);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+int launch_orb_anms(const OrbPlan& plan, int B, const vslam_keypoint* d_sel, const int32_t* d_sel_cnt, int sel_cap, int anms_num,
+                    int regroup, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count, int32_t* d_status, hipStream_t stream) {
+    return launch_anms_common(B, d_sel, d_sel_cnt, kNLevels, sel_cap, anms_num, regroup, plan.w, plan.h, d_kps, kp_capacity, d_count,
+                              d_status, stream);
+}
+
+int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int in_capacity, int anms_num, int regroup, int img_w,
+                     int img_h, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count, int32_t* d_status, hipStream_t stream) {
+    return launch_anms_common(B, d_in, d_nin, 1, in_capacity, anms_num, regroup, img_w, img_h, d_kps, kp_capacity, d_count, d_status, stream);
+}
+
+// ------------------------------------------------------------------------------------------- K6 rBRIEF
+constexpr int kDescWaves = 4;
+constexpr int kRawR = 21, kRawW = 2 * kRawR + 1;   // 43: rotated pattern reach (18) + blur reach (3)
+constexpr int kBlurR = 18, kBlurW = 2 * kBlurR + 1; // 37
+constexpr int kRawPitch = 44, kBlurPitch = 40;
+
+struct DescSmem {
+    uint8_t raw[kRawW * kRawPitch];
+    int tmp[kRawW * kBlurW];
+    uint8_t blur[kBlurW * kBlurPitch];
+};
+
+__global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(LevelTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes,
+                                                                      int pitch0, const uint8_t* __restrict__ d_pyr, size_t pyr_bytes,
+                                                                      const vslam_keypoint* __restrict__ d_kps, int kp_capacity,
+                                                                      const int32_t* __restrict__ d_count, uint8_t* __restrict__ d_desc) {
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * kDescWaves + wave;
+    const int n = min(d_count[b], kp_capacity);
+    __shared__ DescSmem sm[kDescWaves];
+    if (blockIdx.x * kDescWaves >= n) return; // whole block idle (uniform)
+    const bool active = j < n;
+    DescSmem& S = sm[wave];
+    vslam_keypoint kp = {0.f, 0.f, 31.f, 0.f, 0.f, 0, -1};
+    if (active) kp = d_kps[(size_t)b * kp_capacity + j];
+    const int l = min(max(kp.octave, 0), kNLevels - 1);
+    const LevelView V = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
+    const float inv_scale = __fdiv_rn(1.f, T.scale[l]);
+    const int cx = __float2int_rn(__fmul_rn(kp.x, inv_scale)), cy = __float2int_rn(__fmul_rn(kp.y, inv_scale));
+    // stage the raw 43x43 patch (reflect-101 outside the level image)
+    for (int i = lane; i < kRawW * kRawW; i += 64) {
+        const int r = i / kRawW, c = i - r * kRawW;
+        const int y = reflect101(cy - kRawR + r, V.h), x = reflect101(cx - kRawR + c, V.w);
+        S.raw[r * kRawPitch + c] = V.ptr[(size_t)y * V.pitch + x];
+    }
+    __syncthreads();
+    // GaussianBlur 7x7 sigma 2: kernel (float)exp(-x^2/8)/sum -> cvRound(k*256) = {18,34,49,55,49,34,18}
+    const int gk[7] = {18, 34, 49, 55, 49, 34, 18};
+    for (int i = lane; i < kRawW * kBlurW; i += 64) {
+        const int r = i / kBlurW, c = i - r * kBlurW;
+        const uint8_t* p = &S.raw[r * kRawPitch + c];
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s += gk[k] * p[k];
+        S.tmp[i] = s;
+    }
+    __syncthreads();
+    for (int i = lane; i < kBlurW * kBlurW; i += 64) {
+        const int r = i / kBlurW, c = i - r * kBlurW;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s += gk[k] * S.tmp[(r + k) * kBlurW + c];
+        int v = (s + (1 << 15)) >> 16;
+        v = min(max(v, 0), 255);
+        // outside the level image the reference reads the UNBLURRED reflect-101 border of its pyramid buffer
+        const int y = cy - kBlurR + r, x = cx - kBlurR + c;
+        if (x < 0 || x >= V.w || y < 0 || y >= V.h) v = S.raw[(r + 3) * kRawPitch + c + 3];
+        S.blur[r * kBlurPitch + c] = (uint8_t)v;
+    }
+    __syncthreads();
+    // 256 tests: lane L -> tests 4L..4L+3
+    const float ang = __fmul_rn(kp.angle, (float)(3.1415926535897932384626433832795 / 180.f));
+    const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
+    const uint8_t* center = &S.blur[kBlurR * kBlurPitch + kBlurR];
+    int nib = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const signed char* q = &c_pattern[(4 * lane + k) * 4];
+        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
+        const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
+        const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
+        const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
+        const int t0 = center[iy0 * kBlurPitch + ix0], t1 = center[iy1 * kBlurPitch + ix1];
+        nib |= (t0 < t1) << k;
+    }
+    const int hi = __shfl_down(nib, 1);
+    if (active && (lane & 1) == 0) d_desc[((size_t)b * kp_capacity + j) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
+int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
+                        const vslam_keypoint* d_kps, int kp_capacity, const int32_t* d_count, uint8_t* d_desc, hipStream_t stream) {
+    LevelTable T;
+    fill_level_table(plan, &T);
+    // grid sized for the capacity; waves beyond d_count[b] exit immediately
+    const int max_kp = min(kp_capacity, kMaxRows);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + kDescWaves - 1) / kDescWaves, B), dim3(kDescWaves * 64), 0, stream, T, d_imgs,
+                       img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_kps, kp_capacity, d_count, d_desc);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+} // namespace vslam

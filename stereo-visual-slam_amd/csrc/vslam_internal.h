@@ -1,0 +1,175 @@
+// vslam_internal.h -- private declarations shared by the HIP translation units of libvslam_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave64, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vslam_hip.h"
+
+namespace vslam {
+
+void set_error(const char* fmt, ...);
+
+#define VS_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            ::vslam::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return VSLAM_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+constexpr int kWave = 64;
+constexpr int kNLevels = VSLAM_ORB_NLEVELS;
+constexpr int kEdge = 31;            // ORB edgeThreshold
+constexpr int kMaxRows = 4096;       // max descriptors per matcher item / keypoints per image through ANMS
+
+// ----------------------------------------------------------------------------------------------- ORB
+struct OrbLevel {
+    int w, h;          // level size
+    float scale;       // (float)pow(1.2, l)
+    int nfeat;         // per-level budget
+    int pyr_off;       // byte offset of this level inside one image's pyramid buffer (level 0: unused)
+    int corner_cap;    // capacity of the FAST corner list of this level
+    int corner_off;    // offset (entries) of this level's corner list inside one image's corner buffer
+    int tiles_x, tiles_y, tile_off; // FAST tiling of this level
+    int tab_off;       // offset into the resize tables (xofs/ialpha) for this level
+};
+
+struct OrbPlan {
+    OrbLevel lv[kNLevels];
+    int w, h;
+    int pyr_bytes;        // per image, levels 1..7
+    int corner_total;     // per image
+    int total_tiles;      // FAST tiles per image, all levels
+    int sel_cap;          // per (image, level) capacity of the selected keypoint staging list
+};
+
+struct Ctx;
+
+// resize tables (host-computed, OpenCV arithmetic) live in device memory: per level xofs[w], ialpha[2w], yofs[h], ibeta[2h]
+struct OrbTables {
+    int* d_xofs;      // concatenated over levels 1..7
+    short* d_ialpha;
+    int* d_yofs;
+    short* d_ibeta;
+    int x_off[kNLevels], y_off[kNLevels];
+};
+
+int orb_plan_init(OrbPlan* plan, int w, int h, int nfeatures, int kp_capacity);
+int orb_tables_init(const OrbPlan* plan, OrbTables* t);
+void orb_tables_free(OrbTables* t);
+
+struct OrbBuffers {
+    uint8_t* d_pyr;        // B x pyr_bytes
+    uint32_t* d_corners;   // B x corner_total packed (x | y<<12 | score<<24)
+    int32_t* d_corner_cnt; // B x 8
+    vslam_keypoint* d_sel; // B x 8 x sel_cap  (per level, raster order, level coords scaled to L0, with angle)
+    int32_t* d_sel_cnt;    // B x 8
+    int32_t* d_status;     // B  (bit flags: overflow conditions)
+    vslam_keypoint* d_det; // B x kp_capacity: detect output (level asc, raster) when ANMS is run as a separate call
+};
+
+// launches (all asynchronous on `stream`)
+int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch,
+                       int B, uint8_t* d_pyr, hipStream_t stream);
+int launch_orb_fast(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
+                    int fast_thr, uint32_t* d_corners, int32_t* d_corner_cnt, int32_t* d_status, hipStream_t stream);
+int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
+                      const uint32_t* d_corners, const int32_t* d_corner_cnt, vslam_keypoint* d_sel, int32_t* d_sel_cnt,
+                      int32_t* d_status, hipStream_t stream);
+// gather per-level lists (level asc) -> ANMS(num) -> regroup by octave -> d_kps (B x kp_capacity), d_count
+// anms_num <= 0: no ANMS (detect order).  regroup: apply cv::ORB::compute's border cull + octave regrouping.
+int launch_orb_anms(const OrbPlan& plan, int B, const vslam_keypoint* d_sel, const int32_t* d_sel_cnt, int sel_cap,
+                    int anms_num, int regroup, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count, int32_t* d_status,
+                    hipStream_t stream);
+// same ANMS kernel on a flat list per image (d_in: B x in_capacity, d_nin[b]) for the stand-alone vslam_anms call
+int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int in_capacity, int anms_num, int regroup,
+                     int img_w, int img_h, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count, int32_t* d_status,
+                     hipStream_t stream);
+int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
+                        const vslam_keypoint* d_kps, int kp_capacity, const int32_t* d_count, uint8_t* d_desc,
+                        hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------- matcher
+struct MatchBuffers {
+    uint32_t* d_train_best; // B x max_rows : (dist << 16 | query index) per train row
+};
+int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const uint8_t* d_t, size_t t_stride,
+                 const int32_t* d_nt, const double* d_gap, int gate, double ratio, double gap_thr, int B, int max_rows,
+                 uint32_t* d_train_best, vslam_dmatch* d_out, int out_capacity, int32_t* d_nout, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------- geometry
+struct CamParams { double fx, fy, cx, cy, b, dmin, dmax, drel; };
+int launch_find3d_disparity(const vslam_keypoint* d_kps, int n, const float* d_disp, int w, int h, int dstride,
+                            const double* d_T, CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream);
+int launch_triangulate(const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B, const double* d_T,
+                       CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream);
+int launch_gather_uv(const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT, int kp_capacity, const vslam_dmatch* d_m,
+                     const int32_t* d_nm, int match_capacity, int B, float* d_uvQ, float* d_uvT, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------- LM
+struct LmWindowArgs {
+    int n_windows, n_kf;
+    const int32_t* lm_off;
+    const int32_t* edge_off;
+    double* T;              // n_windows x n_kf x 7
+    float* xyz;             // total_lm x 3
+    const uint8_t* reliable;
+    uint8_t* lm_inlier;
+    const int32_t* kf_idx;
+    const int32_t* lm_idx;
+    const float* uv;
+    double* chi2;
+    vslam_lm_stats* stats;
+    // scratch (sized by total_lm / total_edge)
+    double* P;      // total_lm x 3   current landmark estimates
+    double* Ptrial; // total_lm x 3
+    double* Hll;    // total_lm x 6
+    double* bl;     // total_lm x 3
+    double* Dinv;   // total_lm x 6
+    double* db;     // total_lm x 3
+    double* lin;    // total_edge x 6 : X Y Z w ex ey at the linearisation point
+    int32_t* lm_ptr;   // total_lm + n_windows (CSR by landmark, window-local edge ids, built in-kernel)
+    int32_t* kf_ptr;   // n_windows x (MAX_KF + 1)
+    int32_t* kf_edges; // total_edge (edge ids grouped by keyframe, ascending inside a group)
+    int32_t* pair_ptr; // n_windows x (NPAIR + 1)
+    int32_t* pair_hits;// hits: (e1, e2) packed as two int32  -> 2 x hit_capacity
+    int32_t hit_capacity_per_edge; // hits of a window <= n_edges_w * hit_capacity_per_edge
+    double K[4];
+    double huber_delta;
+    double* chi2_thr; // n_windows: final adaptive threshold of the last pass
+    size_t total_lm, total_edge;
+};
+// mode 0 = optimize_map (EdgeProjection + Schur), 1 = optimize_pose_only.
+int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms,
+                      hipStream_t stream);
+size_t lm_hits_per_edge();
+int lm_fetch_status(int n_windows, int32_t* h_status, hipStream_t stream);
+
+struct PnpArgs {
+    const float* xyz; const float* uv; const int32_t* n; int capacity; int B;
+    double* T; int iters; double K[4]; double huber_delta; double reproj_thr;
+    uint8_t* inlier; int32_t* n_inliers; vslam_lm_stats* stats;
+};
+int launch_pnp(const PnpArgs& a, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------- context
+struct Ctx {
+    vslam_params p;
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    size_t dev_bytes;
+    OrbPlan plan;
+    OrbTables tab;
+    OrbBuffers orb;
+    MatchBuffers match;
+    // staging for the host-buffer API (sized for one item)
+    uint8_t* d_stage; size_t stage_bytes;
+    uint8_t* h_pinned; size_t pinned_bytes;
+};
+
+} // namespace vslam

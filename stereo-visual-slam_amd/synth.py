@@ -1,0 +1,251 @@
+"""Seeded synthetic inputs shaped like the reference's workload (there is no KITTI data and no network).
+
+Shapes follow SURVEY.md section 8(d): KITTI-00 grayscale stereo pairs 1241x376 with the intrinsics the
+reference hard-codes (types_def.hpp:53-54, run_vslam.cpp:34-35), random 256-bit descriptor sets with planted
+matches and engineered ties, 3D-2D motion-only problems, and 10-keyframe local-BA windows.
+
+Pure numpy; used by tests/ and bench.py.  Nothing here is on the product's compute path.
+"""
+import numpy as np
+
+W_KITTI, H_KITTI = 1241, 376
+FX, FY, CX, CY, BASELINE = 718.856, 718.856, 607.1928, 185.2157, 0.573
+CAM = np.array([FX, FY, CX, CY, BASELINE])
+K4 = CAM[:4].copy()
+
+
+# --------------------------------------------------------------------------- SE3 helpers (numpy, f64)
+def rot_y(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def so3_exp(w):
+    th = np.linalg.norm(w)
+    Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + Wx
+    return np.eye(3) + np.sin(th) / th * Wx + (1 - np.cos(th)) / th ** 2 * Wx @ Wx
+
+
+def quat_from_R(R):
+    """unit quaternion (x,y,z,w) from a rotation matrix"""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    q /= np.linalg.norm(q)
+    if q[3] < 0:
+        q = -q
+    return q
+
+
+def se3_from_Rt(R, t):
+    return np.concatenate([quat_from_R(R), np.asarray(t, float)])
+
+
+def R_from_quat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def project(T_c_w, pw, K=K4):
+    R = R_from_quat(T_c_w[:4]); t = T_c_w[4:]
+    pc = pw @ R.T + t
+    return np.stack([K[0] * pc[:, 0] / pc[:, 2] + K[2], K[1] * pc[:, 1] / pc[:, 2] + K[3]], 1), pc[:, 2]
+
+
+# --------------------------------------------------------------------------- images
+def _hash_u32(ix, iy, pid, seed):
+    h = (ix.astype(np.uint32) * np.uint32(73856093)) ^ (iy.astype(np.uint32) * np.uint32(19349663)) \
+        ^ np.uint32((pid * 83492791 + seed * 2654435761) & 0xFFFFFFFF)
+    h ^= h >> np.uint32(16); h *= np.uint32(0x7FEB352D); h ^= h >> np.uint32(15)
+    h *= np.uint32(0x846CA68B); h ^= h >> np.uint32(16)
+    return h
+
+
+def _texture(a, b, pid, seed):
+    """blocky multi-octave texture in plane coordinates (metres) -> grey level float"""
+    val = np.full(a.shape, 110.0)
+    for cell, amp, k in ((0.9, 70.0, 1), (0.22, 50.0, 2), (0.06, 30.0, 3)):
+        ix = np.floor(a / cell).astype(np.int64); iy = np.floor(b / cell).astype(np.int64)
+        h = _hash_u32(ix, iy, pid * 4 + k, seed)
+        val += amp * (((h >> np.uint32(8)) & np.uint32(0xFF)).astype(np.float64) / 255.0 - 0.5)
+    return val
+
+
+class Scene:
+    """ground plane + fronto-parallel textured walls + far backdrop, in the world (= first camera) frame.
+    Camera convention: x right, y down, z forward (KITTI)."""
+
+    def __init__(self, seed=0, n_walls=10):
+        rng = np.random.default_rng(seed)
+        self.seed = int(seed)
+        self.walls = []
+        for i in range(n_walls):
+            z = rng.uniform(6.0, 80.0)
+            side = rng.choice([-1.0, 1.0])
+            x0 = side * rng.uniform(2.0, 12.0) + rng.uniform(-2, 2)
+            wdt = rng.uniform(3.0, 10.0); hgt = rng.uniform(2.0, 6.0)
+            self.walls.append((z, x0 - wdt / 2, x0 + wdt / 2, 1.65 - hgt, 1.65))
+        self.ground_y = 1.65
+        self.back_z = 120.0
+
+    def render(self, T_c_w, w=W_KITTI, h=H_KITTI, cam=CAM, x_offset=0.0):
+        """render the view of a camera with pose T_c_w (7: quat xyzw + t); x_offset shifts the optical centre
+        along the camera x axis (right camera: x_offset = baseline)."""
+        fx, fy, cx, cy = cam[:4]
+        R = R_from_quat(T_c_w[:4]); t = T_c_w[4:]
+        Rwc = R.T
+        o = -Rwc @ t + Rwc @ np.array([x_offset, 0, 0])
+        u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+        d = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1) @ Rwc.T
+        best_t = np.full(u.shape, np.inf)
+        img = np.zeros(u.shape)
+        # backdrop
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tt = (self.back_z - o[2]) / d[..., 2]
+            ok = tt > 0
+            X = o[0] + tt * d[..., 0]; Y = o[1] + tt * d[..., 1]
+            img = np.where(ok, _texture(X * 0.25, Y * 0.25, 1, self.seed), 90.0)
+            best_t = np.where(ok, tt, best_t)
+            # ground
+            tt = (self.ground_y - o[1]) / d[..., 1]
+            X = o[0] + tt * d[..., 0]; Z = o[2] + tt * d[..., 2]
+            ok = (tt > 0) & (tt < best_t)
+            img = np.where(ok, _texture(X, Z, 2, self.seed), img)
+            best_t = np.where(ok, tt, best_t)
+            for i, (z, x0, x1, y0, y1) in enumerate(self.walls):
+                tt = (z - o[2]) / d[..., 2]
+                X = o[0] + tt * d[..., 0]; Y = o[1] + tt * d[..., 1]
+                ok = (tt > 0) & (tt < best_t) & (X >= x0) & (X <= x1) & (Y >= y0) & (Y <= y1)
+                img = np.where(ok, _texture(X, Y, 3 + i, self.seed), img)
+                best_t = np.where(ok, tt, best_t)
+        depth = best_t * 1.0  # z-depth along camera axis since d_cam.z == 1
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8), depth
+
+
+def trajectory(n_frames, seed=0):
+    """forward motion 0.8-1.2 m/frame, yaw U(-0.03,0.03) rad/frame. returns T_c_w list."""
+    rng = np.random.default_rng(seed + 1000)
+    Rwc = np.eye(3); p = np.zeros(3)
+    out = []
+    for i in range(n_frames):
+        out.append(se3_from_Rt(Rwc.T, -Rwc.T @ p))
+        yaw = rng.uniform(-0.03, 0.03); step = rng.uniform(0.8, 1.2)
+        Rwc = Rwc @ rot_y(yaw)
+        p = p + Rwc @ np.array([0, 0, step])
+    return out
+
+
+def stereo_sequence(n_frames, seed=0, w=W_KITTI, h=H_KITTI):
+    """list of (left u8, right u8, T_c_w, depth_left)"""
+    sc = Scene(seed)
+    out = []
+    for T in trajectory(n_frames, seed):
+        L, depth = sc.render(T, w, h)
+        Rr, _ = sc.render(T, w, h, x_offset=BASELINE)
+        out.append((L, Rr, T, depth))
+    return out
+
+
+def noise_image(seed, w=W_KITTI, h=H_KITTI):
+    """cheap corner-rich image (blocky noise at three scales + smooth ramp), for ORB parity tests"""
+    rng = np.random.default_rng(seed)
+    img = np.zeros((h, w))
+    for cell, amp in ((37, 80), (11, 60), (4, 40)):
+        g = rng.uniform(-0.5, 0.5, (h // cell + 2, w // cell + 2))
+        img += amp * np.kron(g, np.ones((cell, cell)))[:h, :w]
+    yy, xx = np.mgrid[0:h, 0:w]
+    img += 120 + 20 * np.sin(xx / 90.0) + 10 * np.cos(yy / 40.0) + rng.normal(0, 2.0, (h, w))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------- descriptors
+def random_descriptors(nq, nt, seed=1, planted=0.7, flip_p=0.06, tie_frac=0.05):
+    """q, t ~ U{0,1}^256; `planted` of the query rows get a train partner with Binomial(256, flip_p) bit flips;
+    `tie_frac` of the train rows are exact duplicates of other train rows (engineered distance ties)."""
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    n_pl = int(min(nq, nt) * planted)
+    qi = rng.permutation(nq)[:n_pl]; ti = rng.permutation(nt)[:n_pl]
+    flips = rng.random((n_pl, 256)) < flip_p
+    t[ti] = q[qi] ^ np.packbits(flips, axis=1, bitorder="little")
+    n_tie = int(nt * tie_frac)
+    if n_tie and nt > 1:
+        src = rng.integers(0, nt, n_tie); dst = rng.integers(0, nt, n_tie)
+        t[dst] = t[src]
+    if nq > 2:  # and a few duplicated query rows
+        q[rng.integers(0, nq, max(1, nq // 50))] = q[rng.integers(0, nq, max(1, nq // 50))]
+    return q, t
+
+
+# --------------------------------------------------------------------------- motion-only / BA problems
+def perturb_pose(T, rng, sigma):
+    d = rng.normal(0, sigma, 6)
+    R = so3_exp(d[3:]) @ R_from_quat(T[:4])
+    t = so3_exp(d[3:]) @ T[4:] + d[:3]
+    return se3_from_Rt(R, t)
+
+
+def pnp_problem(M=500, seed=3, sigma_px=0.5, outlier_frac=0.15, guess_sigma=0.02):
+    """M 3D-2D pairs, sigma 0.5 px, 15 % gross outliers U(+-50 px)."""
+    rng = np.random.default_rng(seed)
+    T_true = se3_from_Rt(rot_y(rng.uniform(-0.05, 0.05)), rng.normal(0, 0.3, 3) + np.array([0, 0, -1.0]))
+    Z = rng.uniform(10, 60, M)
+    u = rng.uniform(40, W_KITTI - 40, M); v = rng.uniform(40, H_KITTI - 40, M)
+    pc = np.stack([(u - CX) / FX * Z, (v - CY) / FY * Z, Z], 1)
+    R = R_from_quat(T_true[:4])
+    pw = ((pc - T_true[4:]) @ R).astype(np.float32)
+    uv, _ = project(T_true, pw.astype(np.float64))
+    uv = uv + rng.normal(0, sigma_px, uv.shape)
+    is_out = rng.random(M) < outlier_frac
+    uv[is_out] += rng.uniform(-50, 50, (int(is_out.sum()), 2))
+    T0 = perturb_pose(T_true, rng, guess_sigma)
+    return dict(xyz=pw, uv=uv.astype(np.float32), T_true=T_true, T0=T0, outlier=is_out)
+
+
+def ba_window(n_kf=10, n_lm=3000, seed=2, sigma_px=0.5, outlier_frac=0.05, pose_sigma=0.02, min_obs=2, max_obs=5):
+    """10 poses on a forward arc (1 m spacing, 0.02 rad yaw/KF), landmarks in the frustum
+    with Z in [10,40] m of some keyframe, each seen by 2-5 consecutive keyframes; edges sorted by landmark."""
+    rng = np.random.default_rng(seed)
+    Rwc = np.eye(3); p = np.zeros(3)
+    T_true = []
+    for k in range(n_kf):
+        T_true.append(se3_from_Rt(Rwc.T, -Rwc.T @ p))
+        Rwc = Rwc @ rot_y(0.02); p = p + Rwc @ np.array([0, 0, 1.0])
+    T_true = np.array(T_true)
+    xyz = np.zeros((n_lm, 3), np.float32)
+    kf_idx, lm_idx, uvs = [], [], []
+    for l in range(n_lm):
+        nobs = int(rng.integers(min_obs, max_obs + 1))
+        k0 = int(rng.integers(0, n_kf - nobs + 1))
+        # place in the frustum of the middle observing keyframe
+        km = k0 + nobs // 2
+        Z = rng.uniform(10, 40); u = rng.uniform(150, W_KITTI - 150); v = rng.uniform(60, H_KITTI - 60)
+        pc = np.array([(u - CX) / FX * Z, (v - CY) / FY * Z, Z])
+        R = R_from_quat(T_true[km][:4])
+        xyz[l] = ((pc - T_true[km][4:]) @ R).astype(np.float32)
+        for k in range(k0, k0 + nobs):
+            uv, z = project(T_true[k], xyz[l:l + 1].astype(np.float64))
+            if z[0] < 1.0:
+                continue
+            kf_idx.append(k); lm_idx.append(l); uvs.append(uv[0])
+    kf_idx = np.array(kf_idx, np.int32); lm_idx = np.array(lm_idx, np.int32)
+    uv = np.array(uvs) + rng.normal(0, sigma_px, (len(uvs), 2))
+    is_out = rng.random(len(uv)) < outlier_frac
+    uv[is_out] += rng.uniform(-30, 30, (int(is_out.sum()), 2))
+    T0 = np.array([perturb_pose(T, rng, pose_sigma) for T in T_true])
+    return dict(T_true=T_true, T0=T0, xyz=xyz, kf_idx=kf_idx, lm_idx=lm_idx, uv=uv.astype(np.float32), outlier=is_out)

@@ -1,0 +1,11 @@
+"""Import shim: `import stereo_visual_slam_amd` -> the package in ./stereo-visual-slam_amd/ (a hyphenated directory
+cannot be imported by name)."""
+import importlib.util
+import os
+import sys
+
+_d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stereo-visual-slam_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_d, "__init__.py"), submodule_search_locations=[_d])
+_m = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _m
+_spec.loader.exec_module(_m)

@@ -1,0 +1,74 @@
+"""GPU parity: K9-K12 Levenberg-Marquardt back-end vs the CPU oracle.
+Poses / landmarks within 1e-4 relative (north_star), LM trajectory (chi2 per iteration, lambda, trials) matched.
+Reference path: optimize_map optimization.cpp:103-288, optimize_pose_only :290-436, motion estimation
+visual_odometry.cpp:253-314."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _stats_close(g, w):
+    assert g["iterations"] == w["iterations"], (g["iterations"], w["iterations"])
+    assert g["trials_iter"] == w["trials_iter"], (g["trials_iter"], w["trials_iter"])
+    assert np.allclose(g["chi2_iter"], w["chi2_iter"], rtol=1e-6), (g["chi2_iter"], w["chi2_iter"])
+    assert np.allclose(g["lambda_iter"], w["lambda_iter"], rtol=1e-6)
+    assert np.isclose(g["chi2_init"], w["chi2_init"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("M,seed", [(150, 3), (500, 4), (37, 5)])
+def test_pnp_motion_only_parity(vo, oracle, synth, M, seed):
+    p = synth.pnp_problem(M=M, seed=seed)
+    gT, ginl, gn, gst = vo.motion_estimation(p["xyz"], p["uv"], p["T0"], iters=10)
+    wT, winl, wn, wst = oracle.pnp_motion_only(p["xyz"], p["uv"], p["T0"], iters=10)
+    assert np.allclose(gT, wT, rtol=RTOL, atol=1e-7), (gT, wT)
+    assert gn == wn and (ginl == winl).all()
+    _stats_close(gst, wst)
+    # and the estimate is actually right: close to the ground truth
+    assert np.allclose(gT, p["T_true"], atol=5e-2)
+
+
+@pytest.mark.parametrize("n_lm,seed", [(300, 2), (3000, 7)])
+def test_pose_only_window_parity(vo, oracle, synth, n_lm, seed):
+    w = synth.ba_window(n_kf=10, n_lm=n_lm, seed=seed)
+    r = vo.optimize_pose_only(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], True, 10)
+    T, chi2, st = oracle.pose_only_window(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], iters=10)
+    assert np.allclose(r["T"], T, rtol=RTOL, atol=1e-7)
+    assert np.allclose(r["chi2"], chi2, rtol=1e-6, atol=1e-9)
+    _stats_close(r["stats"], st)
+    th, inl, ni, no = oracle.chi2_classify(chi2, w["lm_idx"], np.ones(n_lm, np.uint8))
+    assert r["threshold"] == th and (r["lm_inlier"] == inl).all()
+
+
+@pytest.mark.parametrize("n_lm,seed,iters", [(300, 2, 5), (3000, 7, 10), (1000, 9, 10)])
+def test_local_ba_parity(vo, oracle, synth, n_lm, seed, iters):
+    w = synth.ba_window(n_kf=10, n_lm=n_lm, seed=seed)
+    # shuffle the edge order: the C-ABI accepts any order
+    perm = np.random.default_rng(seed).permutation(len(w["kf_idx"]))
+    kf, lm, uv = w["kf_idx"][perm], w["lm_idx"][perm], w["uv"][perm]
+    r = vo.optimize_map(w["T0"], w["xyz"], kf, lm, uv, True, True, iters)
+    T, xyz, chi2, st = oracle.local_ba(w["T0"], w["xyz"], kf, lm, uv, iters=iters, update_poses=True, update_lms=True)
+    _stats_close(r["stats"], st)
+    assert np.allclose(r["T"], T, rtol=RTOL, atol=1e-6)
+    assert np.allclose(r["xyz"], xyz, rtol=RTOL, atol=1e-4)
+    assert np.allclose(r["chi2"], chi2, rtol=1e-4, atol=1e-6)
+    th, inl, ni, no = oracle.chi2_classify(chi2, lm, np.ones(n_lm, np.uint8))
+    assert r["threshold"] == th and (r["lm_inlier"] == inl).all()
+
+
+def test_local_ba_no_writeback(vo, synth):
+    w = synth.ba_window(n_kf=10, n_lm=200, seed=4)
+    r = vo.optimize_map(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], False, False, 5)
+    assert (r["T"] == w["T0"]).all() and (r["xyz"] == w["xyz"]).all()
+
+
+def test_local_ba_rejects_bad_graph(vo, pkg, synth):
+    w = synth.ba_window(n_kf=10, n_lm=50, seed=4)
+    bad = w["kf_idx"].copy(); bad[0] = 99
+    with pytest.raises(pkg.VslamError):
+        vo.optimize_map(w["T0"], w["xyz"], bad, w["lm_idx"], w["uv"])
+    dup_kf = np.concatenate([w["kf_idx"], w["kf_idx"][:1]]); dup_lm = np.concatenate([w["lm_idx"], w["lm_idx"][:1]])
+    dup_uv = np.concatenate([w["uv"], w["uv"][:1]])
+    with pytest.raises(pkg.VslamError):
+        vo.optimize_map(w["T0"], w["xyz"], dup_kf, dup_lm, dup_uv)

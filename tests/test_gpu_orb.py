@@ -1,0 +1,95 @@
+"""GPU parity: K1-K6 ORB detect / ANMS / rBRIEF vs the CPU oracle.
+Integer outputs (coordinates, octaves, descriptors) bit-exact; f32 response/angle bit-exact as well (same operation
+order, no FMA contraction on either side).  Reference path: VO::feature_detection, visual_odometry.cpp:70-157."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _kps_equal(a, b, fields=("x", "y", "size", "angle", "response", "octave", "class_id")):
+    assert len(a) == len(b), (len(a), len(b))
+    for f in fields:
+        bad = np.nonzero(a[f] != b[f])[0]
+        assert len(bad) == 0, (f, len(bad), bad[:5], a[f][bad[:5]], b[f][bad[:5]])
+
+
+@pytest.fixture(scope="module")
+def images(synth):
+    sc = synth.Scene(0)
+    T = synth.trajectory(1, 0)[0]
+    left, _ = sc.render(T)
+    return [synth.noise_image(0), synth.noise_image(1), left]
+
+
+def test_orb_detect_parity(vo, oracle, images):
+    for img in images:
+        got = vo.orb_detect(img)
+        want = oracle.orb_detect(img)
+        _kps_equal(got, want)
+
+
+def test_anms_parity(vo, oracle, images):
+    kps = oracle.orb_detect(images[0])
+    for num in (500, 1500, len(kps), len(kps) + 1, 1):
+        _kps_equal(vo.adaptive_non_maximal_suppresion(kps, num), oracle.anms(kps, num))
+
+
+def test_compute_parity(vo, oracle, images):
+    for img in images[:2]:
+        kps = oracle.anms(oracle.orb_detect(img), 500)
+        gk, gd = vo.orb_compute(img, kps)
+        wk, wd = oracle.orb_compute(img, kps)
+        _kps_equal(gk, wk)
+        assert gd.shape == wd.shape and (gd == wd).all(), int((gd != wd).any(axis=1).sum())
+
+
+def test_compute_near_border_keypoints(vo, oracle, images):
+    """user-provided keypoints that sit inside the 31 px level-0 border but near the LEVEL border at coarse octaves"""
+    img = images[0]
+    kps = oracle.orb_detect(img)[:64].copy()
+    kps["x"] = np.linspace(31, img.shape[1] - 32, len(kps)).astype(np.float32)
+    kps["y"] = np.where(np.arange(len(kps)) % 2 == 0, 31.0, img.shape[0] - 32.0).astype(np.float32)
+    kps["octave"] = np.arange(len(kps)) % 8
+    kps["angle"] = np.linspace(0, 359, len(kps)).astype(np.float32)
+    gk, gd = vo.orb_compute(img, kps)
+    wk, wd = oracle.orb_compute(img, kps)
+    _kps_equal(gk, wk)
+    assert (gd == wd).all()
+
+
+@pytest.mark.parametrize("anms_num", [500, 1500])
+def test_feature_detection_parity(pkg, oracle, images, anms_num):
+    ctx = pkg.VO(device=0, max_batch=1, anms_num=anms_num)
+    try:
+        for img in images:
+            gk, gd = ctx.feature_detection(img)
+            wk, wd = oracle.feature_detection(img, 3000, anms_num)
+            _kps_equal(gk, wk)
+            assert (gd == wd).all()
+    finally:
+        ctx.close()
+
+
+def test_feature_detection_batched_dev(vo, oracle, images):
+    import torch
+    from stereo_visual_slam_amd import KEYPOINT_DTYPE
+    B = len(images); h, w = images[0].shape; pitch = (w + 63) // 64 * 64
+    buf = np.zeros((B, h, pitch), np.uint8)
+    for b, im in enumerate(images):
+        buf[b, :, :w] = im
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(buf).to(dev)
+    cap = vo.params.kp_capacity
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev); d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    vo.feature_detection_dev(d_img.data_ptr(), h * pitch, pitch, B, d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr())
+    vo.sync()
+    assert (vo.orb_status(B) == 0).all()
+    cnt = d_cnt.cpu().numpy(); kk = d_kps.cpu().numpy(); dd = d_desc.cpu().numpy()
+    for b, im in enumerate(images):
+        wk, wd = oracle.feature_detection(im, 3000, vo.params.anms_num)
+        gk = kk[b].reshape(-1).view(KEYPOINT_DTYPE)[:cnt[b]]
+        _kps_equal(gk, wk)
+        assert (dd[b][:cnt[b]] == wd).all()
