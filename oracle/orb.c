@@ -497,7 +497,7 @@ int vo_orb_compute(const uint8_t* img, int w, int h, int stride, vo_keypoint* kp
         const int step = estride[l];
         uint8_t* d = desc + (size_t)j * 32;
         const signed char* pat = vo_orb_pattern;
-        for (int i = 0; i < 32; ++i, pat += 64) { /* 16 points = 8 tests per byte */
+        for (int i = 0; i < 32; ++i, pat += 32) { /* 16 points = 8 tests x {x0,y0,x1,y1} per byte */
             int val = 0;
             for (int k = 0; k < 8; ++k) {
                 const signed char* q = pat + 4 * k;

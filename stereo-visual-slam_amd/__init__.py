@@ -86,6 +86,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own libamdhip64 (same SONAME).  Import it first so that this library binds to the HIP runtime
+        # torch already loaded: two HIP runtimes in one process cannot both own the GPU.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(_SO):
         raise VslamError("libvslam_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(there is no CPU fallback for the HIP path)")
