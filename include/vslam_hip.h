@@ -211,6 +211,29 @@ int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status);
 /* per-image ORB capacity flags of the most recent ORB launch (0 = ok) */
 int vslam_orb_status_dev(vslam_ctx* ctx, int B, int32_t* h_status);
 
+/* Device glue between the frame-to-frame matcher and the motion-only stage (the gather of
+ * VO::motion_estimation, visual_odometry.cpp:260-270): for every frame-to-frame match (query = previous frame,
+ * train = current frame) whose query keypoint owns a valid triangulated point (found through the previous frame's
+ * L/R matches d_lr, whose queryIdx is the left keypoint), emit (xyz, current pixel), in match order.
+ * d_kp2lr: B x kp_capacity int32 scratch.  Outputs: B x out_capacity. */
+int vslam_build_pnp_inputs_dev(vslam_ctx* ctx, const vslam_dmatch* d_f2f, const int32_t* d_nf2f, int match_capacity,
+                               const vslam_dmatch* d_lr, const int32_t* d_nlr, int lr_capacity, const float* d_xyz_lr,
+                               const uint8_t* d_valid_lr, const vslam_keypoint* d_kps_cur, int kp_capacity, int B,
+                               int32_t* d_kp2lr, float* d_xyz_out, float* d_uv_out, int32_t* d_nout, int out_capacity);
+
+/* ------------------------------------------------------------------ stage profiler --------------------- */
+/* hipEvent brackets around every kernel family launched by this thread's calls on this context (the reference only
+ * has a commented-out ros::Time stopwatch, visual_odometry.cpp:652,701-702).  vslam_profile_read synchronises the
+ * stream, returns accumulated milliseconds per kernel family since the last read, and resets. */
+typedef struct vslam_kernel_time {
+    char name[48];
+    double total_ms;
+    int32_t launches; /* kernel launches covered */
+    int32_t calls;    /* brackets recorded */
+} vslam_kernel_time;
+int vslam_profile_enable(vslam_ctx* ctx, int on);
+int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_out);
+
 /* ------------------------------------------------------------------ raw device memory helpers ---------- */
 /* For hosts without their own device allocator (the C++ mirror in host/); bench.py passes torch tensors. */
 int vslam_dev_alloc(void** p, size_t bytes);

@@ -60,8 +60,13 @@ ABI_SYMBOLS = [
     "vslam_find_3d_disparity", "vslam_triangulate", "vslam_triangulate_dev", "vslam_gather_matched_uv_dev",
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
-    "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset",
+    "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
+    "vslam_profile_enable", "vslam_profile_read",
 ]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("total_ms", C.c_double), ("launches", C.c_int32), ("calls", C.c_int32)]
 
 
 class VslamError(RuntimeError):
@@ -305,6 +310,21 @@ class VO:
     def ba_batch_dev(self, batch, schedule=1, mode=0, iters=10, update_poses=1, update_lms=0):
         self._chk(self.lib.vslam_ba_batch_dev(self.h, C.byref(batch), int(schedule), int(mode), int(iters), int(update_poses),
                                               int(update_lms)), "vslam_ba_batch_dev")
+
+    def build_pnp_inputs_dev(self, d_f2f, d_nf2f, match_cap, d_lr, d_nlr, lr_cap, d_xyz_lr, d_valid_lr, d_kps_cur, kp_cap, B, d_kp2lr,
+                             d_xyz_out, d_uv_out, d_nout, out_cap):
+        self._chk(self.lib.vslam_build_pnp_inputs_dev(self.h, _p(d_f2f), _p(d_nf2f), int(match_cap), _p(d_lr), _p(d_nlr), int(lr_cap),
+                                                      _p(d_xyz_lr), _p(d_valid_lr), _p(d_kps_cur), int(kp_cap), int(B), _p(d_kp2lr),
+                                                      _p(d_xyz_out), _p(d_uv_out), _p(d_nout), int(out_cap)), "vslam_build_pnp_inputs_dev")
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.vslam_profile_enable(self.h, int(on)), "vslam_profile_enable")
+
+    def profile_read(self):
+        """{kernel family: (total_ms, launches, calls)} since the last read; synchronises the stream"""
+        buf = (KernelTime * 32)(); n = C.c_int()
+        self._chk(self.lib.vslam_profile_read(self.h, buf, 32, C.byref(n)), "vslam_profile_read")
+        return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches, buf[i].calls) for i in range(n.value)}
 
     def ba_status(self, n_windows):
         st = np.zeros(n_windows, np.int32)

@@ -21,6 +21,39 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- stage profiler (hipEvent brackets; see vslam_internal.h)
+struct Prof {
+    struct Rec { const char* name; int launches; hipEvent_t e0, e1; };
+    bool on = false;
+    std::vector<Rec> recs, open;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+static thread_local Prof* g_prof = nullptr;
+Prof* prof_current() { return g_prof; }
+void prof_set_current(Prof* p) { g_prof = p; }
+void prof_begin(hipStream_t s, const char* name, int launches) {
+    Prof* p = g_prof;
+    if (!p || !p->on) return;
+    Prof::Rec r{name, launches, p->get(), p->get()};
+    (void)hipEventRecord(r.e0, s);
+    p->open.push_back(r);
+}
+void prof_end(hipStream_t s) {
+    Prof* p = g_prof;
+    if (!p || !p->on || p->open.empty()) return;
+    Prof::Rec r = p->open.back();
+    p->open.pop_back();
+    (void)hipEventRecord(r.e1, s);
+    p->recs.push_back(r);
+}
+static Prof* g_ctx_prof_table[64] = {nullptr};
+
 // simple bump arena over one growable device allocation (host-buffer API only)
 struct Arena {
     Ctx* c; size_t off;
@@ -579,6 +612,55 @@ int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !h_status || n_windows <= 0) return VSLAM_ERR_ARG;
     return lm_fetch_status(n_windows, h_status, c->stream);
+}
+
+// ---------------------------------------------------------------------------------------------- profiling + glue
+int vslam_profile_enable(vslam_ctx* ctx, int on) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return VSLAM_ERR_ARG;
+    Prof*& p = g_ctx_prof_table[c->device & 63];
+    if (!p) p = new Prof();
+    p->on = on != 0;
+    prof_set_current(on ? p : nullptr);
+    return VSLAM_OK;
+}
+
+int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !out || !n_out || cap <= 0) return VSLAM_ERR_ARG;
+    *n_out = 0;
+    Prof* p = g_ctx_prof_table[c->device & 63];
+    if (!p) return VSLAM_OK;
+    VS_HIP(hipStreamSynchronize(c->stream));
+    int n = 0;
+    for (const Prof::Rec& r : p->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+        int k = 0;
+        for (; k < n; ++k) if (strncmp(out[k].name, r.name, sizeof(out[k].name) - 1) == 0) break;
+        if (k == n) {
+            if (n == cap) continue;
+            memset(&out[n], 0, sizeof(out[n]));
+            strncpy(out[n].name, r.name, sizeof(out[n].name) - 1);
+            ++n;
+        }
+        out[k].total_ms += ms; out[k].launches += r.launches; out[k].calls += 1;
+        p->pool.push_back(r.e0); p->pool.push_back(r.e1);
+    }
+    p->recs.clear();
+    *n_out = n;
+    return VSLAM_OK;
+}
+
+int vslam_build_pnp_inputs_dev(vslam_ctx* ctx, const vslam_dmatch* d_f2f, const int32_t* d_nf2f, int match_capacity,
+                               const vslam_dmatch* d_lr, const int32_t* d_nlr, int lr_capacity, const float* d_xyz_lr,
+                               const uint8_t* d_valid_lr, const vslam_keypoint* d_kps_cur, int kp_capacity, int B, int32_t* d_kp2lr,
+                               float* d_xyz_out, float* d_uv_out, int32_t* d_nout, int out_capacity) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_f2f || !d_nf2f || !d_lr || !d_nlr || !d_xyz_lr || !d_valid_lr || !d_kps_cur || !d_kp2lr || !d_xyz_out || !d_uv_out || !d_nout ||
+        match_capacity <= 0 || lr_capacity <= 0 || kp_capacity <= 0 || out_capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    return launch_build_pnp_inputs(d_f2f, d_nf2f, match_capacity, d_lr, d_nlr, lr_capacity, d_xyz_lr, d_valid_lr, d_kps_cur, kp_capacity, B,
+                                   d_kp2lr, d_xyz_out, d_uv_out, d_nout, out_capacity, c->stream);
 }
 
 // ---------------------------------------------------------------------------------------------- raw device memory helpers

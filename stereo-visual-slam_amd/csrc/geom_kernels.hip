@@ -93,6 +93,69 @@ __global__ __launch_bounds__(256) void gather_uv_kernel(const vslam_keypoint* __
     reinterpret_cast<float2*>(uvT)[i] = make_float2(t->x, t->y);
 }
 
+// One workgroup per item.  Phase 1: kp2lr[queryIdx of L/R match] = L/R match index (or -1).  Phase 2: walk the
+// frame-to-frame matches in order; a match whose query keypoint has a valid triangulated point contributes
+// (xyz of that point, pixel of the train keypoint).  Ordered compaction via ballot ranks.
+__global__ __launch_bounds__(256) void build_pnp_inputs_kernel(const vslam_dmatch* __restrict__ d_m, const int32_t* __restrict__ d_nm,
+                                                              int match_capacity, const vslam_dmatch* __restrict__ d_lr,
+                                                              const int32_t* __restrict__ d_nlr, int lr_capacity,
+                                                              const float* __restrict__ d_xyz_lr, const uint8_t* __restrict__ d_valid_lr,
+                                                              const vslam_keypoint* __restrict__ d_kpsT, int kp_capacity,
+                                                              int32_t* __restrict__ d_kp2lr, float* __restrict__ d_xyz_out,
+                                                              float* __restrict__ d_uv_out, int32_t* __restrict__ d_nout, int out_capacity) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_tot[4];
+    int32_t* kp2lr = d_kp2lr + (size_t)b * kp_capacity;
+    for (int i = tid; i < kp_capacity; i += 256) kp2lr[i] = -1;
+    __syncthreads();
+    const int nlr = min(d_nlr[b], lr_capacity);
+    const vslam_dmatch* lr = d_lr + (size_t)b * lr_capacity;
+    for (int i = tid; i < nlr; i += 256) {
+        const int q = lr[i].queryIdx;
+        if (q >= 0 && q < kp_capacity) kp2lr[q] = i;
+    }
+    __syncthreads();
+    const int nm = min(d_nm[b], match_capacity);
+    const vslam_dmatch* m = d_m + (size_t)b * match_capacity;
+    int written = 0;
+    for (int base = 0; base < nm; base += 256) {
+        const int i = base + tid;
+        bool ok = false; int li = -1, ti = 0;
+        if (i < nm) {
+            const int q = m[i].queryIdx; ti = m[i].trainIdx;
+            if (q >= 0 && q < kp_capacity && ti >= 0 && ti < kp_capacity) { li = kp2lr[q]; ok = li >= 0 && d_valid_lr[(size_t)b * lr_capacity + li] != 0; }
+        }
+        const unsigned long long mask = __ballot(ok);
+        __syncthreads();
+        if (lane == 0) s_tot[wave] = __popcll(mask);
+        __syncthreads();
+        int off = written;
+        for (int w = 0; w < wave; ++w) off += s_tot[w];
+        const int slot = off + __popcll(mask & ((1ull << lane) - 1ull));
+        if (ok && slot < out_capacity) {
+            const float* p = d_xyz_lr + 3 * ((size_t)b * lr_capacity + li);
+            float* o = d_xyz_out + 3 * ((size_t)b * out_capacity + slot);
+            o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+            const vslam_keypoint* k = d_kpsT + (size_t)b * kp_capacity + ti;
+            reinterpret_cast<float2*>(d_uv_out)[(size_t)b * out_capacity + slot] = make_float2(k->x, k->y);
+        }
+        written += s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    }
+    if (tid == 0) d_nout[b] = min(written, out_capacity);
+}
+
+int launch_build_pnp_inputs(const vslam_dmatch* d_m, const int32_t* d_nm, int match_capacity, const vslam_dmatch* d_lr,
+                            const int32_t* d_nlr, int lr_capacity, const float* d_xyz_lr, const uint8_t* d_valid_lr,
+                            const vslam_keypoint* d_kpsT, int kp_capacity, int B, int32_t* d_kp2lr, float* d_xyz_out, float* d_uv_out,
+                            int32_t* d_nout, int out_capacity, hipStream_t stream) {
+    if (B <= 0) return VSLAM_OK;
+    ProfScope prof__(stream, "build_pnp_inputs_kernel");
+    hipLaunchKernelGGL(build_pnp_inputs_kernel, dim3(B), dim3(256), 0, stream, d_m, d_nm, match_capacity, d_lr, d_nlr, lr_capacity, d_xyz_lr,
+                       d_valid_lr, d_kpsT, kp_capacity, d_kp2lr, d_xyz_out, d_uv_out, d_nout, out_capacity);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
 int launch_find3d_disparity(const vslam_keypoint* d_kps, int n, const float* d_disp, int w, int h, int dstride, const double* d_T,
                             CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream) {
     if (n <= 0) return VSLAM_OK;
@@ -105,6 +168,7 @@ int launch_find3d_disparity(const vslam_keypoint* d_kps, int n, const float* d_d
 int launch_triangulate(const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B, const double* d_T, CamParams cam,
                        float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream) {
     if (B <= 0 || capacity <= 0) return VSLAM_OK;
+    ProfScope prof__(stream, "triangulate_kernel");
     hipLaunchKernelGGL(triangulate_kernel, dim3((capacity + 255) / 256, B), dim3(256), 0, stream, d_uvL, d_uvR, d_n, capacity, d_T, cam,
                        d_xyz, d_valid, d_rel);
     VS_HIP(hipGetLastError());
@@ -114,6 +178,7 @@ int launch_triangulate(const float* d_uvL, const float* d_uvR, const int32_t* d_
 int launch_gather_uv(const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT, int kp_capacity, const vslam_dmatch* d_m,
                      const int32_t* d_nm, int match_capacity, int B, float* d_uvQ, float* d_uvT, hipStream_t stream) {
     if (B <= 0 || match_capacity <= 0) return VSLAM_OK;
+    ProfScope prof__(stream, "gather_uv_kernel");
     hipLaunchKernelGGL(gather_uv_kernel, dim3((match_capacity + 255) / 256, B), dim3(256), 0, stream, d_kpsQ, d_kpsT, kp_capacity, d_m,
                        d_nm, match_capacity, d_uvQ, d_uvT);
     VS_HIP(hipGetLastError());

@@ -738,6 +738,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     ka.a = a;
     int rc = carve(ka, total_lm, total_edge, a.n_windows, true, stream);
     if (rc) return rc;
+    ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1);
     if (schedule) {
         // run_vslam.cpp:58-71: optimize_map(5) x2 without write-back, optimize_map(10) writing poses, optimize_pose_only(10)
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 0, 5, 0, 0, 1);
@@ -771,6 +772,7 @@ int launch_pnp(const PnpArgs& p, hipStream_t stream) {
     const size_t tot = (size_t)p.B * p.capacity;
     int rc = carve(ka, tot, tot, p.B, false, stream);
     if (rc) return rc;
+    ProfScope prof__(stream, "lm_window_kernel<pnp>", 2);
     hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0);
     hipLaunchKernelGGL(pnp_inlier_kernel, dim3(p.B), dim3(256), 0, stream, p.xyz, p.uv, p.n, p.capacity, p.T, p.K[0], p.K[1], p.K[2], p.K[3],
                        p.reproj_thr * p.reproj_thr, p.inlier, p.n_inliers);

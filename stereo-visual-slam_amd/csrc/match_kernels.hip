@@ -144,8 +144,12 @@ int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const
     int qsplit = 1;
     while (qsplit < 16 && (long)tblocks * qsplit * B < 1024 && max_rows / (qsplit * 2) >= kQTile) qsplit *= 2;
     if (qsplit > 1) VS_HIP(hipMemsetAsync(d_train_best, 0xFF, (size_t)B * max_rows * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(match_train_nearest_kernel, dim3(tblocks, qsplit, B), dim3(kMatchBlock), 0, stream, d_q, q_stride, d_nq,
-                       d_t, t_stride, d_nt, max_rows, qsplit, d_train_best);
+    {
+        ProfScope prof__(stream, "match_train_nearest_kernel");
+        hipLaunchKernelGGL(match_train_nearest_kernel, dim3(tblocks, qsplit, B), dim3(kMatchBlock), 0, stream, d_q, q_stride, d_nq,
+                           d_t, t_stride, d_nt, max_rows, qsplit, d_train_best);
+    }
+    ProfScope prof__(stream, "match_finalize_kernel");
     hipLaunchKernelGGL(match_finalize_kernel, dim3(B), dim3(kFinBlock), 0, stream, d_nq, d_nt, d_gap, gate, ratio, gap_thr,
                        max_rows, d_train_best, d_out, out_capacity, d_nout);
     VS_HIP(hipGetLastError());

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t* __restri
 
 int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B,
                        uint8_t* d_pyr, hipStream_t stream) {
+    ProfScope prof__(stream, "orb_resize_kernel", kNLevels - 1);
     for (int l = 1; l < kNLevels; ++l) {
         const OrbLevel& S = plan.lv[l - 1];
         const OrbLevel& D = plan.lv[l];
@@ -349,6 +350,7 @@ int launch_orb_fast(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes
     fill_level_table(plan, &T);
     VS_HIP(hipMemsetAsync(d_corner_cnt, 0, sizeof(int32_t) * B * kNLevels, stream));
     VS_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * B, stream));
+    ProfScope prof__(stream, "orb_fast_kernel");
     if (plan.total_tiles > 0)
         hipLaunchKernelGGL(orb_fast_kernel, dim3(plan.total_tiles, B), dim3(256), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
                            (size_t)plan.pyr_bytes, plan.total_tiles, plan.corner_total, fast_thr, d_corners, d_corner_cnt, d_status);
@@ -593,6 +595,7 @@ int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
+    ProfScope prof__(stream, "orb_select_kernel");
     hipLaunchKernelGGL(orb_select_kernel, dim3(kNLevels, B), dim3(kSelBlock), smem, stream, T, d_imgs, img_bytes, pitch, d_pyr,
                        (size_t)plan.pyr_bytes, plan.corner_total, d_corners, d_corner_cnt, plan.sel_cap, d_sel, d_sel_cnt, d_status);
     VS_HIP(hipGetLastError());
@@ -753,6 +756,7 @@ static int launch_anms_common(int B, const vslam_keypoint* d_in, const int32_t* 
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_anms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
+    ProfScope prof__(stream, "orb_anms_kernel");
     hipLaunchKernelGGL(orb_anms_kernel, dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
                        img_w, img_h, d_kps, kp_capacity, d_count, d_status);
     VS_HIP(hipGetLastError());
@@ -857,6 +861,7 @@ int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_b
     fill_level_table(plan, &T);
     // grid sized for the capacity; waves beyond d_count[b] exit immediately
     const int max_kp = min(kp_capacity, kMaxRows);
+    ProfScope prof__(stream, "orb_describe_kernel");
     hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + kDescWaves - 1) / kDescWaves, B), dim3(kDescWaves * 64), 0, stream, T, d_imgs,
                        img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_kps, kp_capacity, d_count, d_desc);
     VS_HIP(hipGetLastError());

@@ -21,6 +21,20 @@ void set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
+// ----------------------------------------------------------------------------------------------- stage profiler
+// Optional hipEvent brackets around every kernel family (SURVEY.md section 5 "Tracing / profiling").  Enabled per
+// context by vslam_profile_enable(); launch functions call PROF_BEGIN/PROF_END, which are no-ops when disabled.
+struct Prof;
+Prof* prof_current();
+void prof_set_current(Prof* p);
+void prof_begin(hipStream_t s, const char* name, int launches);
+void prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s;
+    ProfScope(hipStream_t st, const char* name, int launches = 1) : s(st) { prof_begin(s, name, launches); }
+    ~ProfScope() { prof_end(s); }
+};
+
 constexpr int kWave = 64;
 constexpr int kNLevels = VSLAM_ORB_NLEVELS;
 constexpr int kEdge = 31;            // ORB edgeThreshold
@@ -107,6 +121,11 @@ int launch_find3d_disparity(const vslam_keypoint* d_kps, int n, const float* d_d
                             const double* d_T, CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream);
 int launch_triangulate(const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B, const double* d_T,
                        CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream);
+// f2f matches + per-keypoint 3-D points of the query frame -> compact (xyz, uv) PnP inputs (ordered, valid only)
+int launch_build_pnp_inputs(const vslam_dmatch* d_m, const int32_t* d_nm, int match_capacity, const vslam_dmatch* d_lr,
+                            const int32_t* d_nlr, int lr_capacity, const float* d_xyz_lr, const uint8_t* d_valid_lr,
+                            const vslam_keypoint* d_kpsT, int kp_capacity, int B, int32_t* d_kp2lr, float* d_xyz_out, float* d_uv_out,
+                            int32_t* d_nout, int out_capacity, hipStream_t stream);
 int launch_gather_uv(const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT, int kp_capacity, const vslam_dmatch* d_m,
                      const int32_t* d_nm, int match_capacity, int B, float* d_uvQ, float* d_uvT, hipStream_t stream);
 

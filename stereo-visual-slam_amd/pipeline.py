@@ -1,0 +1,172 @@
+"""Throughput-mode keyframe pipeline: B independent stereo keyframes per step, everything device-resident.
+
+One step = the hot path BASELINE.json's metric names, over a batch of B stereo keyframes:
+    ORB detect+ANMS+describe on the B left and B right images (one 2B-image launch set)
+ -> L/R cross-checked Hamming match + gate          (stereo association, north_star)
+ -> gather matched pixels -> rectified-stereo DLT triangulation (+ depth gates of set_ref_3d_position)
+ -> frame-to-frame match: keyframe b-1 (query) vs keyframe b (train)      (VO::feature_matching, :575)
+ -> 3D(prev, triangulated) - 2D(cur) gather -> motion-only LM pose (10 its) (VO::motion_estimation substitute)
+ -> local BA on B sliding windows (10 KF x ~3000 landmarks): schedule 5+5+10 LM + 10 pose-only (run_vslam.cpp:58-71)
+torch is used only for device memory and the stream; every stage is a C-ABI call into libvslam_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import BaBatch, DMATCH_DTYPE, KEYPOINT_DTYPE, VO, default_params
+from . import synth
+
+
+class KeyframePipeline:
+    def __init__(self, B, device=0, anms_num=1500, n_lm=3000, n_kf=10, unique_scenes=4, unique_windows=4, seed=0, verbose=False,
+                 with_ba=True):
+        self.B = B
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.stream = torch.cuda.current_stream(self.dev)
+        self.with_ba = with_ba
+        p = default_params(max_batch=2 * B, anms_num=anms_num)
+        self.vo = VO(params=p, device=device, stream=self.stream.cuda_stream)
+        self.cap = p.kp_capacity
+        self.w, self.h = p.img_w, p.img_h
+        self.pitch = (self.w + 63) // 64 * 64
+        self.img_bytes = self.pitch * self.h
+        d = self.dev
+        # ---- inputs: 2B images [left 0..B-1 | right 0..B-1]; consecutive keyframes of `unique_scenes` short sequences
+        imgs = np.zeros((2 * B, self.h, self.pitch), np.uint8)
+        per = max(2, (B + unique_scenes - 1) // unique_scenes)
+        seqs = {}
+        for b in range(B):
+            s, f = (b // per) % unique_scenes, b % per
+            if s not in seqs:
+                seqs[s] = synth.stereo_sequence(per, seed=seed + s, w=self.w, h=self.h)
+                if verbose:
+                    print("rendered sequence", s, flush=True)
+            L, R, _, _ = seqs[s][f]
+            imgs[b, :, :self.w] = L
+            imgs[B + b, :, :self.w] = R
+        self.h_imgs = imgs
+        self.d_imgs = torch.from_numpy(imgs).to(d)
+        # ---- ORB outputs
+        self.d_kps = torch.zeros((2 * B, self.cap, 28), dtype=torch.uint8, device=d)
+        self.d_desc = torch.zeros((2 * B, self.cap, 32), dtype=torch.uint8, device=d)
+        self.d_cnt = torch.zeros(2 * B, dtype=torch.int32, device=d)
+        # ---- matches (L/R and frame-to-frame)
+        self.d_gap = torch.ones(B, dtype=torch.float64, device=d)
+        self.d_lr = torch.zeros((B, self.cap, 16), dtype=torch.uint8, device=d)
+        self.d_nlr = torch.zeros(B, dtype=torch.int32, device=d)
+        self.d_f2f = torch.zeros((B, self.cap, 16), dtype=torch.uint8, device=d)
+        self.d_nf2f = torch.zeros(B, dtype=torch.int32, device=d)
+        # ---- triangulation
+        self.d_uvL = torch.zeros((B, self.cap, 2), dtype=torch.float32, device=d)
+        self.d_uvR = torch.zeros((B, self.cap, 2), dtype=torch.float32, device=d)
+        ident = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], np.float64), (B, 1))
+        self.d_Tident = torch.from_numpy(ident).to(d)
+        self.d_xyz = torch.zeros((B, self.cap, 3), dtype=torch.float32, device=d)
+        self.d_valid = torch.zeros((B, self.cap), dtype=torch.uint8, device=d)
+        self.d_rel = torch.zeros((B, self.cap), dtype=torch.uint8, device=d)
+        # ---- PnP
+        self.d_kp2lr = torch.zeros((B, self.cap), dtype=torch.int32, device=d)
+        self.d_pxyz = torch.zeros((B, self.cap, 3), dtype=torch.float32, device=d)
+        self.d_puv = torch.zeros((B, self.cap, 2), dtype=torch.float32, device=d)
+        self.d_pn = torch.zeros(B, dtype=torch.int32, device=d)
+        self.d_Tpnp = torch.from_numpy(ident.copy()).to(d)
+        self.d_inl = torch.zeros((B, self.cap), dtype=torch.uint8, device=d)
+        self.d_ninl = torch.zeros(B, dtype=torch.int32, device=d)
+        # ---- local-BA windows
+        if with_ba:
+            wins = [synth.ba_window(n_kf=n_kf, n_lm=n_lm, seed=seed + 100 + i) for i in range(unique_windows)]
+            lm_off, e_off = [0], [0]
+            T0, xyz, kf, lm, uv = [], [], [], [], []
+            for b in range(B):
+                wn = wins[b % unique_windows]
+                T0.append(wn["T0"]); xyz.append(wn["xyz"]); kf.append(wn["kf_idx"]); lm.append(wn["lm_idx"]); uv.append(wn["uv"])
+                lm_off.append(lm_off[-1] + len(wn["xyz"])); e_off.append(e_off[-1] + len(wn["kf_idx"]))
+            self.n_kf = n_kf
+            self.ba_T0 = torch.from_numpy(np.stack(T0)).to(d)
+            self.ba_T = self.ba_T0.clone()
+            self.ba_xyz = torch.from_numpy(np.concatenate(xyz)).to(d)
+            self.ba_kf = torch.from_numpy(np.concatenate(kf)).to(d)
+            self.ba_lm = torch.from_numpy(np.concatenate(lm)).to(d)
+            self.ba_uv = torch.from_numpy(np.concatenate(uv)).to(d)
+            self.ba_lm_off = torch.tensor(lm_off, dtype=torch.int32, device=d)
+            self.ba_e_off = torch.tensor(e_off, dtype=torch.int32, device=d)
+            self.ba_inl = torch.ones(lm_off[-1], dtype=torch.uint8, device=d)
+            self.ba_chi2 = torch.zeros(e_off[-1], dtype=torch.float64, device=d)
+            self.total_lm, self.total_edge = lm_off[-1], e_off[-1]
+            self.edges_per_window = e_off[-1] / B
+            self.lms_per_window = lm_off[-1] / B
+            bb = BaBatch()
+            bb.n_windows = B; bb.n_kf = n_kf
+            bb.d_lm_off = self.ba_lm_off.data_ptr(); bb.d_edge_off = self.ba_e_off.data_ptr(); bb.d_T_c_w = self.ba_T.data_ptr()
+            bb.d_xyz = self.ba_xyz.data_ptr(); bb.d_reliable = None; bb.d_lm_inlier = self.ba_inl.data_ptr()
+            bb.d_kf_idx = self.ba_kf.data_ptr(); bb.d_lm_idx = self.ba_lm.data_ptr(); bb.d_uv = self.ba_uv.data_ptr()
+            bb.d_chi2 = self.ba_chi2.data_ptr(); bb.d_stats = None; bb.total_lm = self.total_lm; bb.total_edge = self.total_edge
+            self.ba_batch = bb
+        torch.cuda.synchronize(self.dev)
+
+    # ------------------------------------------------------------------ stages
+    def stage_orb(self):
+        self.vo.feature_detection_dev(self.d_imgs.data_ptr(), self.img_bytes, self.pitch, 2 * self.B, self.d_kps.data_ptr(),
+                                      self.d_desc.data_ptr(), self.d_cnt.data_ptr())
+
+    def stage_stereo_match(self):
+        B, cap = self.B, self.cap
+        vo = self.vo
+        # L/R: query = left descriptors of keyframe b, train = right descriptors of keyframe b
+        vo.feature_matching_dev(self.d_desc.data_ptr(), cap * 32, self.d_cnt.data_ptr(), self.d_desc.data_ptr() + B * cap * 32, cap * 32,
+                                self.d_cnt.data_ptr() + 4 * B, self.d_gap.data_ptr(), 1, B, cap, self.d_lr.data_ptr(), cap, self.d_nlr.data_ptr())
+        vo.gather_matched_uv_dev(self.d_kps.data_ptr(), self.d_kps.data_ptr() + B * cap * 28, cap, self.d_lr.data_ptr(), self.d_nlr.data_ptr(),
+                                 cap, B, self.d_uvL.data_ptr(), self.d_uvR.data_ptr())
+        vo.triangulate_dev(self.d_uvL.data_ptr(), self.d_uvR.data_ptr(), self.d_nlr.data_ptr(), cap, B, self.d_Tident.data_ptr(),
+                           self.d_xyz.data_ptr(), self.d_valid.data_ptr(), self.d_rel.data_ptr())
+
+    def stage_track(self):
+        """keyframe b-1 -> keyframe b for b = 1..B-1 (the first keyframe of the batch has no predecessor in the batch)"""
+        B, cap = self.B, self.cap
+        if B < 2:
+            return
+        vo, n = self.vo, B - 1
+        # query = left descriptors of keyframe b-1 (item i = b-1), train = left descriptors of keyframe b
+        vo.feature_matching_dev(self.d_desc.data_ptr(), cap * 32, self.d_cnt.data_ptr(), self.d_desc.data_ptr() + cap * 32, cap * 32,
+                                self.d_cnt.data_ptr() + 4, self.d_gap.data_ptr(), 1, n, cap, self.d_f2f.data_ptr(), cap, self.d_nf2f.data_ptr())
+        vo.build_pnp_inputs_dev(self.d_f2f.data_ptr(), self.d_nf2f.data_ptr(), cap, self.d_lr.data_ptr(), self.d_nlr.data_ptr(), cap,
+                                self.d_xyz.data_ptr(), self.d_valid.data_ptr(), self.d_kps.data_ptr() + cap * 28, cap, n, self.d_kp2lr.data_ptr(),
+                                self.d_pxyz.data_ptr(), self.d_puv.data_ptr(), self.d_pn.data_ptr(), cap)
+        self.d_Tpnp.copy_(self.d_Tident)
+        vo.motion_estimation_dev(self.d_pxyz.data_ptr(), self.d_puv.data_ptr(), self.d_pn.data_ptr(), cap, n, self.d_Tpnp.data_ptr(), 10,
+                                 self.d_inl.data_ptr(), self.d_ninl.data_ptr())
+
+    def stage_ba(self):
+        if not self.with_ba:
+            return
+        self.ba_T.copy_(self.ba_T0)
+        self.ba_inl.fill_(1)
+        self.vo.ba_batch_dev(self.ba_batch, schedule=1)
+
+    def step(self):
+        self.stage_orb()
+        self.stage_stereo_match()
+        self.stage_track()
+        self.stage_ba()
+
+    # ------------------------------------------------------------------ host views (tests / reports)
+    def download(self):
+        self.vo.sync()
+        torch.cuda.synchronize(self.dev)
+        B, cap = self.B, self.cap
+        out = dict(cnt=self.d_cnt.cpu().numpy(), nlr=self.d_nlr.cpu().numpy(), nf2f=self.d_nf2f.cpu().numpy(), pn=self.d_pn.cpu().numpy(),
+                   ninl=self.d_ninl.cpu().numpy(), Tpnp=self.d_Tpnp.cpu().numpy())
+        out["kps"] = self.d_kps.cpu().numpy().reshape(2 * B, -1).view(KEYPOINT_DTYPE).reshape(2 * B, cap)
+        out["desc"] = self.d_desc.cpu().numpy()
+        out["lr"] = self.d_lr.cpu().numpy().reshape(B, -1).view(DMATCH_DTYPE).reshape(B, cap)
+        out["f2f"] = self.d_f2f.cpu().numpy().reshape(B, -1).view(DMATCH_DTYPE).reshape(B, cap)
+        out["xyz"] = self.d_xyz.cpu().numpy(); out["valid"] = self.d_valid.cpu().numpy(); out["rel"] = self.d_rel.cpu().numpy()
+        out["pxyz"] = self.d_pxyz.cpu().numpy(); out["puv"] = self.d_puv.cpu().numpy(); out["inl"] = self.d_inl.cpu().numpy()
+        if self.with_ba:
+            out["ba_T"] = self.ba_T.cpu().numpy(); out["ba_inl"] = self.ba_inl.cpu().numpy(); out["ba_chi2"] = self.ba_chi2.cpu().numpy()
+        return out
+
+    def close(self):
+        self.vo.close()
