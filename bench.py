@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="stereo keyframes per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="stereo keyframes per GPU per step")
     ap.add_argument("--anms", type=int, default=1500, help="keypoints per image after ANMS (BASELINE config 2: ~1500; reference: 500)")
     ap.add_argument("--landmarks", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -123,12 +123,12 @@ def main():
     pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
                             with_ba=not args.no_ba)
     dev = pipe.dev
-    gathered = torch.zeros((world, B, 7), dtype=torch.float64, device=dev) if world > 1 else None
+    from stereo_visual_slam_amd.sharding import gather_poses
 
     def one_step():
         pipe.step()
         if world > 1:  # throughput-mode pose gather (RCCL over xGMI), 56 B per keyframe
-            dist.all_gather_into_tensor(gathered.view(-1), pipe.d_Tpnp.view(-1))
+            gather_poses(pipe.d_Tpnp, dist)
 
     for _ in range(args.warmup):
         one_step()

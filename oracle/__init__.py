@@ -103,7 +103,7 @@ def build_pyramid(img, nlevels=8, nfeatures=3000):
 
 def fast_corner_score(img, x, y, threshold=20):
     img = _u8img(img)
-    return lib().vo_fast_corner_score(C.c_void_p(img.ctypes.data + y * img.strides[0] + x), img.strides[0], threshold)
+    return lib().vo_fast_corner_score(C.c_void_p(int(img.ctypes.data) + int(y) * int(img.strides[0]) + int(x)), int(img.strides[0]), int(threshold))
 
 
 def fast9_16(img, threshold=20, nonmax=True, cap=None):

@@ -35,7 +35,7 @@ class KeyframePipeline:
         d = self.dev
         # ---- inputs: 2B images [left 0..B-1 | right 0..B-1]; consecutive keyframes of `unique_scenes` short sequences
         imgs = np.zeros((2 * B, self.h, self.pitch), np.uint8)
-        per = max(2, (B + unique_scenes - 1) // unique_scenes)
+        per = 4  # frames per rendered sequence; the batch tiles `unique_scenes` sequences of `per` consecutive keyframes
         seqs = {}
         for b in range(B):
             s, f = (b // per) % unique_scenes, b % per

@@ -112,26 +112,32 @@ class Scene:
         u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
         d = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1) @ Rwc.T
         best_t = np.full(u.shape, np.inf)
-        img = np.zeros(u.shape)
-        # backdrop
+        img = np.full(u.shape, 90.0)
+        pid = np.zeros(u.shape, np.int32)          # winning plane per pixel (0 = none)
+        A = np.zeros(u.shape); Bc = np.zeros(u.shape)  # plane coordinates of the hit
         with np.errstate(divide="ignore", invalid="ignore"):
+            # backdrop
             tt = (self.back_z - o[2]) / d[..., 2]
             ok = tt > 0
-            X = o[0] + tt * d[..., 0]; Y = o[1] + tt * d[..., 1]
-            img = np.where(ok, _texture(X * 0.25, Y * 0.25, 1, self.seed), 90.0)
-            best_t = np.where(ok, tt, best_t)
+            best_t = np.where(ok, tt, best_t); pid = np.where(ok, 1, pid)
+            A = np.where(ok, (o[0] + tt * d[..., 0]) * 0.25, A); Bc = np.where(ok, (o[1] + tt * d[..., 1]) * 0.25, Bc)
             # ground
             tt = (self.ground_y - o[1]) / d[..., 1]
-            X = o[0] + tt * d[..., 0]; Z = o[2] + tt * d[..., 2]
             ok = (tt > 0) & (tt < best_t)
-            img = np.where(ok, _texture(X, Z, 2, self.seed), img)
-            best_t = np.where(ok, tt, best_t)
+            best_t = np.where(ok, tt, best_t); pid = np.where(ok, 2, pid)
+            A = np.where(ok, o[0] + tt * d[..., 0], A); Bc = np.where(ok, o[2] + tt * d[..., 2], Bc)
             for i, (z, x0, x1, y0, y1) in enumerate(self.walls):
                 tt = (z - o[2]) / d[..., 2]
                 X = o[0] + tt * d[..., 0]; Y = o[1] + tt * d[..., 1]
                 ok = (tt > 0) & (tt < best_t) & (X >= x0) & (X <= x1) & (Y >= y0) & (Y <= y1)
-                img = np.where(ok, _texture(X, Y, 3 + i, self.seed), img)
-                best_t = np.where(ok, tt, best_t)
+                best_t = np.where(ok, tt, best_t); pid = np.where(ok, 3 + i, pid)
+                A = np.where(ok, X, A); Bc = np.where(ok, Y, Bc)
+        # texture lookup once per pixel, for the winning plane only
+        for p in np.unique(pid):
+            if p == 0:
+                continue
+            m = pid == p
+            img[m] = _texture(A[m], Bc[m], int(p), self.seed)
         depth = best_t * 1.0  # z-depth along camera axis since d_cam.z == 1
         return np.clip(np.rint(img), 0, 255).astype(np.uint8), depth
 

@@ -1,0 +1,71 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/vslam_hip.h declares; the product has no CPU
+fallback (context creation fails loudly without a GPU) and never touches oracle/."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "vslam_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(vslam_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(pkg):
+    lib = pkg.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(pkg.ABI_SYMBOLS) == declared
+
+
+def test_header_is_plain_c():
+    src = '#include "vslam_hip.h"\nint main(void){ vslam_params p; vslam_default_params(&p); return sizeof(vslam_keypoint)==28 && sizeof(vslam_dmatch)==16 ? 0 : 1; }\n'
+    out = "/tmp/abi_c_check.o"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-c", "-", "-o", out], input=src.encode(), check=True)
+
+
+def test_struct_layouts(pkg):
+    import ctypes as C
+    assert pkg.KEYPOINT_DTYPE.itemsize == 28 and pkg.DMATCH_DTYPE.itemsize == 16
+    p = pkg.default_params()
+    assert (p.img_w, p.img_h, p.orb_nfeatures, p.anms_num, p.fast_threshold) == (1241, 376, 3000, 500, 20)
+    assert list(p.cam) == [718.856, 718.856, 607.1928, 185.2157, 0.573]
+    assert (p.depth_min, p.depth_max, p.depth_reliable, p.match_ratio, p.match_gap_thr, p.huber_delta, p.pnp_reproj_thr) == (10, 400, 40, 2.0, 30.0, 5.991, 4.0)
+    assert C.sizeof(pkg.LmStats) == 4 + 4 + 3 * 8 + 32 * 8 * 2 + 32 * 4
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.VslamError) as e:
+        pkg.VO()
+    assert "no HIP device" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_product_never_references_oracle():
+    pk = os.path.join(ROOT, "stereo-visual-slam_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", ".inc")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "vo_oracle" not in txt and "libvo_oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_check_motion_host_scalar(pkg, oracle):
+    """vslam_check_motion is host arithmetic and runs without a GPU"""
+    import ctypes as C
+    import numpy as np
+    lib = pkg.load_library()
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        xi = rng.normal(0, 2.0, 6); xi[3:] *= 0.3
+        T = oracle.se3_exp(xi); n = int(rng.integers(0, 25)); gap = float(rng.integers(1, 4))
+        got = lib.vslam_check_motion(n, T.ctypes.data_as(C.c_void_p), C.c_double(gap))
+        assert bool(got) == oracle.check_motion(n, T, gap)
