@@ -1,0 +1,57 @@
+// vo_host.hpp -- C++ mirror of vslam::VO (/root/reference/include/stereo_visual_slam_main/visual_odometry.hpp:27-185)
+// on top of the C-ABI.  Same public state and method names; OpenCV/ROS types are replaced by the PODs in types.hpp and
+// every arithmetic-heavy step is one C-ABI call into libvslam_hip.so.  Stereo depth uses the north_star stage
+// (L/R match + DLT) because SGBM is not built yet.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "map_host.hpp"
+#include "types.hpp"
+
+namespace vslam {
+
+enum TrackState { Init, Track, Lost };
+
+// replaces cv::imread on `dataset + "image_0/%06d.png"` (visual_odometry.cpp:37-68): binary PGM (P5) files
+struct ImageSource {
+    std::string dataset_;
+    explicit ImageSource(std::string dataset) : dataset_(std::move(dataset)) {}
+    int read(int id, Image& left, Image& right) const;
+    static int read_pgm(const std::string& path, Image& img);
+};
+
+class VO {
+public:
+    Frame frame_last_;
+    Frame frame_current_;
+    Map& my_map_;
+    ImageSource source_;
+    vslam_ctx* ctx_;
+    int num_inliers_ = 0;
+    SE3 T_c_l_;
+    SE3 T_c_w_;
+    int seq_ = 1;
+    TrackState state_ = Init;
+    int num_lost_ = 0;
+    int curr_keyframe_id_ = 0;
+    int curr_landmark_id_ = 0;
+    int pnp_iterations_ = 10;
+
+    VO(std::string dataset, vslam_ctx* ctx, Map& map) : my_map_(map), source_(std::move(dataset)), ctx_(ctx) {}
+
+    int read_img(int id, Image& left_img, Image& right_img) { return source_.read(id, left_img, right_img); }
+    int feature_detection(const Image& img, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors);
+    void adaptive_non_maximal_suppresion(std::vector<KeyPoint>& keypoints, const int num);
+    int feature_matching(const DescriptorMat& descriptors_1, const DescriptorMat& descriptors_2, std::vector<DMatch>& feature_matches);
+    std::vector<bool> set_ref_3d_position(std::vector<Point3f>& pts_3d, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors, Frame& frame);
+    void motion_estimation(Frame& frame);
+    bool check_motion_estimation();
+    bool insert_key_frame(bool check, std::vector<Point3f>& pts_3d, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors);
+    void move_frame() { frame_last_ = frame_current_; }
+    bool initialization();
+    bool tracking(bool& if_insert_keyframe);
+    bool pipeline(bool& if_insert_keyframe);
+};
+
+} // namespace vslam

@@ -255,3 +255,22 @@ def ba_window(n_kf=10, n_lm=3000, seed=2, sigma_px=0.5, outlier_frac=0.05, pose_
     uv[is_out] += rng.uniform(-30, 30, (int(is_out.sum()), 2))
     T0 = np.array([perturb_pose(T, rng, pose_sigma) for T in T_true])
     return dict(T_true=T_true, T0=T0, xyz=xyz, kf_idx=kf_idx, lm_idx=lm_idx, uv=uv.astype(np.float32), outlier=is_out)
+
+
+# --------------------------------------------------------------------------- dataset on disk (C++ driver)
+def write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, np.uint8).tobytes())
+
+
+def write_pgm_sequence(root, n_frames, seed=0, w=W_KITTI, h=H_KITTI):
+    """KITTI-like layout with binary PGMs: root/image_0/%06d.pgm (left), root/image_1/%06d.pgm (right).
+    returns the ground-truth T_c_w list"""
+    import os
+    os.makedirs(os.path.join(root, "image_0"), exist_ok=True); os.makedirs(os.path.join(root, "image_1"), exist_ok=True)
+    seq = stereo_sequence(n_frames, seed, w, h)
+    for i, (L, R, T, _) in enumerate(seq):
+        write_pgm(os.path.join(root, "image_0", "%06d.pgm" % i), L)
+        write_pgm(os.path.join(root, "image_1", "%06d.pgm" % i), R)
+    return [s[2] for s in seq]
