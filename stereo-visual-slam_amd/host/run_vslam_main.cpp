@@ -17,6 +17,7 @@ int main(int argc, char** argv) {
     const bool if_write_pose = argc > 3 ? std::atoi(argv[3]) != 0 : true;
     const int anms_num = argc > 4 ? std::atoi(argv[4]) : 500;
     const std::string traj = argc > 5 ? argv[5] : "estimated_traj.txt";
+    const bool q1 = argc > 6 ? std::atoi(argv[6]) != 0 : true; // reproduce the reference's feature_id-as-index behaviour
 
     vslam::Image probe_l, probe_r;
     if (vslam::ImageSource(dataset).read(0, probe_l, probe_r) != 0) return 1;
@@ -29,23 +30,24 @@ int main(int argc, char** argv) {
     std::remove(traj.c_str());
     vslam::Map my_map(if_write_pose, traj);
     vslam::VO my_VO(dataset, ctx, my_map);
-    int n_keyframes = 0, n_ok = 0;
+    int n_keyframes = 0, n_ok = 0, n_ba = 0;
     for (int ite = 0; ite < n_frames; ite++) { // run_vslam.cpp:40
         bool if_insert_keyframe = false;
         const bool not_lost = my_VO.pipeline(if_insert_keyframe);
         if (if_insert_keyframe) ++n_keyframes;
         if (not_lost) ++n_ok;
         if (if_insert_keyframe && my_map.keyframes_.size() >= 10) { // :58-71
-            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, false, false, 5);
-            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, false, false, 5);
-            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, true, false, 10);
-            vslam::optimize_pose_only(ctx, my_map.keyframes_, my_map.landmarks_, true, 10);
+            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, false, false, 5, q1);
+            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, false, false, 5, q1);
+            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, true, false, 10, q1);
+            vslam::optimize_pose_only(ctx, my_map.keyframes_, my_map.landmarks_, true, 10, q1);
+            ++n_ba;
         }
         if (!not_lost) break;
     }
     if (if_write_pose) my_map.write_remaining_pose(); // :84-87
-    std::printf("frames %d keyframes_inserted %d map_keyframes %zu landmarks %zu last_inliers %d\n", my_VO.seq_, n_keyframes, my_map.keyframes_.size(),
-                my_map.landmarks_.size(), my_VO.num_inliers_);
+    std::printf("frames %d keyframes_inserted %d ba_runs %d map_keyframes %zu landmarks %zu last_inliers %d\n", my_VO.seq_, n_keyframes, n_ba,
+                my_map.keyframes_.size(), my_map.landmarks_.size(), my_VO.num_inliers_);
     const auto t = my_VO.T_c_w_.inverse().translation();
     std::printf("final_position %.6f %.6f %.6f\n", t[0], t[1], t[2]);
     vslam_destroy(ctx);
