@@ -20,16 +20,24 @@
 // No MFMA: the largest dense object is the 72x72 reduced system; the path is latency/f64-VALU bound.
 #include "vslam_internal.h"
 
+#include <stdlib.h>
+
+#include <vector>
+
 #include "se3_device.h"
 
 namespace vslam {
 
-constexpr int kLmBlock = 256;
+constexpr int kLmBlock = 512;
 constexpr int kLmWaves = kLmBlock / 64;
 constexpr int kMaxKf = VSLAM_MAX_KF;
 constexpr int kMaxNp = 6 * kMaxKf;
 constexpr int kMaxPairs = kMaxKf * (kMaxKf + 1) / 2;
 constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
+constexpr int kLin = 8;        // doubles per edge of linearisation scratch: {X, Y, 1/Z, w} + {ex, ey} (+2 pad: 64-B aligned windows)
+constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
+constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
+constexpr int kItemSlots = 10; // Schur work items (keyframe pairs) per wave: ceil(kMaxPairs / kLmWaves)
 
 size_t lm_hits_per_edge() { return kHitsPerEdge; }
 
@@ -40,10 +48,16 @@ struct LmShared {
     double Rt[kMaxKf * 12], RtTrial[kMaxKf * 12];
     double T[kMaxKf * 7], TTrial[kMaxKf * 7];
     double red[kLmWaves * 2];
-    double sc[8];
-    int cnt[kMaxPairs + 2];
+    double part[kMaxKf * kPoseParts * 27]; // per (pose, part) partial sums of the pose blocks
+    int ptot[kCntStride];                  // hits per keyframe pair
+    uint16_t cnt[kLmWaves * kCntStride];   // per-wave counters / running offsets of the list builders
+    uint8_t item[kLmWaves * kItemSlots];   // Schur work items (pair << 1 | row half) dealt to waves, 0xFF = none
+    uint8_t pk1[kCntStride], pk2[kCntStride];
     int flag[8];
 };
+static_assert(kMaxKf * kPoseParts >= kLmWaves, "part[] must hold one slot per wave for single-pose problems");
+static_assert(kLmWaves <= 16, "cnt rows");
+static_assert(kMaxPairs <= kLmWaves * kItemSlots, "item[] too small");
 
 struct LmKernelArgs {
     LmWindowArgs a;
@@ -53,6 +67,8 @@ struct LmKernelArgs {
     uint8_t* act;     // total_lm
     uint8_t* eo;      // total_lm x kMaxKf
     int32_t* status;  // n_windows
+    long long* dbg_cycles; // tuning aid (VSLAM_LM_PROFILE=1): 16 phase cycle counters per window, thread 0
+    int dbg_skip;     // tuning aid (VSLAM_LM_SKIP): bit0 Schur hits, bit1 Cholesky, bit2 pose blocks, bit3 landmark blocks, bit4 eval, bit5 back-subst, bit6 setup lists
 };
 
 __device__ inline double wave_sum(double v) {
@@ -94,18 +110,13 @@ __device__ inline void huber(double e, double delta, double& rho, double& w) {
     else { const double s = sqrt(e); rho = 2 * s * delta - dsqr; w = delta / s; }
 }
 
-// 2x6 pose Jacobian of the reprojection error; mode 0: EdgeProjection (Zinv = 1/(Z+1e-18)), mode 1: PoseOnlyEdgeProjection
-__device__ inline void jac_pose(const double* K, double X, double Y, double Z, int mode, double A[12]) {
+// 2x6 pose Jacobian of the reprojection error from (X, Y, 1/Z).  EdgeProjection uses 1/(Z+1e-18) (optimization.cpp:66),
+// PoseOnlyEdgeProjection divides by Z (:96-100); the caller passes the matching reciprocal.
+__device__ inline void jac_pose(const double* K, double X, double Y, double Zi, double A[12]) {
     const double fx = K[0], fy = K[1];
-    if (mode == 0) {
-        const double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;
-        A[0] = -fx * Zinv; A[1] = 0; A[2] = fx * X * Zinv2; A[3] = fx * X * Y * Zinv2; A[4] = -fx - fx * X * X * Zinv2; A[5] = fx * Y * Zinv;
-        A[6] = 0; A[7] = -fy * Zinv; A[8] = fy * Y * Zinv2; A[9] = fy + fy * Y * Y * Zinv2; A[10] = -fy * X * Y * Zinv2; A[11] = -fy * X * Zinv;
-    } else {
-        const double Z2 = Z * Z;
-        A[0] = -fx / Z; A[1] = 0; A[2] = fx * X / Z2; A[3] = fx * X * Y / Z2; A[4] = -fx - fx * X * X / Z2; A[5] = fx * Y / Z;
-        A[6] = 0; A[7] = -fy / Z; A[8] = fy * Y / (Z * Z); A[9] = fy + fy * Y * Y / Z2; A[10] = -fy * X * Y / Z2; A[11] = -fy * X / Z;
-    }
+    const double Zi2 = Zi * Zi;
+    A[0] = -fx * Zi; A[1] = 0; A[2] = fx * X * Zi2; A[3] = fx * X * Y * Zi2; A[4] = -fx - fx * X * X * Zi2; A[5] = fx * Y * Zi;
+    A[6] = 0; A[7] = -fy * Zi; A[8] = fy * Y * Zi2; A[9] = fy + fy * Y * Y * Zi2; A[10] = -fy * X * Y * Zi2; A[11] = -fy * X * Zi;
 }
 // 2x3 landmark Jacobian = A[:, 0:3] * R
 __device__ inline void jac_point(const double A[12], const double* R, double B[6]) {
@@ -198,28 +209,45 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
     double* bl = a.bl + 3 * (size_t)lm0;
     double* Dinv = a.Dinv + 6 * (size_t)lm0;
     double* db = a.db + 3 * (size_t)lm0;
-    double* lin = a.lin + 6 * (size_t)e0;
+    double* lin = a.lin + kLin * (size_t)e0;
     double* chi2 = a.chi2 + e0;
     int32_t* lm_ptr = a.lm_ptr + lm0 + w;
     int32_t* kf_ptr = a.kf_ptr + (size_t)w * (kMaxKf + 1);
     int32_t* kf_edges = a.kf_edges + e0;
     int32_t* pair_ptr = a.pair_ptr + (size_t)w * (kMaxPairs + 1);
-    int32_t* hits = a.pair_hits + 2 * (size_t)e0 * kHitsPerEdge;
+    int4* hits = reinterpret_cast<int4*>(a.pair_hits) + (size_t)e0 * kHitsPerEdge;
     uint8_t* act = ka.act + lm0;
     uint8_t* eo = ka.eo + (size_t)lm0 * kMaxKf;
     const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
     const double delta = a.huber_delta;
     const bool with_lm = (mode == 0);
+    const int npairs = nk * (nk + 1) / 2;
+    const int nparts = nk == 1 ? kLmWaves : kPoseParts; // a pose's edge list is split over `nparts` waves
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + 16 * (size_t)w : nullptr;
+    long long t_ph = cyc ? clock64() : 0;
+#define PH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); cyc[i] += t1__ - t_ph; t_ph = t1__; } } while (0)
+    // component-major (SoA) scratch: consecutive lanes touch consecutive addresses in every edge- or landmark-ordered loop
+    // per-edge linearisation records, AoS so that gathers (by-pose lists, Schur hits) fetch one 32-B chunk per edge:
+    double4* recA = reinterpret_cast<double4*>(lin);                 // {X, Y, 1/Z, w}
+    double2* recB = reinterpret_cast<double2*>(lin + 4 * (size_t)ne); // {ex, ey}
+#define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
     auto EKF = [&](int e) -> int { return IMPL ? 0 : kfi[e]; };
     auto ELM = [&](int e) -> int { return IMPL ? e : lmi[e]; };
 
     // ------------------------------------------------------------------ setup
     if (tid < 8) sm.flag[tid] = 0;
     for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = a.T[(size_t)w * nk * 7 + i];
+    for (int i = tid; i < kLmWaves * kCntStride; i += kLmBlock) sm.cnt[i] = 0;
+    if (tid < npairs) {
+        int k1 = 0, rem = tid;
+        while (rem >= nk - k1) { rem -= nk - k1; ++k1; }
+        sm.pk1[tid] = (uint8_t)k1; sm.pk2[tid] = (uint8_t)(k1 + rem);
+    }
     __syncthreads();
     if (tid < nk) expand_pose(&sm.T[7 * tid], &sm.Rt[12 * tid]);
     for (int l = tid; l < nl; l += kLmBlock) {
-        P[3 * l] = (double)xyz[3 * l]; P[3 * l + 1] = (double)xyz[3 * l + 1]; P[3 * l + 2] = (double)xyz[3 * l + 2];
+        PC(P, 0, l) = (double)xyz[3 * l]; PC(P, 1, l) = (double)xyz[3 * l + 1]; PC(P, 2, l) = (double)xyz[3 * l + 2];
     }
     if (!IMPL) {
         // CSR by landmark from the sorted lm_idx; bad indices / unsorted input -> error flag
@@ -246,97 +274,147 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
     }
     __syncthreads();
     if (!IMPL) {
-        // by-pose edge lists (ascending edge id inside a pose): wave per keyframe, ballot-ordered append
+        // ---- by-pose edge lists (ascending edge id inside a pose).  Every wave owns a contiguous edge range, loads it
+        // once per pass (few dependent global loads), and ranks its edges per keyframe with ballots.
+        const int e_lo = (int)((long long)ne * wave / kLmWaves), e_hi = (int)((long long)ne * (wave + 1) / kLmWaves);
         for (int pass = 0; pass < 2; ++pass) {
-            for (int k = wave; k < nk; k += kLmWaves) {
-                int base = pass ? kf_ptr[k] : 0;
-                for (int c = 0; c < ne; c += 64) {
-                    const int e = c + lane;
-                    const bool hit = e < ne && kfi[e] == k && act[lmi[e]];
-                    const unsigned long long m = __ballot(hit);
-                    if (pass && hit) kf_edges[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
-                    base += __popcll(m);
+            int run[kMaxKf];
+#pragma unroll
+            for (int kk = 0; kk < kMaxKf; ++kk) run[kk] = pass ? (int)sm.cnt[wave * kCntStride + kk] : 0;
+            for (int base = e_lo; base < e_hi; base += 64) {
+                const int e = base + lane;
+                int k = -1;
+                if (e < e_hi && act[lmi[e]]) k = kfi[e];
+#pragma unroll
+                for (int kk = 0; kk < kMaxKf; ++kk) {
+                    if (kk < nk) {
+                        const unsigned long long m = __ballot(k == kk);
+                        if (pass && k == kk) kf_edges[run[kk] + __popcll(m & lt_mask)] = e;
+                        run[kk] += __popcll(m);
+                    }
                 }
-                if (!pass && lane == 0) sm.cnt[k] = base;
             }
-            __syncthreads();
             if (!pass) {
-                if (tid == 0) { int acc = 0; for (int k = 0; k < nk; ++k) { kf_ptr[k] = acc; acc += sm.cnt[k]; } kf_ptr[nk] = acc; }
+                if (lane == 0)
+#pragma unroll
+                    for (int kk = 0; kk < kMaxKf; ++kk) sm.cnt[wave * kCntStride + kk] = run[kk];
+                __syncthreads();
+                if (tid == 0) {
+                    int acc = 0;
+                    for (int kk = 0; kk < nk; ++kk) {
+                        kf_ptr[kk] = acc;
+                        for (int ww = 0; ww < kLmWaves; ++ww) { const int c = sm.cnt[ww * kCntStride + kk]; sm.cnt[ww * kCntStride + kk] = acc; acc += c; }
+                    }
+                    kf_ptr[nk] = acc;
+                }
                 __syncthreads();
             }
         }
+        __syncthreads();
         if (with_lm) {
-            // per-landmark edge offset table, then the Schur hit lists per keyframe pair
+            // ---- per-landmark edge offset table eo[l][k] (0xFF = keyframe k does not see landmark l)
             for (int l = tid; l < nl; l += kLmBlock) {
-                for (int k = 0; k < nk; ++k) eo[(size_t)l * kMaxKf + k] = 0xFF;
+                uint32_t wds[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 if (act[l]) {
                     const int b0 = lm_ptr[l], b1 = lm_ptr[l + 1];
                     for (int e = b0; e < b1; ++e) {
                         const int k = kfi[e];
-                        if (eo[(size_t)l * kMaxKf + k] != 0xFF || e - b0 >= 0xFF) sm.flag[7] = 2; // duplicate (kf, landmark) edge
-                        eo[(size_t)l * kMaxKf + k] = (uint8_t)(e - b0);
+                        const uint32_t cur = (wds[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                        if (cur != 0xFFu || e - b0 >= 0xFF) sm.flag[7] = 2; // duplicate (keyframe, landmark) edge
+                        wds[k >> 2] = (wds[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)(e - b0) << (8 * (k & 3)));
                     }
                 }
+                uint32_t* dst = reinterpret_cast<uint32_t*>(eo + (size_t)l * kMaxKf);
+                dst[0] = wds[0]; dst[1] = wds[1]; dst[2] = wds[2];
             }
+            for (int i = tid; i < kLmWaves * kCntStride; i += kLmBlock) sm.cnt[i] = 0;
             __syncthreads();
             if (sm.flag[7]) { if (tid == 0) ka.status[w] = VSLAM_ERR_ARG; return; }
-            const int npairs = nk * (nk + 1) / 2;
+            // ---- Schur hit lists per keyframe pair, landmark-ordered: wave = contiguous landmark range, 2 passes
+            const int l_lo = (int)((long long)nl * wave / kLmWaves), l_hi = (int)((long long)nl * (wave + 1) / kLmWaves);
             for (int pass = 0; pass < 2; ++pass) {
-                for (int p = wave; p < npairs; p += kLmWaves) {
-                    int k1 = 0, rem = p;
-                    while (rem >= nk - k1) { rem -= nk - k1; ++k1; }
-                    const int k2 = k1 + rem;
-                    int base = pass ? pair_ptr[p] : 0;
-                    for (int c = 0; c < nl; c += 64) {
-                        const int l = c + lane;
-                        uint8_t o1 = 0xFF, o2 = 0xFF;
-                        if (l < nl) { o1 = eo[(size_t)l * kMaxKf + k1]; o2 = eo[(size_t)l * kMaxKf + k2]; }
-                        const bool hit = o1 != 0xFF && o2 != 0xFF;
-                        const unsigned long long m = __ballot(hit);
-                        if (pass && hit) {
-                            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                            hits[2 * slot] = lm_ptr[l] + o1;
-                            hits[2 * slot + 1] = lm_ptr[l] + o2;
-                        }
-                        base += __popcll(m);
+                for (int base = l_lo; base < l_hi; base += 64) {
+                    const int l = base + lane;
+                    uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu;
+                    int eb0 = 0;
+                    if (l < l_hi) {
+                        const uint32_t* src = reinterpret_cast<const uint32_t*>(eo + (size_t)l * kMaxKf);
+                        w0 = src[0]; w1 = src[1]; w2 = src[2];
+                        eb0 = lm_ptr[l];
                     }
-                    if (!pass && lane == 0) sm.cnt[p] = base;
+                    for (int p = 0; p < npairs; ++p) {
+                        const int k1 = sm.pk1[p], k2 = sm.pk2[p];
+                        const uint32_t wa = k1 < 4 ? w0 : (k1 < 8 ? w1 : w2), wb = k2 < 4 ? w0 : (k2 < 8 ? w1 : w2);
+                        const uint32_t o1 = (wa >> (8 * (k1 & 3))) & 0xFFu, o2 = (wb >> (8 * (k2 & 3))) & 0xFFu;
+                        const bool hit = o1 != 0xFFu && o2 != 0xFFu;
+                        const unsigned long long m = __ballot(hit);
+                        if (m == 0) continue; // uniform
+                        const int cur = sm.cnt[wave * kCntStride + p];
+                        if (pass && hit) hits[cur + __popcll(m & lt_mask)] = make_int4(eb0 + (int)o1, eb0 + (int)o2, l, 0);
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) sm.cnt[wave * kCntStride + p] = (uint16_t)0 + cur + __popcll(m);
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
-                __syncthreads();
                 if (!pass) {
-                    if (tid == 0) { int acc = 0; for (int p = 0; p < npairs; ++p) { pair_ptr[p] = acc; acc += sm.cnt[p]; } pair_ptr[npairs] = acc; }
+                    __syncthreads();
+                    if (tid < npairs) { int t = 0; for (int ww = 0; ww < kLmWaves; ++ww) t += sm.cnt[ww * kCntStride + tid]; sm.ptot[tid] = t; }
+                    __syncthreads();
+                    if (tid == 0) { int acc = 0; for (int p = 0; p < npairs; ++p) { pair_ptr[p] = acc; acc += sm.ptot[p]; } pair_ptr[npairs] = acc; }
+                    __syncthreads();
+                    if (tid < npairs) { int run = pair_ptr[tid]; for (int ww = 0; ww < kLmWaves; ++ww) { const int c = sm.cnt[ww * kCntStride + tid]; sm.cnt[ww * kCntStride + tid] = run; run += c; } }
                     __syncthreads();
                 }
             }
+            // ---- balance the Schur work: item = keyframe pair; rank by hit count, deal ranks to waves in snake order
+            const int nitems = npairs;
+            for (int i = tid; i < kLmWaves * kItemSlots; i += kLmBlock) sm.item[i] = 0xFF;
+            __syncthreads();
+            if (tid < nitems) {
+                const int mine = sm.ptot[tid];
+                int rank = 0;
+                for (int j = 0; j < nitems; ++j) { const int c = sm.ptot[j]; rank += (c > mine) || (c == mine && j < tid); }
+                const int row = rank / kLmWaves, col = rank % kLmWaves;
+                sm.item[((row & 1) ? kLmWaves - 1 - col : col) * kItemSlots + row] = (uint8_t)tid;
+            }
         }
     }
+    __syncthreads();
 
+    PH(0);
     // ------------------------------------------------------------------ LM iterations
     double lambda = 0, ni = 2, currentChi = 0;
     int it = 0, total_trials = 0;
     vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
 
-    // error evaluation at (Rt, Pcur); STORE_LIN also records the linearisation point
+    // error evaluation at (Rt, Pcur); store_lin also records the linearisation point (X, Y, 1/Z, w, e, B)
     auto eval = [&](const double* Rt, const double* Pcur, bool store_lin) -> double {
         double part = 0;
+#pragma unroll 2
         for (int e = tid; e < ne; e += kLmBlock) {
             const int l = ELM(e);
             if (!act[l]) continue;
             const int k = EKF(e);
             double X, Y, Z, ex, ey;
-            project_err(&Rt[12 * k], K, Pcur[3 * l], Pcur[3 * l + 1], Pcur[3 * l + 2], uv[2 * e], uv[2 * e + 1], X, Y, Z, ex, ey);
+            const float2 z = reinterpret_cast<const float2*>(uv)[e];
+            project_err(&Rt[12 * k], K, PC(Pcur, 0, l), PC(Pcur, 1, l), PC(Pcur, 2, l), z.x, z.y, X, Y, Z, ex, ey);
             const double c = ex * ex + ey * ey;
             chi2[e] = c;
             double rho, wgt;
             huber(c, delta, rho, wgt);
             part += rho;
-            if (store_lin) { double* q = lin + 6 * (size_t)e; q[0] = X; q[1] = Y; q[2] = Z; q[3] = wgt; q[4] = ex; q[5] = ey; }
+            if (store_lin) {
+                const double Zi = with_lm ? 1.0 / (Z + 1e-18) : 1.0 / Z; // optimization.cpp:66 vs :96-100
+                recA[e] = make_double4(X, Y, Zi, wgt);
+                recB[e] = make_double2(ex, ey);
+            }
         }
         return block_sum(part, sm.red);
     };
 
     for (it = 0; it < iters; ++it) {
         currentChi = eval(sm.Rt, P, true);
+        PH(1);
         if (it == 0 && st && tid == 0) st->chi2_init = currentChi;
         // ---- buildSystem: landmark blocks
         double maxdiag = 0;
@@ -345,55 +423,67 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                 if (!act[l]) continue;
                 double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
                 for (int e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
-                    const double* q = lin + 6 * (size_t)e;
+                    const double4 ra = recA[e];
+                    const double2 rb = recB[e];
                     double A[12], B[6];
-                    jac_pose(K, q[0], q[1], q[2], 0, A);
+                    jac_pose(K, ra.x, ra.y, ra.z, A);
                     jac_point(A, &sm.Rt[12 * EKF(e)], B);
-                    const double wg = q[3];
+                    const double wg = ra.w, ex = rb.x, ey = rb.y;
                     h[0] += wg * (B[0] * B[0] + B[3] * B[3]); h[1] += wg * (B[0] * B[1] + B[3] * B[4]); h[2] += wg * (B[0] * B[2] + B[3] * B[5]);
                     h[3] += wg * (B[1] * B[1] + B[4] * B[4]); h[4] += wg * (B[1] * B[2] + B[4] * B[5]); h[5] += wg * (B[2] * B[2] + B[5] * B[5]);
-                    g[0] -= wg * (B[0] * q[4] + B[3] * q[5]); g[1] -= wg * (B[1] * q[4] + B[4] * q[5]); g[2] -= wg * (B[2] * q[4] + B[5] * q[5]);
+                    g[0] -= wg * (B[0] * ex + B[3] * ey); g[1] -= wg * (B[1] * ex + B[4] * ey); g[2] -= wg * (B[2] * ex + B[5] * ey);
                 }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) Hll[6 * (size_t)l + i] = h[i];
+                for (int i = 0; i < 6; ++i) PC(Hll, i, l) = h[i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) bl[3 * (size_t)l + i] = g[i];
+                for (int i = 0; i < 3; ++i) PC(bl, i, l) = g[i];
                 maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
             }
         }
-        // ---- buildSystem: pose blocks (wave per pose)
-        for (int k = wave; k < nk; k += kLmWaves) {
+        PH(2);
+        // ---- buildSystem: pose blocks.  item = (pose, part): one wave sums a third of the pose's edge list
+        for (int item = wave; item < nk * nparts; item += kLmWaves) {
+            const int k = item / nparts, part = item - k * nparts;
             double acc[27];
 #pragma unroll
             for (int i = 0; i < 27; ++i) acc[i] = 0;
             const int b0 = IMPL ? 0 : kf_ptr[k], b1 = IMPL ? ne : kf_ptr[k + 1];
-            for (int j = b0 + lane; j < b1; j += 64) {
+            const int s0 = b0 + (int)((long long)(b1 - b0) * part / nparts), s1 = b0 + (int)((long long)(b1 - b0) * (part + 1) / nparts);
+            for (int j = s0 + lane; j < s1; j += 64) {
                 const int e = IMPL ? j : kf_edges[j];
-                const double* q = lin + 6 * (size_t)e;
+                const double4 ra = recA[e];
+                const double2 rb = recB[e];
                 double A[12];
-                jac_pose(K, q[0], q[1], q[2], mode, A);
-                const double wg = q[3];
+                jac_pose(K, ra.x, ra.y, ra.z, A);
+                const double wg = ra.w, ex = rb.x, ey = rb.y;
                 int idx = 0;
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
                     for (int c = r; c < 6; ++c) acc[idx++] += wg * (A[r] * A[c] + A[6 + r] * A[6 + c]);
 #pragma unroll
-                for (int r = 0; r < 6; ++r) acc[21 + r] -= wg * (A[r] * q[4] + A[6 + r] * q[5]);
+                for (int r = 0; r < 6; ++r) acc[21 + r] -= wg * (A[r] * ex + A[6 + r] * ey);
             }
 #pragma unroll
             for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-            if (lane == 0) {
-                int idx = 0;
+            if (lane == 0)
 #pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = r; c < 6; ++c) { sm.Hpp[36 * k + 6 * r + c] = acc[idx]; sm.Hpp[36 * k + 6 * c + r] = acc[idx]; ++idx; }
-#pragma unroll
-                for (int r = 0; r < 6; ++r) sm.bp[6 * k + r] = acc[21 + r];
-            }
+                for (int i = 0; i < 27; ++i) sm.part[item * 27 + i] = acc[i];
         }
         __syncthreads();
+        for (int t = tid; t < nk * 27; t += kLmBlock) { // parts summed in a fixed order
+            const int k = t / 27, i = t - k * 27;
+            double v = 0;
+            for (int part = 0; part < nparts; ++part) v += sm.part[(k * nparts + part) * 27 + i];
+            if (i < 21) {
+                int r = 0, rem = i;
+                while (rem >= 6 - r) { rem -= 6 - r; ++r; }
+                const int c = r + rem;
+                sm.Hpp[36 * k + 6 * r + c] = v; sm.Hpp[36 * k + 6 * c + r] = v;
+            } else sm.bp[6 * k + i - 21] = v;
+        }
+        __syncthreads();
+        PH(3);
         if (it == 0) { // computeLambdaInit: tau * max |H_jj| over every vertex
             if (tid < np) maxdiag = fmax(maxdiag, fabs(sm.Hpp[36 * (tid / 6) + 7 * (tid % 6)]));
             lambda = 1e-5 * block_max(maxdiag, sm.red);
@@ -410,31 +500,34 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                 int bad = 0;
                 for (int l = tid; l < nl; l += kLmBlock) {
                     if (!act[l]) continue;
-                    const double* h = Hll + 6 * (size_t)l;
                     double Di[6];
-                    if (!inv3_sym(h[0] + lambda, h[1], h[2], h[3] + lambda, h[4], h[5] + lambda, Di)) bad = 1;
-                    const double* g = bl + 3 * (size_t)l;
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) Dinv[6 * (size_t)l + i] = Di[i];
-                    db[3 * (size_t)l] = Di[0] * g[0] + Di[1] * g[1] + Di[2] * g[2];
-                    db[3 * (size_t)l + 1] = Di[1] * g[0] + Di[3] * g[1] + Di[4] * g[2];
-                    db[3 * (size_t)l + 2] = Di[2] * g[0] + Di[4] * g[1] + Di[5] * g[2];
+                    if (!inv3_sym(PC(Hll, 0, l) + lambda, PC(Hll, 1, l), PC(Hll, 2, l), PC(Hll, 3, l) + lambda, PC(Hll, 4, l), PC(Hll, 5, l) + lambda, Di)) bad = 1;
+                    const double g[3] = {PC(bl, 0, l), PC(bl, 1, l), PC(bl, 2, l)};
+                    double2* Dp = reinterpret_cast<double2*>(Dinv + 6 * (size_t)l);
+                    Dp[0] = make_double2(Di[0], Di[1]); Dp[1] = make_double2(Di[2], Di[3]); Dp[2] = make_double2(Di[4], Di[5]);
+                    PC(db, 0, l) = Di[0] * g[0] + Di[1] * g[1] + Di[2] * g[2];
+                    PC(db, 1, l) = Di[1] * g[0] + Di[3] * g[1] + Di[4] * g[2];
+                    PC(db, 2, l) = Di[2] * g[0] + Di[4] * g[1] + Di[5] * g[2];
                 }
                 if (bad) sm.flag[1] = 1;
                 for (int i = tid; i < np * np; i += kLmBlock) sm.S[i] = 0;
                 __syncthreads(); // Dinv/db visible (global, same workgroup) + S zeroed
-                // bs[k] = bp[k] - sum_e W_e db_l   (wave per pose)
-                for (int k = wave; k < nk; k += kLmWaves) {
+                PH(4);
+                // bs[k] = bp[k] - sum_e W_e db_l   (item = (pose, part))
+                for (int item = wave; item < nk * nparts; item += kLmWaves) {
+                    const int k = item / nparts, part = item - k * nparts;
                     double acc[6] = {0, 0, 0, 0, 0, 0};
-                    for (int j = kf_ptr[k] + lane; j < kf_ptr[k + 1]; j += 64) {
+                    const int b0 = kf_ptr[k], b1 = kf_ptr[k + 1];
+                    const int s0 = b0 + (int)((long long)(b1 - b0) * part / nparts), s1 = b0 + (int)((long long)(b1 - b0) * (part + 1) / nparts);
+                    for (int j = s0 + lane; j < s1; j += 64) {
                         const int e = kf_edges[j], l = lmi[e];
-                        const double* q = lin + 6 * (size_t)e;
+                        const double4 ra = recA[e];
                         double A[12], B[6];
-                        jac_pose(K, q[0], q[1], q[2], 0, A);
+                        jac_pose(K, ra.x, ra.y, ra.z, A);
                         jac_point(A, &sm.Rt[12 * k], B);
-                        const double* d3 = db + 3 * (size_t)l;
-                        const double m0 = q[3] * (B[0] * d3[0] + B[1] * d3[1] + B[2] * d3[2]);
-                        const double m1 = q[3] * (B[3] * d3[0] + B[4] * d3[1] + B[5] * d3[2]);
+                        const double d0 = PC(db, 0, l), d1 = PC(db, 1, l), d2 = PC(db, 2, l), wg = ra.w;
+                        const double m0 = wg * (B[0] * d0 + B[1] * d1 + B[2] * d2);
+                        const double m1 = wg * (B[3] * d0 + B[4] * d1 + B[5] * d2);
 #pragma unroll
                         for (int r = 0; r < 6; ++r) acc[r] += A[r] * m0 + A[6 + r] * m1;
                     }
@@ -442,49 +535,55 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                     for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
                     if (lane == 0)
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) sm.bs[6 * k + r] = sm.bp[6 * k + r] - acc[r];
+                        for (int r = 0; r < 6; ++r) sm.part[item * 27 + r] = acc[r];
                 }
-                // Schur blocks: S[k1][k2] = [k1==k2](Hpp + lambda I) - sum_hits W1 Dinv W2^T   (wave per pair)
-                const int npairs = nk * (nk + 1) / 2;
-                for (int p = wave; p < npairs; p += kLmWaves) {
-                    int k1 = 0, rem = p;
-                    while (rem >= nk - k1) { rem -= nk - k1; ++k1; }
-                    const int k2 = k1 + rem;
+                __syncthreads();
+                if (tid < np) {
+                    const int k = tid / 6, r = tid - 6 * k;
+                    double v = sm.bp[tid];
+                    for (int part = 0; part < nparts; ++part) v -= sm.part[(k * nparts + part) * 27 + r];
+                    sm.bs[tid] = v;
+                }
+                PH(5);
+                // Schur blocks: S[k1][k2] = [k1==k2](Hpp + lambda I) - sum_hits W1 Dinv W2^T.  item = (pair, row half), owned by one wave
+                for (int slot = 0; slot < kItemSlots; ++slot) {
+                    const int p = sm.item[wave * kItemSlots + slot];
+                    if (p == 0xFF) continue; // uniform per wave
+                    const int k1 = sm.pk1[p], k2 = sm.pk2[p];
                     double acc[36];
 #pragma unroll
                     for (int i = 0; i < 36; ++i) acc[i] = 0;
                     for (int j = pair_ptr[p] + lane; j < pair_ptr[p + 1]; j += 64) {
-                        const int ea = hits[2 * j], eb = hits[2 * j + 1], l = lmi[ea];
-                        const double* qa = lin + 6 * (size_t)ea;
-                        const double* qb = lin + 6 * (size_t)eb;
-                        const double* Di = Dinv + 6 * (size_t)l;
-                        double A1[12], B1[6], A2[12], B2[6];
-                        jac_pose(K, qa[0], qa[1], qa[2], 0, A1);
+                        const int4 h = hits[j];
+                        const double4 ra = recA[h.x], rb = recA[h.y];
+                        const double2* Dp = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
+                        const double2 Da = Dp[0], Db = Dp[1], Dc = Dp[2]; // D00 D01 | D02 D11 | D12 D22
+                        double A1[12], A2[12], B1[6], B2[6];
+                        jac_pose(K, ra.x, ra.y, ra.z, A1);
                         jac_point(A1, &sm.Rt[12 * k1], B1);
-                        jac_pose(K, qb[0], qb[1], qb[2], 0, A2);
+                        jac_pose(K, rb.x, rb.y, rb.z, A2);
                         jac_point(A2, &sm.Rt[12 * k2], B2);
                         // M (2x2) = (w1 B1) Dinv (w2 B2)^T
                         double BD[6];
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
-                            BD[3 * r] = B1[3 * r] * Di[0] + B1[3 * r + 1] * Di[1] + B1[3 * r + 2] * Di[2];
-                            BD[3 * r + 1] = B1[3 * r] * Di[1] + B1[3 * r + 1] * Di[3] + B1[3 * r + 2] * Di[4];
-                            BD[3 * r + 2] = B1[3 * r] * Di[2] + B1[3 * r + 1] * Di[4] + B1[3 * r + 2] * Di[5];
+                            BD[3 * r] = B1[3 * r] * Da.x + B1[3 * r + 1] * Da.y + B1[3 * r + 2] * Db.x;
+                            BD[3 * r + 1] = B1[3 * r] * Da.y + B1[3 * r + 1] * Db.y + B1[3 * r + 2] * Dc.x;
+                            BD[3 * r + 2] = B1[3 * r] * Db.x + B1[3 * r + 1] * Dc.x + B1[3 * r + 2] * Dc.y;
                         }
-                        const double ww = qa[3] * qb[3];
+                        const double ww = ra.w * rb.w;
                         double M[4];
 #pragma unroll
                         for (int r = 0; r < 2; ++r)
 #pragma unroll
                             for (int c = 0; c < 2; ++c) M[2 * r + c] = ww * (BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]);
                         // C = A1^T M A2
-                        double AM[12]; // 6x2
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) { AM[2 * r] = A1[r] * M[0] + A1[6 + r] * M[2]; AM[2 * r + 1] = A1[r] * M[1] + A1[6 + r] * M[3]; }
+                        for (int r = 0; r < 6; ++r) {
+                            const double m0 = A1[r] * M[0] + A1[6 + r] * M[2], m1 = A1[r] * M[1] + A1[6 + r] * M[3];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) acc[6 * r + c] += AM[2 * r] * A2[c] + AM[2 * r + 1] * A2[6 + c];
+                            for (int c = 0; c < 6; ++c) acc[6 * r + c] += m0 * A2[c] + m1 * A2[6 + c];
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 36; ++i) acc[i] = wave_sum(acc[i]);
@@ -501,22 +600,54 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                     }
                 }
                 __syncthreads();
-                // Cholesky (right-looking, lower) on S, whole workgroup
-                for (int j = 0; j < np; ++j) {
-                    const double d = sm.S[j * np + j];
-                    if (!(d > 0.0) || !isfinite(d)) { ok2 = false; break; } // uniform: every thread reads the same LDS word
-                    const double ljj = sqrt(d);
+                PH(6);
+                // Cholesky S = L L^T, left-looking over 6x6 block columns (np = 6 nk): 3 barriers per block column
+                for (int J = 0; J < nk && ok2; ++J) {
+                    // (1) block column J -= L[.,0..J) L[J,0..J)^T   -- one lane per element of the (nk-J) x 1 block column
+                    const int nel = (nk - J) * 36;
+                    for (int t = tid; t < nel; t += kLmBlock) {
+                        const int I = J + t / 36, r = (t % 36) / 6, c = t % 6;
+                        double v = sm.S[(6 * I + r) * np + 6 * J + c];
+                        for (int kk = 0; kk < 6 * J; ++kk) v -= sm.S[(6 * I + r) * np + kk] * sm.S[(6 * J + c) * np + kk];
+                        sm.S[(6 * I + r) * np + 6 * J + c] = v;
+                    }
                     __syncthreads();
-                    for (int i = j + 1 + tid; i < np; i += kLmBlock) sm.S[i * np + j] /= ljj;
-                    if (tid == 0) sm.S[j * np + j] = ljj;
+                    // (2) factor the diagonal block (thread 0), flag failure
+                    if (tid == 0) {
+                        bool good = true;
+                        for (int j = 0; j < 6 && good; ++j) {
+                            double d = sm.S[(6 * J + j) * np + 6 * J + j];
+                            for (int kk = 0; kk < j; ++kk) d -= sm.S[(6 * J + j) * np + 6 * J + kk] * sm.S[(6 * J + j) * np + 6 * J + kk];
+                            if (!(d > 0.0) || !isfinite(d)) { good = false; break; }
+                            d = sqrt(d);
+                            sm.S[(6 * J + j) * np + 6 * J + j] = d;
+                            for (int i = j + 1; i < 6; ++i) {
+                                double v = sm.S[(6 * J + i) * np + 6 * J + j];
+                                for (int kk = 0; kk < j; ++kk) v -= sm.S[(6 * J + i) * np + 6 * J + kk] * sm.S[(6 * J + j) * np + 6 * J + kk];
+                                sm.S[(6 * J + i) * np + 6 * J + j] = v / d;
+                            }
+                        }
+                        if (!good) sm.flag[1] = 1;
+                    }
                     __syncthreads();
-                    const int rem = np - j - 1;
-                    for (int t = tid; t < rem * rem; t += kLmBlock) {
-                        const int i = j + 1 + t / rem, c = j + 1 + t % rem;
-                        if (c <= i) sm.S[i * np + c] -= sm.S[i * np + j] * sm.S[c * np + j];
+                    if (sm.flag[1]) { ok2 = false; break; } // uniform
+                    // (3) rows below: L[I][J] = S[I][J] L[J][J]^-T   -- one lane per row
+                    for (int t = tid; t < (nk - J - 1) * 6; t += kLmBlock) {
+                        const int row = 6 * (J + 1) + t;
+                        double x[6];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            double v = sm.S[row * np + 6 * J + c];
+#pragma unroll
+                            for (int kk = 0; kk < 6; ++kk) if (kk < c) v -= x[kk] * sm.S[(6 * J + c) * np + 6 * J + kk];
+                            x[c] = v / sm.S[(6 * J + c) * np + 6 * J + c];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) sm.S[row * np + 6 * J + c] = x[c];
                     }
                     __syncthreads();
                 }
+                PH(7);
                 if (sm.flag[1]) ok2 = false;
                 __syncthreads();
                 if (tid == 0) sm.flag[1] = 0;
@@ -562,31 +693,33 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                 if (!ok2) { for (int i = tid; i < np; i += kLmBlock) sm.xp[i] = 0; if (tid == 0) sm.flag[1] = 0; }
                 __syncthreads();
             }
+            PH(8);
             // ---- update: landmarks (back-substitution) and poses; computeScale
             double scale_part = 0;
             if (with_lm) {
                 for (int l = tid; l < nl; l += kLmBlock) {
-                    if (!act[l]) { Pt[3 * l] = P[3 * l]; Pt[3 * l + 1] = P[3 * l + 1]; Pt[3 * l + 2] = P[3 * l + 2]; continue; }
-                    const double* g = bl + 3 * (size_t)l;
+                    if (!act[l]) { PC(Pt, 0, l) = PC(P, 0, l); PC(Pt, 1, l) = PC(P, 1, l); PC(Pt, 2, l) = PC(P, 2, l); continue; }
+                    const double g[3] = {PC(bl, 0, l), PC(bl, 1, l), PC(bl, 2, l)};
                     double c0 = g[0], c1 = g[1], c2 = g[2];
                     for (int e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
                         const int k = kfi[e];
-                        const double* q = lin + 6 * (size_t)e;
+                        const double4 ra = recA[e];
                         double A[12], B[6];
-                        jac_pose(K, q[0], q[1], q[2], 0, A);
+                        jac_pose(K, ra.x, ra.y, ra.z, A);
                         jac_point(A, &sm.Rt[12 * k], B);
                         // W^T xp = w B^T (A xp_k)
                         double a0 = 0, a1 = 0;
 #pragma unroll
                         for (int r = 0; r < 6; ++r) { a0 += A[r] * sm.xp[6 * k + r]; a1 += A[6 + r] * sm.xp[6 * k + r]; }
-                        a0 *= q[3]; a1 *= q[3];
+                        a0 *= ra.w; a1 *= ra.w;
                         c0 -= B[0] * a0 + B[3] * a1; c1 -= B[1] * a0 + B[4] * a1; c2 -= B[2] * a0 + B[5] * a1;
                     }
-                    const double* Di = Dinv + 6 * (size_t)l;
-                    double x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
-                    double x1 = Di[1] * c0 + Di[3] * c1 + Di[4] * c2;
-                    double x2 = Di[2] * c0 + Di[4] * c1 + Di[5] * c2;
-                    Pt[3 * l] = P[3 * l] + x0; Pt[3 * l + 1] = P[3 * l + 1] + x1; Pt[3 * l + 2] = P[3 * l + 2] + x2;
+                    const double* Dq = Dinv + 6 * (size_t)l;
+                    const double D0 = Dq[0], D1 = Dq[1], D2 = Dq[2], D3 = Dq[3], D4 = Dq[4], D5 = Dq[5];
+                    const double x0 = D0 * c0 + D1 * c1 + D2 * c2;
+                    const double x1 = D1 * c0 + D3 * c1 + D4 * c2;
+                    const double x2 = D2 * c0 + D4 * c1 + D5 * c2;
+                    PC(Pt, 0, l) = PC(P, 0, l) + x0; PC(Pt, 1, l) = PC(P, 1, l) + x1; PC(Pt, 2, l) = PC(P, 2, l) + x2;
                     scale_part += x0 * (lambda * x0 + g[0]) + x1 * (lambda * x1 + g[1]) + x2 * (lambda * x2 + g[2]);
                 }
             }
@@ -598,7 +731,9 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                 expand_pose(&sm.TTrial[7 * tid], &sm.RtTrial[12 * tid]);
             }
             const double scale = block_sum(scale_part, sm.red) + 1e-3;
+            PH(9);
             double tempChi = eval(sm.RtTrial, with_lm ? Pt : P, false);
+            PH(10);
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho_gain = (currentChi - tempChi) / scale;
             const bool accept = rho_gain > 0 && isfinite(tempChi); // uniform: all inputs are block-uniform
@@ -626,6 +761,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
     }
     if (st && tid == 0) { st->iterations = it; st->total_trials = total_trials; st->chi2_final = currentChi; st->lambda_final = lambda; }
 
+    PH(11);
     // ------------------------------------------------------------------ chi2 classification (optimization.cpp:224-266)
     if (classify && !IMPL) {
         double th = 5.991;
@@ -650,8 +786,11 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
     if (update_poses) for (int i = tid; i < nk * 7; i += kLmBlock) a.T[(size_t)w * nk * 7 + i] = sm.T[i];
     if (with_lm && update_lms)
         for (int l = tid; l < nl; l += kLmBlock)
-            if (act[l]) { a.xyz[3 * ((size_t)lm0 + l)] = (float)P[3 * l]; a.xyz[3 * ((size_t)lm0 + l) + 1] = (float)P[3 * l + 1]; a.xyz[3 * ((size_t)lm0 + l) + 2] = (float)P[3 * l + 2]; }
+            if (act[l]) { a.xyz[3 * ((size_t)lm0 + l)] = (float)PC(P, 0, l); a.xyz[3 * ((size_t)lm0 + l) + 1] = (float)PC(P, 1, l); a.xyz[3 * ((size_t)lm0 + l) + 2] = (float)PC(P, 2, l); }
+    PH(12);
     if (tid == 0) ka.status[w] = VSLAM_OK;
+#undef PH
+#undef PC
 }
 
 // reprojection-error inlier test of the motion-only stage (solvePnPRansac's reprojectionError contract)
@@ -706,12 +845,12 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     const size_t o_bl = need; need += al(total_lm * 3 * 8);
     const size_t o_Di = need; need += al(total_lm * 6 * 8);
     const size_t o_db = need; need += al(total_lm * 3 * 8);
-    const size_t o_lin = need; need += al(total_edge * 6 * 8);
+    const size_t o_lin = need; need += al(total_edge * kLin * 8);
     const size_t o_lmptr = need; need += al((total_lm + n_windows + 1) * 4);
     const size_t o_kfptr = need; need += al((size_t)n_windows * (kMaxKf + 1) * 4);
     const size_t o_kfe = need; need += al(total_edge * 4);
     const size_t o_pp = need; need += al((size_t)n_windows * (kMaxPairs + 1) * 4);
-    const size_t o_hits = need; need += with_lm ? al(total_edge * kHitsPerEdge * 8) : 256;
+    const size_t o_hits = need; need += with_lm ? al(total_edge * kHitsPerEdge * 16) : 256;
     const size_t o_act = need; need += al(total_lm);
     const size_t o_eo = need; need += with_lm ? al(total_lm * kMaxKf) : 256;
     const size_t o_st = need; need += al((size_t)n_windows * 4);
@@ -736,6 +875,13 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     LmKernelArgs ka;
     memset(&ka, 0, sizeof(ka));
     ka.a = a;
+    { const char* e = getenv("VSLAM_LM_SKIP"); ka.dbg_skip = e ? atoi(e) : 0; }
+    static long long* d_cyc = nullptr; static int cyc_n = 0;
+    if (getenv("VSLAM_LM_PROFILE")) {
+        if (cyc_n < a.n_windows) { if (d_cyc) hipFree(d_cyc); hipMalloc((void**)&d_cyc, sizeof(long long) * 16 * a.n_windows); cyc_n = a.n_windows; }
+        hipMemsetAsync(d_cyc, 0, sizeof(long long) * 16 * a.n_windows, stream);
+        ka.dbg_cycles = d_cyc;
+    }
     int rc = carve(ka, total_lm, total_edge, a.n_windows, true, stream);
     if (rc) return rc;
     ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1);
@@ -749,6 +895,15 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, mode, iters, update_poses, update_lms, 1);
     }
     VS_HIP(hipGetLastError());
+    if (ka.dbg_cycles) {
+        hipStreamSynchronize(stream);
+        std::vector<long long> h(16 * (size_t)a.n_windows);
+        hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+        static const char* names[15] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(schur hits w0)", "(schur reduce w0)"};
+        double tot = 0;
+        for (int i = 0; i < 15; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
+        fprintf(stderr, "  [lm profile] total %.0f ticks (clock64 = 100 MHz s_memtime units)\n", tot);
+    }
     return VSLAM_OK;
 }
 

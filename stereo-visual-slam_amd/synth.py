@@ -223,7 +223,7 @@ def pnp_problem(M=500, seed=3, sigma_px=0.5, outlier_frac=0.15, guess_sigma=0.02
     return dict(xyz=pw, uv=uv.astype(np.float32), T_true=T_true, T0=T0, outlier=is_out)
 
 
-def ba_window(n_kf=10, n_lm=3000, seed=2, sigma_px=0.5, outlier_frac=0.05, pose_sigma=0.02, min_obs=2, max_obs=5):
+def ba_window(n_kf=10, n_lm=3000, seed=2, sigma_px=0.5, outlier_frac=0.05, pose_sigma=0.02, min_obs=2, max_obs=5, ordered=True):
     """10 poses on a forward arc (1 m spacing, 0.02 rad yaw/KF), landmarks in the frustum
     with Z in [10,40] m of some keyframe, each seen by 2-5 consecutive keyframes; edges sorted by landmark."""
     rng = np.random.default_rng(seed)
@@ -235,9 +235,16 @@ def ba_window(n_kf=10, n_lm=3000, seed=2, sigma_px=0.5, outlier_frac=0.05, pose_
     T_true = np.array(T_true)
     xyz = np.zeros((n_lm, 3), np.float32)
     kf_idx, lm_idx, uvs = [], [], []
+    # landmark ids follow creation order (curr_landmark_id_++ at the keyframe that first sees the point,
+    # visual_odometry.cpp:411-417): draw the observation spans first, then number the landmarks by first keyframe
+    spans = []
     for l in range(n_lm):
         nobs = int(rng.integers(min_obs, max_obs + 1))
-        k0 = int(rng.integers(0, n_kf - nobs + 1))
+        spans.append((int(rng.integers(0, n_kf - nobs + 1)), nobs))
+    if ordered:
+        spans.sort(key=lambda s: s[0])
+    for l in range(n_lm):
+        k0, nobs = spans[l]
         # place in the frustum of the middle observing keyframe
         km = k0 + nobs // 2
         Z = rng.uniform(10, 40); u = rng.uniform(150, W_KITTI - 150); v = rng.uniform(60, H_KITTI - 60)
