@@ -3,6 +3,7 @@
 // device-resident batched entry points (`vslam_*_dev`).  No CPU fallback anywhere: without a HIP device every
 // compute call fails with VSLAM_ERR_HIP / VSLAM_ERR_NO_DEVICE.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <cmath>
@@ -112,11 +113,14 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
                               c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
     if ((rc = launch_orb_select(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel,
                                 c->orb.d_sel_cnt, c->orb.d_status, c->stream))) return rc;
-    if ((rc = launch_orb_anms(c->plan, B, c->orb.d_sel, c->orb.d_sel_cnt, c->plan.sel_cap, anms_num, regroup, d_kps, c->p.kp_capacity,
+    if ((rc = launch_orb_anms(c->plan, B, c->orb.d_sel, c->orb.d_sel_cnt, c->plan.sel_cap, anms_num, regroup, d_kps, c->orb.d_cs, c->p.kp_capacity,
                               d_count, c->orb.d_status, c->stream))) return rc;
-    if (describe)
-        if ((rc = launch_orb_describe(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, d_kps, c->p.kp_capacity, d_count, d_desc, c->stream)))
-            return rc;
+    if (describe) {
+        if ((rc = launch_orb_blur(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
+        if ((rc = launch_orb_describe(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, c->p.kp_capacity, d_count,
+                                      d_desc, c->stream))) return rc;
+    }
+    if (getenv("VSLAM_ORB_PROFILE")) orb_debug_dump(c->stream);
     return VSLAM_OK;
 }
 
@@ -145,7 +149,7 @@ void vslam_default_params(vslam_params* p) {
 const char* vslam_last_error(void) { return g_err; }
 const char* vslam_version(void) { return "vslam_hip 0.1 (gfx950)"; }
 const char* vslam_kernel_names(void) {
-    return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_describe_kernel match_train_nearest_kernel "
+    return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_blur_kernel orb_describe_kernel match_train_nearest_kernel "
            "match_finalize_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel";
 }
 
@@ -165,6 +169,7 @@ int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** ou
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return VSLAM_ERR_HIP; }
         c->own_stream = true;
     }
+    if (getenv("VSLAM_ORB_PROFILE")) orb_debug_enable();
     int rc = orb_plan_init(&c->plan, p->img_w, p->img_h, p->orb_nfeatures, p->kp_capacity);
     if (rc == VSLAM_OK) rc = orb_tables_init(&c->plan, &c->tab);
     const size_t B = (size_t)p->max_batch;
@@ -174,6 +179,8 @@ int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** ou
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_sel, B * kNLevels * c->plan.sel_cap);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_sel_cnt, B * kNLevels);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_status, B);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_blur, B * c->plan.blur_bytes);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_cs, B * (size_t)p->kp_capacity);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->match.d_train_best, B * kMaxRows);
     if (rc != VSLAM_OK) { vslam_destroy(reinterpret_cast<vslam_ctx*>(c)); return rc; }
     *out = reinterpret_cast<vslam_ctx*>(c);
@@ -186,7 +193,7 @@ void vslam_destroy(vslam_ctx* ctx) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     orb_tables_free(&c->tab);
-    void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det,
+    void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs,
                     c->match.d_train_best, c->d_stage};
     for (void* q : ptrs) if (q) hipFree(q);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -265,7 +272,7 @@ int vslam_anms(vslam_ctx* ctx, vslam_keypoint* kps, int n, int num, int* n_out) 
     VS_HIP(hipMemcpyAsync(d_in, kps, sizeof(vslam_keypoint) * n, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
-    if ((rc = launch_anms_flat(1, d_in, d_n, kMaxRows, num, 0, c->p.img_w, c->p.img_h, d_out, kMaxRows, d_cnt, c->orb.d_status, c->stream))) return rc;
+    if ((rc = launch_anms_flat(1, d_in, d_n, kMaxRows, num, 0, c->p.img_w, c->p.img_h, d_out, nullptr, kMaxRows, d_cnt, c->orb.d_status, c->stream))) return rc;
     int32_t m = 0;
     VS_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(m), hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
@@ -300,8 +307,9 @@ int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stri
     VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
     if ((rc = launch_orb_pyramid(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->stream))) return rc;
-    if ((rc = launch_anms_flat(1, d_in, d_n, kc, 0, 1, w, h, d_kps, kc, d_cnt, c->orb.d_status, c->stream))) return rc;
-    if ((rc = launch_orb_describe(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, d_kps, kc, d_cnt, d_desc, c->stream))) return rc;
+    if ((rc = launch_anms_flat(1, d_in, d_n, kc, 0, 1, w, h, d_kps, c->orb.d_cs, kc, d_cnt, c->orb.d_status, c->stream))) return rc;
+    if ((rc = launch_orb_blur(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
+    if ((rc = launch_orb_describe(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, kc, d_cnt, d_desc, c->stream))) return rc;
     int32_t m = 0;
     VS_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(m), hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));

@@ -31,6 +31,34 @@
 namespace vslam {
 
 __device__ __constant__ signed char c_pattern[256 * 4];
+
+// tuning aid (VSLAM_ORB_PROFILE=1): per-phase cycle counters, thread 0 of every block adds its clock64 deltas
+__device__ long long* g_orb_dbg = nullptr;
+// (per-block rows, plain stores: atomics on shared counters would serialise the blocks and distort the timing)
+constexpr int kDbgRows = 8192;
+#define OPH_INIT() long long* dbg__ = g_orb_dbg ? g_orb_dbg + 32 * (size_t)((blockIdx.x + 977u * blockIdx.y) % kDbgRows) : nullptr; long long tph__ = dbg__ ? clock64() : 0
+#define OPH(slot) do { if (dbg__ && threadIdx.x == 0) { const long long t1__ = clock64(); dbg__[(slot) & 31] += t1__ - tph__; tph__ = t1__; } } while (0)
+static long long* g_orb_dbg_host = nullptr;
+void orb_debug_enable() {
+    if (g_orb_dbg_host) return;
+    hipMalloc((void**)&g_orb_dbg_host, sizeof(long long) * 32 * kDbgRows);
+    hipMemset(g_orb_dbg_host, 0, sizeof(long long) * 32 * kDbgRows);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_orb_dbg), &g_orb_dbg_host, sizeof(g_orb_dbg_host));
+}
+void orb_debug_dump(hipStream_t stream) {
+    if (!g_orb_dbg_host) return;
+    hipStreamSynchronize(stream);
+    static long long hall[32 * kDbgRows];
+    hipMemcpy(hall, g_orb_dbg_host, sizeof(hall), hipMemcpyDeviceToHost);
+    hipMemset(g_orb_dbg_host, 0, sizeof(hall));
+    long long h[64] = {0};
+    for (int r = 0; r < kDbgRows; ++r) for (int i = 0; i < 32; ++i) h[i] += hall[32 * r + i];
+    static const char* names[64] = {"sel: hist+cut", "sel: harris", "sel: radix select", "sel: compact+sort", "sel: angle+out", nullptr, nullptr, nullptr,
+                                    "desc: patch load", "desc: row blur", "desc: col blur", "desc: sincos+tests", nullptr, nullptr, nullptr, nullptr,
+                                    "fast: tile load", "fast: corner test", "fast: score", "fast: nms+append", nullptr, nullptr, nullptr, nullptr,
+                                    "anms: gather+sort", "anms: radii", "anms: radius sort", "anms: compact+regroup+out"};
+    for (int i = 0; i < 64; ++i) if (names[i] && h[i]) fprintf(stderr, "  [orb profile] %-28s %14lld block-cycles (sum over blocks)\n", names[i], h[i]);
+}
 static bool g_pattern_uploaded[16] = {false};
 
 // status bits
@@ -63,6 +91,36 @@ __device__ inline LevelView level_view(const LevelTable& T, int l, const uint8_t
     return v;
 }
 
+// Stage a tw x th (tw % 4 == 0) pixel tile with origin (x0, y0) into LDS.  Interior tiles take one unaligned dword load
+// per 4 pixels (global memory tolerates unaligned dwords); tiles that cross the image edge fall back to per-byte loads
+// with reflect-101 (REFLECT) or clamped (!REFLECT) coordinates.
+template <bool REFLECT, int NTHREADS>
+__device__ inline void load_tile_u8(uint8_t* lds, int lds_pitch, const uint8_t* __restrict__ src, int spitch, int W, int H, int x0, int y0,
+                                    int tw, int th) {
+    const int tw4 = tw >> 2;
+    if (x0 >= 0 && y0 >= 0 && x0 + tw <= W && y0 + th <= H) { // uniform
+        for (int i = threadIdx.x; i < th * tw4; i += NTHREADS) {
+            const int r = i / tw4, c4 = (i - r * tw4) << 2;
+            uint32_t v;
+            __builtin_memcpy(&v, src + (size_t)(y0 + r) * spitch + x0 + c4, 4);
+            *reinterpret_cast<uint32_t*>(lds + r * lds_pitch + c4) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < th * tw4; i += NTHREADS) {
+            const int r = i / tw4, c4 = (i - r * tw4) << 2;
+            const int y = REFLECT ? reflect101(y0 + r, H) : min(max(y0 + r, 0), H - 1);
+            const uint8_t* row = src + (size_t)y * spitch;
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = REFLECT ? reflect101(x0 + c4 + k, W) : min(max(x0 + c4 + k, 0), W - 1);
+                v |= (uint32_t)row[x] << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(lds + r * lds_pitch + c4) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- host plan
 static inline int cv_round_host(double v) { return (int)lrint(v); }
 
@@ -90,6 +148,9 @@ int orb_plan_init(OrbPlan* plan, int w, int h, int nfeatures, int kp_capacity) {
         L.tile_off = tiles; tiles += L.tiles_x * L.tiles_y;
         L.tab_off = tab; tab += L.w;
     }
+    int blur = 0;
+    for (int l = 0; l < kNLevels; ++l) { plan->blur_off[l] = blur; blur += ((plan->lv[l].w + 63) & ~63) * plan->lv[l].h; }
+    plan->blur_bytes = (blur + 255) & ~255;
     plan->pyr_bytes = (pyr + 255) & ~255;
     plan->corner_total = corners;
     plan->total_tiles = tiles;
@@ -277,71 +338,83 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
 
     __shared__ __attribute__((aligned(16))) uint8_t pix[kPixH * kPixPitch];
     __shared__ uint8_t sc[kScH * kScW];
-    __shared__ uint16_t queue[kScH * kScW];
-    __shared__ int qcount;
+    __shared__ uint16_t queue[kScH * kScW];   // positions that pass the compass pre-test
+    __shared__ uint16_t cqueue[kScH * kScW];  // corners
+    __shared__ uint32_t outq[kTileW * kTileH / 4];
+    __shared__ int qcount, ccount, ocount, obase;
 
-    if (threadIdx.x == 0) qcount = 0;
-    for (int i = threadIdx.x; i < kPixH * (kPixW / 4); i += 256) {
-        const int r = i / (kPixW / 4), c4 = (i % (kPixW / 4)) * 4;
-        const int y = min(oy - 4 + r, V.h - 1);
-        const uint8_t* row = V.ptr + (size_t)y * V.pitch;
-        uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v |= (uint32_t)row[min(ox - 4 + c4 + k, V.w - 1)] << (8 * k);
-        *reinterpret_cast<uint32_t*>(&pix[r * kPixPitch + c4]) = v;
-    }
+    OPH_INIT();
+    if (threadIdx.x == 0) { qcount = 0; ccount = 0; ocount = 0; }
+    load_tile_u8<false, 256>(pix, kPixPitch, V.ptr, V.pitch, V.w, V.h, ox - 4, oy - 4, kPixW, kPixH);
     for (int i = threadIdx.x; i < kScH * kScW; i += 256) sc[i] = 0;
     __syncthreads();
+    OPH(16);
 
-    // corner test on the 66 x 18 score region
+    // (a) compass pre-test on the 66 x 18 score region: a 9-arc always contains two ADJACENT compass pixels (ring
+    // positions 0, 4, 8, 12), so a corner needs two adjacent compass pixels all brighter or all darker.  Cheap, and it
+    // thins the candidates before the full 16-pixel test runs with all lanes busy.
     for (int i = threadIdx.x; i < kScH * kScW; i += 256) {
         const int sy = i / kScW, sx = i - sy * kScW;
         const int x = ox - 1 + sx, y = oy - 1 + sy;
         if (x >= V.w - 3 || y >= V.h - 3) continue; // outside cv::FAST's own range (left/top are always >= 30)
         const uint8_t* p = &pix[(sy + 3) * kPixPitch + sx + 3];
-        const int v = p[0];
-        const int hi = v + thr, lo = v - thr;
-        const int r[16] = RING_LOAD(p, kPixPitch);
-        uint32_t bright = 0, dark = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { bright |= (uint32_t)(r[k] > hi) << k; dark |= (uint32_t)(r[k] < lo) << k; }
-        if (ring9(bright) || ring9(dark)) queue[atomicAdd(&qcount, 1)] = (uint16_t)i;
+        const int v = p[0], hi = v + thr, lo = v - thr;
+        const int c0 = p[3 * kPixPitch], c4 = p[3], c8 = p[-3 * kPixPitch], c12 = p[-3];
+        const bool b0 = c0 > hi, b4 = c4 > hi, b8 = c8 > hi, b12 = c12 > hi;
+        const bool d0 = c0 < lo, d4 = c4 < lo, d8 = c8 < lo, d12 = c12 < lo;
+        const bool pass = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (d0 & d4) | (d4 & d8) | (d8 & d12) | (d12 & d0);
+        if (pass) queue[atomicAdd(&qcount, 1)] = (uint16_t)i;
     }
     __syncthreads();
+    // (b) full FAST-9/16 test on the survivors
     const int nq = qcount;
     for (int q = threadIdx.x; q < nq; q += 256) {
         const int i = queue[q];
         const int sy = i / kScW, sx = i - sy * kScW;
+        const uint8_t* p = &pix[(sy + 3) * kPixPitch + sx + 3];
+        const int v = p[0], hi = v + thr, lo = v - thr;
+        const int r[16] = RING_LOAD(p, kPixPitch);
+        uint32_t bright = 0, dark = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { bright |= (uint32_t)(r[k] > hi) << k; dark |= (uint32_t)(r[k] < lo) << k; }
+        if (ring9(bright) || ring9(dark)) cqueue[atomicAdd(&ccount, 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    OPH(17);
+    // (c) corner scores
+    const int nc = ccount;
+    for (int q = threadIdx.x; q < nc; q += 256) {
+        const int i = cqueue[q];
+        const int sy = i / kScW, sx = i - sy * kScW;
         sc[i] = (uint8_t)fast_score(&pix[(sy + 3) * kPixPitch + sx + 3], thr);
     }
     __syncthreads();
-    // 3x3 non-max suppression + border cull (edgeThreshold 31) + append
-    uint32_t* corners = d_corners + (size_t)b * corner_total + T.corner_off[l];
-    int32_t* cnt = d_corner_cnt + b * kNLevels + l;
-    const int cap = T.corner_cap[l];
-    for (int i = threadIdx.x; i < kTileW * kTileH; i += 256) {
-        const int ey = i / kTileW, ex = i - ey * kTileW;
-        const int x = ox + ex, y = oy + ey;
-        const uint8_t* s = &sc[(ey + 1) * kScW + ex + 1];
+    OPH(18);
+    // (d) 3x3 non-max suppression + border cull (edgeThreshold 31): survivors collected in LDS, ONE global atomic per block
+    for (int q = threadIdx.x; q < nc; q += 256) {
+        const int i = cqueue[q];
+        const int sy = i / kScW, sx = i - sy * kScW;
+        if (sx < 1 || sx > kTileW || sy < 1 || sy > kTileH) continue; // halo positions only feed the NMS
+        const int x = ox - 1 + sx, y = oy - 1 + sy;
+        if (x >= V.w - kEdge || y >= V.h - kEdge) continue;
+        const uint8_t* s = &sc[i];
         const int v = s[0];
-        bool keep = v > 0 && x < V.w - kEdge && y < V.h - kEdge;
-        if (keep)
-            keep = v > s[-1] && v > s[1] && v > s[-kScW - 1] && v > s[-kScW] && v > s[-kScW + 1] && v > s[kScW - 1] && v > s[kScW] &&
-                   v > s[kScW + 1];
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            const int lane = threadIdx.x & 63;
-            const int leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(cnt, __popcll(m));
-            base = __shfl(base, leader);
-            if (keep) {
-                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < cap) corners[slot] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)v << 24);
-                else atomicOr(&d_status[b], kStCornerOverflow);
-            }
+        if (v > s[-1] && v > s[1] && v > s[-kScW - 1] && v > s[-kScW] && v > s[-kScW + 1] && v > s[kScW - 1] && v > s[kScW] && v > s[kScW + 1])
+            outq[atomicAdd(&ocount, 1)] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)v << 24);
+    }
+    __syncthreads();
+    const int no = ocount; // a strict 3x3 maximum: at most one survivor per 2x2 cell, so no <= 1024 / 4
+    if (no > 0) {
+        if (threadIdx.x == 0) obase = atomicAdd(d_corner_cnt + b * kNLevels + l, no);
+        __syncthreads();
+        uint32_t* corners = d_corners + (size_t)b * corner_total + T.corner_off[l];
+        const int cap = T.corner_cap[l], base = obase;
+        for (int q = threadIdx.x; q < no; q += 256) {
+            if (base + q < cap) corners[base + q] = outq[q];
+            else atomicOr(&d_status[b], kStCornerOverflow);
         }
     }
+    OPH(19);
 }
 
 int launch_orb_fast(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, int fast_thr,
@@ -487,6 +560,7 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     int& s_cut = hist[256]; int& s_ncand = hist[257]; int& s_rank = hist[258]; int& s_keep = hist[259];
     uint32_t& s_prefix = reinterpret_cast<uint32_t*>(hist)[260];
 
+    OPH_INIT();
     // ---- retainBest(2 * nfeat) on the FAST score (ties at the cut are kept)
     for (int i = threadIdx.x; i < 256; i += kSelBlock) hist[i] = 0;
     if (threadIdx.x == 0) { s_ncand = 0; s_cut = 0; }
@@ -500,6 +574,7 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     }
     __syncthreads();
     const int cut = (nfeat > 0) ? s_cut : 256;
+    OPH(0);
     // ---- Harris response of every survivor
     for (int i = threadIdx.x; i < n; i += kSelBlock) {
         const uint32_t c = corners[i];
@@ -513,6 +588,7 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     __syncthreads();
     int m = s_ncand;
     if (m > kCandCap) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStCandOverflow); m = kCandCap; }
+    OPH(1);
     // ---- retainBest(nfeat) on the Harris response: radix select of the nfeat-th largest key
     uint32_t cutkey = 0;
     if (m > nfeat) {
@@ -540,6 +616,7 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     }
     // ---- compact survivors (key >= cutkey), then raster sort by (y, x)
     __syncthreads();
+    OPH(2);
     if (threadIdx.x == 0) s_keep = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < m; i += kSelBlock) {
@@ -560,6 +637,7 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     if (np2 > 1) bitonic_sort_lds(keep, np2);
     int nout = nk;
     if (nout > sel_cap) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStSelOverflow); nout = sel_cap; }
+    OPH(3);
     // ---- orientation + output (wave per keypoint)
     vslam_keypoint* out = d_sel + ((size_t)b * kNLevels + l) * sel_cap;
     const int wave = threadIdx.x >> 6, nwaves = kSelBlock >> 6, lane = threadIdx.x & 63;
@@ -581,6 +659,8 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
             out[i] = kp;
         }
     }
+    __syncthreads();
+    OPH(4);
     if (threadIdx.x == 0) d_sel_cnt[b * kNLevels + l] = nout;
 }
 
@@ -625,7 +705,7 @@ __device__ inline int block_rank_1024(bool flag, int* s_wave_tot, int& total) {
 // Input: either 8 per-level lists (d_sel, d_sel_cnt; in_capacity = sel_cap) or one flat list (levels = 1).
 __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoint* __restrict__ d_in, const int32_t* __restrict__ d_nin,
                                                              int nlists, int in_capacity, int anms_num, int regroup, int img_w,
-                                                             int img_h, vslam_keypoint* __restrict__ d_kps, int kp_capacity,
+                                                             int img_h, vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, int kp_capacity,
                                                              int32_t* __restrict__ d_count, int32_t* __restrict__ d_status) {
     const int b = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -654,6 +734,14 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
         int k = 0;
         for (int t = 1; t < nlists; ++t) if (g >= s_off[t]) k = t;
         return in + (size_t)k * in_capacity + (g - s_off[k]);
+    };
+    // rotation of the rBRIEF pattern: a = (float)cos(angle * pi/180), b = (float)sin(...), evaluated in f64 like the CPU side
+    auto emit = [&](int r, const vslam_keypoint* kp) {
+        d_kps[(size_t)b * kp_capacity + r] = *kp;
+        if (d_cs) {
+            const float ang = __fmul_rn(kp->angle, (float)(3.1415926535897932384626433832795 / 180.f));
+            d_cs[(size_t)b * kp_capacity + r] = make_float2((float)cos((double)ang), (float)sin((double)ang));
+        }
     };
     const bool do_anms = anms_num > 0 && N >= anms_num; // visual_odometry.cpp:100
     int M = N; // count after ANMS
@@ -737,18 +825,18 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (k32[mid] != 0xFFFFFFFFu) lo = mid + 1; else hi = mid; }
         cnt = lo;
         if (cnt > kp_capacity) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStOutOverflow); cnt = kp_capacity; }
-        for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) d_kps[(size_t)b * kp_capacity + r] = *src_ptr(sord[k32[r] & 0xFFFFu]);
+        for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) emit(r, src_ptr(sord[k32[r] & 0xFFFFu]));
         if (threadIdx.x == 0) d_count[b] = cnt;
     } else {
         int cnt = M;
         if (cnt > kp_capacity) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStOutOverflow); cnt = kp_capacity; }
-        for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) d_kps[(size_t)b * kp_capacity + r] = *src_ptr(sord[r]);
+        for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) emit(r, src_ptr(sord[r]));
         if (threadIdx.x == 0) d_count[b] = cnt;
     }
 }
 
 static int launch_anms_common(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int nlists, int in_capacity, int anms_num,
-                              int regroup, int img_w, int img_h, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count,
+                              int regroup, int img_w, int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count,
                               int32_t* d_status, hipStream_t stream) {
     const size_t smem = (size_t)kMaxRows * (8 + 12 + 8 + 2 + 2) + 16 + 4 * (kAnmsBlock / 64 + kNLevels + 1 + 3);
     static bool attr_set = false;
@@ -758,87 +846,145 @@ static int launch_anms_common(int B, const vslam_keypoint* d_in, const int32_t* 
     }
     ProfScope prof__(stream, "orb_anms_kernel");
     hipLaunchKernelGGL(orb_anms_kernel, dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
-                       img_w, img_h, d_kps, kp_capacity, d_count, d_status);
+                       img_w, img_h, d_kps, d_cs, kp_capacity, d_count, d_status);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
 
 int launch_orb_anms(const OrbPlan& plan, int B, const vslam_keypoint* d_sel, const int32_t* d_sel_cnt, int sel_cap, int anms_num,
-                    int regroup, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count, int32_t* d_status, hipStream_t stream) {
-    return launch_anms_common(B, d_sel, d_sel_cnt, kNLevels, sel_cap, anms_num, regroup, plan.w, plan.h, d_kps, kp_capacity, d_count,
+                    int regroup, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status, hipStream_t stream) {
+    return launch_anms_common(B, d_sel, d_sel_cnt, kNLevels, sel_cap, anms_num, regroup, plan.w, plan.h, d_kps, d_cs, kp_capacity, d_count,
                               d_status, stream);
 }
 
 int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int in_capacity, int anms_num, int regroup, int img_w,
-                     int img_h, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count, int32_t* d_status, hipStream_t stream) {
-    return launch_anms_common(B, d_in, d_nin, 1, in_capacity, anms_num, regroup, img_w, img_h, d_kps, kp_capacity, d_count, d_status, stream);
+                     int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status, hipStream_t stream) {
+    return launch_anms_common(B, d_in, d_nin, 1, in_capacity, anms_num, regroup, img_w, img_h, d_kps, d_cs, kp_capacity, d_count, d_status, stream);
 }
 
-// ------------------------------------------------------------------------------------------- K6 rBRIEF
-constexpr int kDescWaves = 4;
-constexpr int kRawR = 21, kRawW = 2 * kRawR + 1;   // 43: rotated pattern reach (18) + blur reach (3)
-constexpr int kBlurR = 18, kBlurW = 2 * kBlurR + 1; // 37
-constexpr int kRawPitch = 44, kBlurPitch = 40;
+// ------------------------------------------------------------------------------------------- K6 blur + rBRIEF
+// K6a orb_blur_kernel: GaussianBlur 7x7 sigma 2 (8-bit fixed point, BORDER_REFLECT_101) of every pyramid level into a
+// second pyramid, one launch for all levels.  64x16 output tiles: (70 x 22) raw pixels staged in LDS, separable
+// passes through an int32 LDS tile -- the arithmetic of cv::GaussianBlur's 8U path: taps cvRound(k*256) =
+// {18,34,49,55,49,34,18} per pass, (sum + 2^15) >> 16 after the column pass.
+constexpr int kBlurTileW = 64, kBlurTileH = 32;
+constexpr int kBlurRawW = kBlurTileW + 8, kBlurRawH = kBlurTileH + 6, kBlurRawPitch = 76; // raw tile starts at x0 - 4 (dword loads)
 
-struct DescSmem {
-    uint8_t raw[kRawW * kRawPitch];
-    int tmp[kRawW * kBlurW];
-    uint8_t blur[kBlurW * kBlurPitch];
+struct BlurTable {
+    int w[kNLevels], h[kNLevels], pitch[kNLevels], pyr_off[kNLevels], blur_off[kNLevels];
+    int tiles_x[kNLevels], tile_off[kNLevels + 1];
 };
 
-__global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(LevelTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes,
-                                                                      int pitch0, const uint8_t* __restrict__ d_pyr, size_t pyr_bytes,
-                                                                      const vslam_keypoint* __restrict__ d_kps, int kp_capacity,
-                                                                      const int32_t* __restrict__ d_count, uint8_t* __restrict__ d_desc) {
+static void fill_blur_table(const OrbPlan& plan, BlurTable* T) {
+    int tiles = 0;
+    for (int l = 0; l < kNLevels; ++l) {
+        const OrbLevel& L = plan.lv[l];
+        T->w[l] = L.w; T->h[l] = L.h; T->pitch[l] = (L.w + 63) & ~63; T->pyr_off[l] = L.pyr_off; T->blur_off[l] = plan.blur_off[l];
+        T->tiles_x[l] = (L.w + kBlurTileW - 1) / kBlurTileW;
+        T->tile_off[l] = tiles;
+        tiles += T->tiles_x[l] * ((L.h + kBlurTileH - 1) / kBlurTileH);
+    }
+    T->tile_off[kNLevels] = tiles;
+}
+
+__global__ __launch_bounds__(256) void orb_blur_kernel(BlurTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes, int pitch0,
+                                                      const uint8_t* __restrict__ d_pyr, size_t pyr_bytes, uint8_t* __restrict__ d_blur,
+                                                      size_t blur_bytes) {
+    const int b = blockIdx.y;
+    int tile = blockIdx.x, l = 0;
+#pragma unroll
+    for (int k = 1; k < kNLevels; ++k) if (tile >= T.tile_off[k]) l = k;
+    tile -= T.tile_off[l];
+    const int W = T.w[l], H = T.h[l];
+    const uint8_t* src = l == 0 ? d_imgs + (size_t)b * img_bytes : d_pyr + (size_t)b * pyr_bytes + T.pyr_off[l];
+    const int spitch = l == 0 ? pitch0 : T.pitch[l];
+    uint8_t* dst = d_blur + (size_t)b * blur_bytes + T.blur_off[l];
+    const int dpitch = T.pitch[l];
+    const int ox = (tile % T.tiles_x[l]) * kBlurTileW, oy = (tile / T.tiles_x[l]) * kBlurTileH;
+
+    __shared__ __attribute__((aligned(16))) uint8_t raw[kBlurRawH * kBlurRawPitch];
+    __shared__ int tmp[kBlurRawH * kBlurTileW];
+    load_tile_u8<true, 256>(raw, kBlurRawPitch, src, spitch, W, H, ox - 4, oy - 3, kBlurRawW, kBlurRawH);
+    __syncthreads();
+    const int gk[7] = {18, 34, 49, 55, 49, 34, 18};
+    // row pass: one lane = 4 consecutive outputs of one row (10 taps read once)
+    for (int i = threadIdx.x; i < kBlurRawH * (kBlurTileW / 4); i += 256) {
+        const int r = i / (kBlurTileW / 4), c = (i - r * (kBlurTileW / 4)) * 4;
+        const uint8_t* p = &raw[r * kBlurRawPitch + c + 1]; // output column c reads raw columns c+1 .. c+7
+        int v[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) v[k] = p[k];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) s += gk[k] * v[o + k];
+            tmp[r * kBlurTileW + c + o] = s;
+        }
+    }
+    __syncthreads();
+    // column pass: one lane = 4 consecutive rows of one column
+    for (int i = threadIdx.x; i < (kBlurTileH / 4) * kBlurTileW; i += 256) {
+        const int c = i & (kBlurTileW - 1), r = (i / kBlurTileW) * 4;
+        int v[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) v[k] = tmp[(r + k) * kBlurTileW + c];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) s += gk[k] * v[o + k];
+            int px = (s + (1 << 15)) >> 16;
+            px = min(max(px, 0), 255);
+            const int x = ox + c, y = oy + r + o;
+            if (x < W && y < H) dst[(size_t)y * dpitch + x] = (uint8_t)px;
+        }
+    }
+}
+
+int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, uint8_t* d_blur,
+                    hipStream_t stream) {
+    BlurTable T;
+    fill_blur_table(plan, &T);
+    ProfScope prof__(stream, "orb_blur_kernel");
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(T.tile_off[kNLevels], B), dim3(256), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
+                       (size_t)plan.pyr_bytes, d_blur, (size_t)plan.blur_bytes);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+// K6b orb_describe_kernel: one wave per keypoint, 256 rotated tests (4 per lane) read straight from the blurred
+// pyramid (L2-resident gathers inside a 37x37 window); rotation cos/sin come precomputed per keypoint (d_cs, written
+// by the ANMS kernel with one lane per keypoint, so the f64 sin/cos is not repeated by all 64 lanes of a wave).
+constexpr int kDescWaves = 4;
+
+__global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable T, LevelTable LT, const uint8_t* __restrict__ d_imgs,
+                                                                      size_t img_bytes, int pitch0, const uint8_t* __restrict__ d_pyr,
+                                                                      size_t pyr_bytes, const uint8_t* __restrict__ d_blur, size_t blur_bytes,
+                                                                      const vslam_keypoint* __restrict__ d_kps, const float2* __restrict__ d_cs,
+                                                                      int kp_capacity, const int32_t* __restrict__ d_count,
+                                                                      uint8_t* __restrict__ d_desc) {
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * kDescWaves + wave;
     const int n = min(d_count[b], kp_capacity);
-    __shared__ DescSmem sm[kDescWaves];
-    if (blockIdx.x * kDescWaves >= n) return; // whole block idle (uniform)
-    const bool active = j < n;
-    DescSmem& S = sm[wave];
-    vslam_keypoint kp = {0.f, 0.f, 31.f, 0.f, 0.f, 0, -1};
-    if (active) kp = d_kps[(size_t)b * kp_capacity + j];
+    if (j >= n) return; // no block-level barrier below
+    const vslam_keypoint kp = d_kps[(size_t)b * kp_capacity + j];
+    const float2 cs = d_cs[(size_t)b * kp_capacity + j];
     const int l = min(max(kp.octave, 0), kNLevels - 1);
-    const LevelView V = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
-    const float inv_scale = __fdiv_rn(1.f, T.scale[l]);
+    const int W = T.w[l], H = T.h[l], bpitch = T.pitch[l];
+    const uint8_t* blur = d_blur + (size_t)b * blur_bytes + T.blur_off[l];
+    const uint8_t* rawp = l == 0 ? d_imgs + (size_t)b * img_bytes : d_pyr + (size_t)b * pyr_bytes + T.pyr_off[l];
+    const int rpitch = l == 0 ? pitch0 : T.pitch[l];
+    const float inv_scale = __fdiv_rn(1.f, LT.scale[l]);
     const int cx = __float2int_rn(__fmul_rn(kp.x, inv_scale)), cy = __float2int_rn(__fmul_rn(kp.y, inv_scale));
-    // stage the raw 43x43 patch (reflect-101 outside the level image)
-    for (int i = lane; i < kRawW * kRawW; i += 64) {
-        const int r = i / kRawW, c = i - r * kRawW;
-        const int y = reflect101(cy - kRawR + r, V.h), x = reflect101(cx - kRawR + c, V.w);
-        S.raw[r * kRawPitch + c] = V.ptr[(size_t)y * V.pitch + x];
-    }
-    __syncthreads();
-    // GaussianBlur 7x7 sigma 2: kernel (float)exp(-x^2/8)/sum -> cvRound(k*256) = {18,34,49,55,49,34,18}
-    const int gk[7] = {18, 34, 49, 55, 49, 34, 18};
-    for (int i = lane; i < kRawW * kBlurW; i += 64) {
-        const int r = i / kBlurW, c = i - r * kBlurW;
-        const uint8_t* p = &S.raw[r * kRawPitch + c];
-        int s = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) s += gk[k] * p[k];
-        S.tmp[i] = s;
-    }
-    __syncthreads();
-    for (int i = lane; i < kBlurW * kBlurW; i += 64) {
-        const int r = i / kBlurW, c = i - r * kBlurW;
-        int s = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) s += gk[k] * S.tmp[(r + k) * kBlurW + c];
-        int v = (s + (1 << 15)) >> 16;
-        v = min(max(v, 0), 255);
-        // outside the level image the reference reads the UNBLURRED reflect-101 border of its pyramid buffer
-        const int y = cy - kBlurR + r, x = cx - kBlurR + c;
-        if (x < 0 || x >= V.w || y < 0 || y >= V.h) v = S.raw[(r + 3) * kRawPitch + c + 3];
-        S.blur[r * kBlurPitch + c] = (uint8_t)v;
-    }
-    __syncthreads();
-    // 256 tests: lane L -> tests 4L..4L+3
-    const float ang = __fmul_rn(kp.angle, (float)(3.1415926535897932384626433832795 / 180.f));
-    const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
-    const uint8_t* center = &S.blur[kBlurR * kBlurPitch + kBlurR];
+    const float ca = cs.x, sa = cs.y;
+    auto sample = [&](int ix, int iy) -> int {
+        const int x = cx + ix, y = cy + iy;
+        if (x >= 0 && x < W && y >= 0 && y < H) return blur[(size_t)y * bpitch + x];
+        // outside the level the reference reads the UNBLURRED reflect-101 border of its pyramid buffer
+        return rawp[(size_t)reflect101(y, H) * rpitch + reflect101(x, W)];
+    };
     int nib = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -848,22 +994,25 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(LevelTabl
         const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
         const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
         const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-        const int t0 = center[iy0 * kBlurPitch + ix0], t1 = center[iy1 * kBlurPitch + ix1];
+        const int t0 = sample(ix0, iy0), t1 = sample(ix1, iy1);
         nib |= (t0 < t1) << k;
     }
     const int hi = __shfl_down(nib, 1);
-    if (active && (lane & 1) == 0) d_desc[((size_t)b * kp_capacity + j) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    if ((lane & 1) == 0) d_desc[((size_t)b * kp_capacity + j) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
 }
 
 int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
-                        const vslam_keypoint* d_kps, int kp_capacity, const int32_t* d_count, uint8_t* d_desc, hipStream_t stream) {
-    LevelTable T;
-    fill_level_table(plan, &T);
+                        const uint8_t* d_blur, const vslam_keypoint* d_kps, const float2* d_cs, int kp_capacity, const int32_t* d_count,
+                        uint8_t* d_desc, hipStream_t stream) {
+    BlurTable T;
+    fill_blur_table(plan, &T);
+    LevelTable LT;
+    fill_level_table(plan, &LT);
     // grid sized for the capacity; waves beyond d_count[b] exit immediately
     const int max_kp = min(kp_capacity, kMaxRows);
     ProfScope prof__(stream, "orb_describe_kernel");
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + kDescWaves - 1) / kDescWaves, B), dim3(kDescWaves * 64), 0, stream, T, d_imgs,
-                       img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_kps, kp_capacity, d_count, d_desc);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + kDescWaves - 1) / kDescWaves, B), dim3(kDescWaves * 64), 0, stream, T, LT, d_imgs,
+                       img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_blur, (size_t)plan.blur_bytes, d_kps, d_cs, kp_capacity, d_count, d_desc);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }

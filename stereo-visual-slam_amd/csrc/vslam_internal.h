@@ -59,6 +59,8 @@ struct OrbPlan {
     int corner_total;     // per image
     int total_tiles;      // FAST tiles per image, all levels
     int sel_cap;          // per (image, level) capacity of the selected keypoint staging list
+    int blur_off[kNLevels]; // byte offset of each level inside one image's blurred pyramid (level 0 included)
+    int blur_bytes;       // per image
 };
 
 struct Ctx;
@@ -72,6 +74,8 @@ struct OrbTables {
     int x_off[kNLevels], y_off[kNLevels];
 };
 
+void orb_debug_enable();
+void orb_debug_dump(hipStream_t stream);
 int orb_plan_init(OrbPlan* plan, int w, int h, int nfeatures, int kp_capacity);
 int orb_tables_init(const OrbPlan* plan, OrbTables* t);
 void orb_tables_free(OrbTables* t);
@@ -84,6 +88,8 @@ struct OrbBuffers {
     int32_t* d_sel_cnt;    // B x 8
     int32_t* d_status;     // B  (bit flags: overflow conditions)
     vslam_keypoint* d_det; // B x kp_capacity: detect output (level asc, raster) when ANMS is run as a separate call
+    uint8_t* d_blur;       // B x blur_bytes: Gaussian-blurred pyramid (rBRIEF samples these)
+    float2* d_cs;          // B x kp_capacity: per-keypoint (cos, sin) of the rBRIEF rotation
 };
 
 // launches (all asynchronous on `stream`)
@@ -97,15 +103,17 @@ int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
 // gather per-level lists (level asc) -> ANMS(num) -> regroup by octave -> d_kps (B x kp_capacity), d_count
 // anms_num <= 0: no ANMS (detect order).  regroup: apply cv::ORB::compute's border cull + octave regrouping.
 int launch_orb_anms(const OrbPlan& plan, int B, const vslam_keypoint* d_sel, const int32_t* d_sel_cnt, int sel_cap,
-                    int anms_num, int regroup, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count, int32_t* d_status,
+                    int anms_num, int regroup, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status,
                     hipStream_t stream);
 // same ANMS kernel on a flat list per image (d_in: B x in_capacity, d_nin[b]) for the stand-alone vslam_anms call
 int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int in_capacity, int anms_num, int regroup,
-                     int img_w, int img_h, vslam_keypoint* d_kps, int kp_capacity, int32_t* d_count, int32_t* d_status,
+                     int img_w, int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status,
                      hipStream_t stream);
+int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, uint8_t* d_blur,
+                    hipStream_t stream);
 int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
-                        const vslam_keypoint* d_kps, int kp_capacity, const int32_t* d_count, uint8_t* d_desc,
-                        hipStream_t stream);
+                        const uint8_t* d_blur, const vslam_keypoint* d_kps, const float2* d_cs, int kp_capacity, const int32_t* d_count,
+                        uint8_t* d_desc, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- matcher
 struct MatchBuffers {
