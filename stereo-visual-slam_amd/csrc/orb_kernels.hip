@@ -173,8 +173,9 @@ static void fill_level_table(const OrbPlan& plan, LevelTable* T) {
 int orb_tables_init(const OrbPlan* plan, OrbTables* t) {
     memset(t, 0, sizeof(*t));
     int nx = 0, ny = 0;
-    for (int l = 1; l < kNLevels; ++l) { t->x_off[l] = nx; nx += plan->lv[l].w; t->y_off[l] = ny; ny += plan->lv[l].h; }
+    for (int l = 1; l < kNLevels; ++l) { t->x_off[l] = nx; nx += (plan->lv[l].w + 7) & ~3; t->y_off[l] = ny; ny += plan->lv[l].h; } // x tables padded: the kernel reads 4 entries at a time
     int* xofs = new int[nx]; short* ialpha = new short[2 * nx]; int* yofs = new int[ny]; short* ibeta = new short[2 * ny];
+    for (int i = 0; i < nx; ++i) { xofs[i] = 0; ialpha[2 * i] = 2048; ialpha[2 * i + 1] = 0; }
     for (int l = 1; l < kNLevels; ++l) {
         const int sw = plan->lv[l - 1].w, sh = plan->lv[l - 1].h, dw = plan->lv[l].w, dh = plan->lv[l].h;
         const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
@@ -229,36 +230,45 @@ void orb_tables_free(OrbTables* t) {
 }
 
 // ------------------------------------------------------------------------------------------- K1 pyramid
-// each thread produces 4 consecutive output pixels of one row (one 32-bit store)
+// each thread produces 4 consecutive output pixels of one row: per source row ONE unaligned 8-byte load covers the <= 6
+// source pixels they interpolate (scale 1.2), coefficients come as one int4 + one 16-byte load, the result is one dword store
 __global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t* __restrict__ src_base, size_t src_img_stride, int spitch,
                                                         int sw, int sh, uint8_t* __restrict__ dst_base, size_t dst_img_stride,
                                                         int dpitch, int dw, int dh, const int* __restrict__ xofs,
                                                         const short* __restrict__ ialpha, const int* __restrict__ yofs,
                                                         const short* __restrict__ ibeta) {
-    const int b = blockIdx.z, dy = blockIdx.y;
-    const int dx0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (dx0 >= dw) return;
+    const int b = blockIdx.z;
+    const int quads = (dw + 3) >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= quads * dh) return;
+    const int dy = idx / quads, dx0 = (idx - dy * quads) << 2;
     const uint8_t* src = src_base + (size_t)b * src_img_stride;
     uint8_t* dst = dst_base + (size_t)b * dst_img_stride;
     const int sy = yofs[dy];
     const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
     const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
-    const uint8_t* S0 = src + (size_t)y0 * spitch;
-    const uint8_t* S1 = src + (size_t)y1 * spitch;
+    const int4 xo = *reinterpret_cast<const int4*>(xofs + dx0);
+    const uint4 al = *reinterpret_cast<const uint4*>(ialpha + 2 * dx0); // a0,a1 of 4 pixels as 8 shorts
+    // window start: xo.x, pulled back if an 8-byte read would leave the row's pitch
+    const int wx = min(xo.x, spitch - 8);
+    unsigned long long r0, r1;
+    __builtin_memcpy(&r0, src + (size_t)y0 * spitch + wx, 8);
+    __builtin_memcpy(&r1, src + (size_t)y1 * spitch + wx, 8);
+    const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
+    const uint32_t alw[4] = {al.x, al.y, al.z, al.w};
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int dx = dx0 + k;
-        if (dx < dw) {
-            const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
-            const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
-            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xFF) << (8 * k);
-        }
+        const int rel = sxs[k] - wx;              // 0..6 (the +1 neighbour at most 7)
+        const int a0 = (int)(short)(alw[k] & 0xFFFFu), a1 = (int)(short)(alw[k] >> 16);
+        // when sx is the last source column a1 == 0, so whatever byte sits at rel + 1 does not matter
+        const int p00 = (int)((r0 >> (8 * rel)) & 0xFFu), p01 = (int)((r0 >> (8 * min(rel + 1, 7))) & 0xFFu);
+        const int p10 = (int)((r1 >> (8 * rel)) & 0xFFu), p11 = (int)((r1 >> (8 * min(rel + 1, 7))) & 0xFFu);
+        const int h0 = p00 * a0 + p01 * a1, h1 = p10 * a0 + p11 * a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 0xFF) << (8 * k);
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + dx0) = packed; // dpitch is a multiple of 64
+    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + dx0) = packed; // dpitch is a multiple of 64; lanes past dw write padding
 }
 
 int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B,
@@ -271,7 +281,7 @@ int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t*
         const size_t sstride = l == 1 ? img_bytes : (size_t)plan.pyr_bytes;
         const int spitch = l == 1 ? pitch : ((S.w + 63) & ~63);
         const int dpitch = (D.w + 63) & ~63;
-        dim3 grid((D.w + 1023) / 1024, D.h, B);
+        dim3 grid((((D.w + 3) / 4) * D.h + 255) / 256, 1, B);
         hipLaunchKernelGGL(orb_resize_kernel, grid, dim3(256), 0, stream, src, sstride, spitch, S.w, S.h, d_pyr + D.pyr_off,
                            (size_t)plan.pyr_bytes, dpitch, D.w, D.h, tab.d_xofs + tab.x_off[l], tab.d_ialpha + 2 * tab.x_off[l],
                            tab.d_yofs + tab.y_off[l], tab.d_ibeta + 2 * tab.y_off[l]);
@@ -463,20 +473,21 @@ __device__ inline float float_from_order_key(uint32_t k) {
 // ------------------------------------------------------------------------------------------- K3 select
 __device__ inline float harris_response_dev(const LevelView& V, int x0, int y0) {
     const int step = V.pitch;
-    const uint8_t* ptr0 = V.ptr + (size_t)(y0 - 3) * step + (x0 - 3);
-    int a = 0, b = 0, c = 0;
-    for (int i = 0; i < 7; ++i) {
-        // three rows of 9 pixels around block row i
-        const uint8_t* r0 = ptr0 + (i - 1) * step - 1;
-        const uint8_t* r1 = r0 + step;
-        const uint8_t* r2 = r1 + step;
-        int p0[9], p1[9], p2[9];
+    // 9 x 9 pixel window (7x7 block + 1 px Sobel apron) as 9 rows x 3 unaligned dwords, all loads in flight at once
+    const uint8_t* base = V.ptr + (size_t)(y0 - 4) * step + (x0 - 4);
+    uint32_t wdw[9][3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { p0[k] = r0[k]; p1[k] = r1[k]; p2[k] = r2[k]; }
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) __builtin_memcpy(&wdw[r][q], base + (size_t)r * step + 4 * q, 4);
+    auto px = [&](int r, int c) -> int { return (int)((wdw[r][c >> 2] >> (8 * (c & 3))) & 0xFFu); };
+    int a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-            const int Ix = (p1[j + 2] - p1[j]) * 2 + (p0[j + 2] - p0[j]) + (p2[j + 2] - p2[j]);
-            const int Iy = (p2[j + 1] - p0[j + 1]) * 2 + (p2[j] - p0[j]) + (p2[j + 2] - p0[j + 2]);
+            const int Ix = (px(i + 1, j + 2) - px(i + 1, j)) * 2 + (px(i, j + 2) - px(i, j)) + (px(i + 2, j + 2) - px(i + 2, j));
+            const int Iy = (px(i + 2, j + 1) - px(i, j + 1)) * 2 + (px(i + 2, j) - px(i, j)) + (px(i + 2, j + 2) - px(i, j + 2));
             a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
         }
     }
@@ -510,36 +521,65 @@ __device__ inline float fast_atan2_dev(float y, float x) {
     return a;
 }
 
-// wave-cooperative intensity-centroid angle: lane = (v row 0..15) x (u quarter 0..3)
-__device__ inline float ic_angle_wave(const LevelView& V, int x, int y) {
+// intensity-centroid angle by a 16-lane group (4 keypoints per wave): lane v of the group owns the row pair +-v, read
+// as 2 x 8 unaligned dwords (u = -15..16) issued together; |u| > umax[v] is masked out.
+__device__ inline float ic_angle_group16(const LevelView& V, int x, int y, bool valid) {
     const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-    const int lane = threadIdx.x & 63;
-    const int v = lane >> 2, q = lane & 3;
+    const int v = threadIdx.x & 15;
     int dmax = 15;
 #pragma unroll
     for (int k = 0; k < 16; ++k) if (k == v) dmax = umax[k];
-    const int len = 2 * dmax + 1;
-    const int u0 = -dmax + (len * q) / 4, u1 = -dmax + (len * (q + 1)) / 4;
-    const uint8_t* c = V.ptr + (size_t)y * V.pitch + x;
     int m10 = 0, vsum = 0;
-    if (v == 0) {
-        for (int u = u0; u < u1; ++u) m10 += u * c[u];
-    } else {
-        const uint8_t* cp = c + v * V.pitch;
-        const uint8_t* cm = c - v * V.pitch;
-        for (int u = u0; u < u1; ++u) {
-            const int vp = cp[u], vm = cm[u];
-            vsum += vp - vm;
-            m10 += u * (vp + vm);
+    if (valid) {
+        const uint8_t* cp = V.ptr + (size_t)(y + v) * V.pitch + x - 15;
+        const uint8_t* cm = V.ptr + (size_t)(y - v) * V.pitch + x - 15;
+        uint32_t wp[8], wm[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { __builtin_memcpy(&wp[q], cp + 4 * q, 4); __builtin_memcpy(&wm[q], cm + 4 * q, 4); }
+#pragma unroll
+        for (int t = 0; t < 31; ++t) {
+            const int u = t - 15;
+            const int vp = (int)((wp[t >> 2] >> (8 * (t & 3))) & 0xFFu), vm = (int)((wm[t >> 2] >> (8 * (t & 3))) & 0xFFu);
+            const int in = (u >= -dmax && u <= dmax) ? 1 : 0;
+            vsum += in * (vp - vm);
+            m10 += in * u * (vp + vm); // row 0: vp == vm (same row read twice), halved below
         }
+        if (v == 0) m10 >>= 1; // exact: m10 = 2 * sum(u * I) on the centre row
     }
     int m01 = v * vsum;
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
     return fast_atan2_dev((float)m01, (float)m10);
 }
 
+// Largest bin d (255..0) such that the count of entries in bins >= d reaches `rank` (clamped to bin 0); optionally the
+// count strictly above d.  Wave 0 does a suffix scan with 4 bins per lane; every thread returns the same answer.
+__device__ inline int find_rank_bin(const int* hist, int rank, int* above_out) {
+    __shared__ int s_bin, s_above;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int b0 = 252 - 4 * lane; // this lane owns bins b0+3, b0+2, b0+1, b0 (descending); lane 0 owns 255..252
+        const int h3 = hist[b0 + 3], h2 = hist[b0 + 2], h1 = hist[b0 + 1], h0 = hist[b0];
+        const int mine = h3 + h2 + h1 + h0;
+        int incl = mine; // inclusive prefix over lanes = entries in bins >= b0
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int before = incl - mine; // entries in bins > b0 + 3
+        const bool here = before < rank && incl >= rank;
+        const bool last = lane == 63 && incl < rank; // fewer than `rank` entries in total: bin 0
+        if (here || last) {
+            int acc = before, d = b0 + 3;
+            if (acc + h3 >= rank) d = b0 + 3;
+            else { acc += h3; if (acc + h2 >= rank) d = b0 + 2; else { acc += h2; if (acc + h1 >= rank) d = b0 + 1; else { acc += h1; d = b0; } } }
+            if (last) { d = 0; acc = incl - h0; }
+            s_bin = d; s_above = acc;
+        }
+    }
+    __syncthreads();
+    if (above_out) *above_out = s_above;
+    return s_bin;
+}
+
 constexpr int kSelBlock = 512;
-constexpr int kCandCap = 8192;
+constexpr int kCandCap = 4096;
 
 __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes,
                                                               int pitch0, const uint8_t* __restrict__ d_pyr, size_t pyr_bytes,
@@ -567,10 +607,9 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kSelBlock) atomicAdd(&hist[corners[i] >> 24], 1);
     __syncthreads();
-    if (threadIdx.x == 0 && n > 2 * nfeat && nfeat > 0) {
-        int acc = 0, s = 255;
-        for (; s > 0; --s) { acc += hist[s]; if (acc >= 2 * nfeat) break; }
-        s_cut = s;
+    if (n > 2 * nfeat && nfeat > 0) { // uniform
+        const int d = find_rank_bin(hist, 2 * nfeat, nullptr);
+        if (threadIdx.x == 0) s_cut = d;
     }
     __syncthreads();
     const int cut = (nfeat > 0) ? s_cut : 256;
@@ -604,11 +643,12 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
                 if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFF], 1);
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                int rank = s_rank, acc = 0, d = 255;
-                for (; d > 0; --d) { if (acc + hist[d] >= rank) break; acc += hist[d]; }
-                s_rank = rank - acc;
-                s_prefix = prefix | ((uint32_t)d << shift);
+            {
+                int above = 0;
+                const int rank = s_rank;
+                const int d = find_rank_bin(hist, rank, &above);
+                __syncthreads();
+                if (threadIdx.x == 0) { s_rank = rank - above; s_prefix = prefix | ((uint32_t)d << shift); }
             }
             __syncthreads();
         }
@@ -640,14 +680,16 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     OPH(3);
     // ---- orientation + output (wave per keypoint)
     vslam_keypoint* out = d_sel + ((size_t)b * kNLevels + l) * sel_cap;
-    const int wave = threadIdx.x >> 6, nwaves = kSelBlock >> 6, lane = threadIdx.x & 63;
+    const int grp = threadIdx.x >> 4, ngrp = kSelBlock >> 4;
     const float scale = T.scale[l];
-    for (int i = wave; i < nout; i += nwaves) {
-        const unsigned long long e = keep[i];
+    for (int i0 = 0; i0 < nout; i0 += ngrp) { // uniform trip count: the group shuffles need whole waves
+        const int i = i0 + grp;
+        const bool valid = i < nout;
+        const unsigned long long e = valid ? keep[i] : 0ull;
         const uint32_t raster = (uint32_t)(e >> 32);
         const int x = raster & 0xFFF, y = raster >> 12;
-        const float ang = ic_angle_wave(V, x, y);
-        if (lane == 0) {
+        const float ang = ic_angle_group16(V, x, y, valid);
+        if (valid && (threadIdx.x & 15) == 0) {
             vslam_keypoint kp;
             kp.x = __fmul_rn((float)x, scale);
             kp.y = __fmul_rn((float)y, scale);
