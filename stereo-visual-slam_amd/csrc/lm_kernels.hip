@@ -66,6 +66,7 @@ struct LmKernelArgs {
     int capacity;
     uint8_t* act;     // total_lm
     uint8_t* eo;      // total_lm x kMaxKf
+    int32_t* kf_pos;  // total_edge
     int32_t* status;  // n_windows
     long long* dbg_cycles; // tuning aid (VSLAM_LM_PROFILE=1): 16 phase cycle counters per window, thread 0
     int dbg_skip;     // tuning aid (VSLAM_LM_SKIP): bit0 Schur hits, bit1 Cholesky, bit2 pose blocks, bit3 landmark blocks, bit4 eval, bit5 back-subst, bit6 setup lists
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
     double* chi2 = a.chi2 + e0;
     int32_t* lm_ptr = a.lm_ptr + lm0 + w;
     int32_t* kf_ptr = a.kf_ptr + (size_t)w * (kMaxKf + 1);
-    int32_t* kf_edges = a.kf_edges + e0;
+    int32_t* kf_lm = a.kf_edges + e0;   // landmark of the edge stored at by-pose position j
+    int32_t* kf_pos = ka.kf_pos + e0;    // by-pose (keyframe-major) position of edge e: where its linearisation record lives
     int32_t* pair_ptr = a.pair_ptr + (size_t)w * (kMaxPairs + 1);
     int4* hits = reinterpret_cast<int4*>(a.pair_hits) + (size_t)e0 * kHitsPerEdge;
     uint8_t* act = ka.act + lm0;
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
     auto EKF = [&](int e) -> int { return IMPL ? 0 : kfi[e]; };
     auto ELM = [&](int e) -> int { return IMPL ? e : lmi[e]; };
+    auto POS = [&](int e) -> int { return IMPL ? e : kf_pos[e]; };
 
     // ------------------------------------------------------------------ setup
     if (tid < 8) sm.flag[tid] = 0;
@@ -274,8 +277,10 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
     }
     __syncthreads();
     if (!IMPL) {
-        // ---- by-pose edge lists (ascending edge id inside a pose).  Every wave owns a contiguous edge range, loads it
-        // once per pass (few dependent global loads), and ranks its edges per keyframe with ballots.
+        // ---- keyframe-major positions (ascending edge id inside a pose).  The per-edge linearisation records are STORED in this
+        // order: pose-wise phases stream them, Schur hits of a keyframe pair read two nearly contiguous runs, and landmark-wise
+        // phases stay coalesced because neighbouring landmarks (creation order) sit at neighbouring positions of the same pose.
+        // Every wave owns a contiguous edge range, loads it once per pass and ranks its edges per keyframe with ballots.
         const int e_lo = (int)((long long)ne * wave / kLmWaves), e_hi = (int)((long long)ne * (wave + 1) / kLmWaves);
         for (int pass = 0; pass < 2; ++pass) {
             int run[kMaxKf];
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                 for (int kk = 0; kk < kMaxKf; ++kk) {
                     if (kk < nk) {
                         const unsigned long long m = __ballot(k == kk);
-                        if (pass && k == kk) kf_edges[run[kk] + __popcll(m & lt_mask)] = e;
+                        if (pass && k == kk) { const int slot = run[kk] + __popcll(m & lt_mask); kf_pos[e] = slot; kf_lm[slot] = lmi[e]; }
                         run[kk] += __popcll(m);
                     }
                 }
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                         const unsigned long long m = __ballot(hit);
                         if (m == 0) continue; // uniform
                         const int cur = sm.cnt[wave * kCntStride + p];
-                        if (pass && hit) hits[cur + __popcll(m & lt_mask)] = make_int4(eb0 + (int)o1, eb0 + (int)o2, l, 0);
+                        if (pass && hit) hits[cur + __popcll(m & lt_mask)] = make_int4(kf_pos[eb0 + (int)o1], kf_pos[eb0 + (int)o2], l, 0);
                         __builtin_amdgcn_wave_barrier();
                         if (lane == 0) sm.cnt[wave * kCntStride + p] = (uint16_t)0 + cur + __popcll(m);
                         __builtin_amdgcn_wave_barrier();
@@ -405,8 +410,9 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
             part += rho;
             if (store_lin) {
                 const double Zi = with_lm ? 1.0 / (Z + 1e-18) : 1.0 / Z; // optimization.cpp:66 vs :96-100
-                recA[e] = make_double4(X, Y, Zi, wgt);
-                recB[e] = make_double2(ex, ey);
+                const int ps = POS(e);
+                recA[ps] = make_double4(X, Y, Zi, wgt);
+                recB[ps] = make_double2(ex, ey);
             }
         }
         return block_sum(part, sm.red);
@@ -423,8 +429,9 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                 if (!act[l]) continue;
                 double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
                 for (int e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
-                    const double4 ra = recA[e];
-                    const double2 rb = recB[e];
+                    const int ps = kf_pos[e];
+                    const double4 ra = recA[ps];
+                    const double2 rb = recB[ps];
                     double A[12], B[6];
                     jac_pose(K, ra.x, ra.y, ra.z, A);
                     jac_point(A, &sm.Rt[12 * EKF(e)], B);
@@ -450,9 +457,8 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
             const int b0 = IMPL ? 0 : kf_ptr[k], b1 = IMPL ? ne : kf_ptr[k + 1];
             const int s0 = b0 + (int)((long long)(b1 - b0) * part / nparts), s1 = b0 + (int)((long long)(b1 - b0) * (part + 1) / nparts);
             for (int j = s0 + lane; j < s1; j += 64) {
-                const int e = IMPL ? j : kf_edges[j];
-                const double4 ra = recA[e];
-                const double2 rb = recB[e];
+                const double4 ra = recA[j];
+                const double2 rb = recB[j];
                 double A[12];
                 jac_pose(K, ra.x, ra.y, ra.z, A);
                 const double wg = ra.w, ex = rb.x, ey = rb.y;
@@ -520,8 +526,8 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                     const int b0 = kf_ptr[k], b1 = kf_ptr[k + 1];
                     const int s0 = b0 + (int)((long long)(b1 - b0) * part / nparts), s1 = b0 + (int)((long long)(b1 - b0) * (part + 1) / nparts);
                     for (int j = s0 + lane; j < s1; j += 64) {
-                        const int e = kf_edges[j], l = lmi[e];
-                        const double4 ra = recA[e];
+                        const int l = kf_lm[j];
+                        const double4 ra = recA[j];
                         double A[12], B[6];
                         jac_pose(K, ra.x, ra.y, ra.z, A);
                         jac_point(A, &sm.Rt[12 * k], B);
@@ -612,40 +618,60 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                         sm.S[(6 * I + r) * np + 6 * J + c] = v;
                     }
                     __syncthreads();
-                    // (2) factor the diagonal block (thread 0), flag failure
-                    if (tid == 0) {
+                    // (2) every lane that owns a row below (and lane 0, which stores L_JJ) factors the 6x6 diagonal block in
+                    //     registers (redundantly: cheaper than a serial thread + barrier), then solves its row against it
+                    const int nrows = (nk - J - 1) * 6;
+                    if (tid < nrows || tid == 0) {
+                        double D[21]; // lower triangle, row-major: (i,j) -> i*(i+1)/2 + j
+#pragma unroll
+                        for (int i = 0; i < 6; ++i)
+#pragma unroll
+                            for (int j = 0; j <= i; ++j) D[i * (i + 1) / 2 + j] = sm.S[(6 * J + i) * np + 6 * J + j];
                         bool good = true;
-                        for (int j = 0; j < 6 && good; ++j) {
-                            double d = sm.S[(6 * J + j) * np + 6 * J + j];
-                            for (int kk = 0; kk < j; ++kk) d -= sm.S[(6 * J + j) * np + 6 * J + kk] * sm.S[(6 * J + j) * np + 6 * J + kk];
-                            if (!(d > 0.0) || !isfinite(d)) { good = false; break; }
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            double d = D[j * (j + 1) / 2 + j];
+#pragma unroll
+                            for (int kk = 0; kk < j; ++kk) d -= D[j * (j + 1) / 2 + kk] * D[j * (j + 1) / 2 + kk];
+                            if (!(d > 0.0) || !isfinite(d)) good = false;
                             d = sqrt(d);
-                            sm.S[(6 * J + j) * np + 6 * J + j] = d;
+                            D[j * (j + 1) / 2 + j] = d;
+#pragma unroll
                             for (int i = j + 1; i < 6; ++i) {
-                                double v = sm.S[(6 * J + i) * np + 6 * J + j];
-                                for (int kk = 0; kk < j; ++kk) v -= sm.S[(6 * J + i) * np + 6 * J + kk] * sm.S[(6 * J + j) * np + 6 * J + kk];
-                                sm.S[(6 * J + i) * np + 6 * J + j] = v / d;
+                                double v = D[i * (i + 1) / 2 + j];
+#pragma unroll
+                                for (int kk = 0; kk < j; ++kk) v -= D[i * (i + 1) / 2 + kk] * D[j * (j + 1) / 2 + kk];
+                                D[i * (i + 1) / 2 + j] = v / d;
                             }
                         }
-                        if (!good) sm.flag[1] = 1;
-                    }
-                    __syncthreads();
-                    if (sm.flag[1]) { ok2 = false; break; } // uniform
-                    // (3) rows below: L[I][J] = S[I][J] L[J][J]^-T   -- one lane per row
-                    for (int t = tid; t < (nk - J - 1) * 6; t += kLmBlock) {
-                        const int row = 6 * (J + 1) + t;
                         double x[6];
+                        const int row = 6 * (J + 1) + tid;
+                        if (tid < nrows) {
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            double v = sm.S[row * np + 6 * J + c];
+                            for (int c = 0; c < 6; ++c) {
+                                double v = sm.S[row * np + 6 * J + c];
 #pragma unroll
-                            for (int kk = 0; kk < 6; ++kk) if (kk < c) v -= x[kk] * sm.S[(6 * J + c) * np + 6 * J + kk];
-                            x[c] = v / sm.S[(6 * J + c) * np + 6 * J + c];
+                                for (int kk = 0; kk < c; ++kk) v -= x[kk] * D[c * (c + 1) / 2 + kk];
+                                x[c] = v / D[c * (c + 1) / 2 + c];
+                            }
                         }
+                        if (tid == 0 && !good) sm.flag[1] = 1;
+                        if (tid < nrows)
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) sm.S[row * np + 6 * J + c] = x[c];
+                            for (int c = 0; c < 6; ++c) sm.S[row * np + 6 * J + c] = x[c];
+                        // L_JJ is written only after the barrier below: other waves may still be reading the unfactored block
+                        if (tid == 0) {
+#pragma unroll
+                            for (int i = 0; i < 21; ++i) sm.xp[i] = D[i]; // parked in xp (free until the solves)
+                        }
                     }
                     __syncthreads();
+                    if (tid < 21) { // unpack the parked lower triangle into S (J,J)
+                        int i = 0, rem = tid;
+                        while (rem > i) { rem -= i + 1; ++i; }
+                        sm.S[(6 * J + i) * np + 6 * J + rem] = sm.xp[tid];
+                    }
+                    if (sm.flag[1]) { ok2 = false; break; } // uniform
                 }
                 PH(7);
                 if (sm.flag[1]) ok2 = false;
@@ -703,7 +729,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                     double c0 = g[0], c1 = g[1], c2 = g[2];
                     for (int e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
                         const int k = kfi[e];
-                        const double4 ra = recA[e];
+                        const double4 ra = recA[kf_pos[e]];
                         double A[12], B[6];
                         jac_pose(K, ra.x, ra.y, ra.z, A);
                         jac_point(A, &sm.Rt[12 * k], B);
@@ -853,6 +879,7 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     const size_t o_hits = need; need += with_lm ? al(total_edge * kHitsPerEdge * 16) : 256;
     const size_t o_act = need; need += al(total_lm);
     const size_t o_eo = need; need += with_lm ? al(total_lm * kMaxKf) : 256;
+    const size_t o_kpos = need; need += al(total_edge * 4);
     const size_t o_st = need; need += al((size_t)n_windows * 4);
     const size_t o_chi = need; need += al(total_edge * 8);
     // hipFree/hipMalloc are synchronising; growth only happens on the first call of a given size
@@ -862,7 +889,7 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     ka.a.bl = (double*)(base + o_bl); ka.a.Dinv = (double*)(base + o_Di); ka.a.db = (double*)(base + o_db);
     ka.a.lin = (double*)(base + o_lin); ka.a.lm_ptr = (int32_t*)(base + o_lmptr); ka.a.kf_ptr = (int32_t*)(base + o_kfptr);
     ka.a.kf_edges = (int32_t*)(base + o_kfe); ka.a.pair_ptr = (int32_t*)(base + o_pp); ka.a.pair_hits = (int32_t*)(base + o_hits);
-    ka.act = base + o_act; ka.eo = base + o_eo; ka.status = (int32_t*)(base + o_st);
+    ka.act = base + o_act; ka.eo = base + o_eo; ka.kf_pos = (int32_t*)(base + o_kpos); ka.status = (int32_t*)(base + o_st);
     g_lm.status = ka.status; g_lm.status_n = n_windows;
     if (!ka.a.chi2) ka.a.chi2 = (double*)(base + o_chi);
     return VSLAM_OK;

@@ -66,6 +66,19 @@ def test_local_ba_parity(vo, oracle, synth, n_lm, seed, iters):
     assert r["threshold"] == th and (r["lm_inlier"] == inl).all()
 
 
+@pytest.mark.parametrize("n_kf,n_lm", [(12, 800), (3, 120), (1, 60)])
+def test_local_ba_other_window_sizes(vo, oracle, synth, n_kf, n_lm):
+    """window sizes other than the reference's 10 (VSLAM_MAX_KF = 12 crosses a wave boundary in the LDS Cholesky)"""
+    w = synth.ba_window(n_kf=n_kf, n_lm=n_lm, seed=21, min_obs=1 if n_kf < 3 else 2, max_obs=min(5, n_kf))
+    r = vo.optimize_map(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], True, True, 8)
+    T, xyz, chi2, st = oracle.local_ba(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], iters=8, update_poses=True, update_lms=True)
+    _stats_close(r["stats"], st)
+    assert np.allclose(r["T"], T, rtol=RTOL, atol=1e-6)
+    r = vo.optimize_pose_only(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], True, 8)
+    T, chi2, st = oracle.pose_only_window(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], iters=8)
+    assert np.allclose(r["T"], T, rtol=RTOL, atol=1e-6)
+
+
 def test_local_ba_no_writeback(vo, synth):
     w = synth.ba_window(n_kf=10, n_lm=200, seed=4)
     r = vo.optimize_map(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], False, False, 5)
