@@ -28,7 +28,10 @@
 
 namespace vslam {
 
-constexpr int kLmBlock = 512;
+#ifndef VSLAM_LM_BLOCK
+#define VSLAM_LM_BLOCK 512
+#endif
+constexpr int kLmBlock = VSLAM_LM_BLOCK;
 constexpr int kLmWaves = kLmBlock / 64;
 constexpr int kMaxKf = VSLAM_MAX_KF;
 constexpr int kMaxNp = 6 * kMaxKf;
@@ -37,7 +40,7 @@ constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
 constexpr int kLin = 8;        // doubles per edge of linearisation scratch: {X, Y, 1/Z, w} + {ex, ey} (+2 pad: 64-B aligned windows)
 constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
 constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
-constexpr int kItemSlots = 10; // Schur work items (keyframe pairs) per wave: ceil(kMaxPairs / kLmWaves)
+constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work items (keyframe pairs) per wave
 
 size_t lm_hits_per_edge() { return kHitsPerEdge; }
 
@@ -132,9 +135,9 @@ __device__ inline void project_err(const double* Rt, const double* K, double px,
     X = Rt[0] * px + Rt[1] * py + Rt[2] * pz + Rt[9];
     Y = Rt[3] * px + Rt[4] * py + Rt[5] * pz + Rt[10];
     Z = Rt[6] * px + Rt[7] * py + Rt[8] * pz + Rt[11];
-    const double qx = K[0] * X + K[2] * Z, qy = K[1] * Y + K[3] * Z;
-    ex = (double)u - qx / Z;
-    ey = (double)v - qy / Z;
+    const double rz = 1.0 / Z; // one reciprocal instead of two divisions (K*(T*p) / z, optimization.cpp:46-49); tolerance-checked
+    ex = (double)u - (K[0] * X * rz + K[2]);
+    ey = (double)v - (K[1] * Y * rz + K[3]);
 }
 
 __device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double Di[6]) {
@@ -559,36 +562,82 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                     double acc[36];
 #pragma unroll
                     for (int i = 0; i < 36; ++i) acc[i] = 0;
-                    for (int j = pair_ptr[p] + lane; j < pair_ptr[p + 1]; j += 64) {
-                        const int4 h = hits[j];
-                        const double4 ra = recA[h.x], rb = recA[h.y];
-                        const double2* Dp = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
-                        const double2 Da = Dp[0], Db = Dp[1], Dc = Dp[2]; // D00 D01 | D02 D11 | D12 D22
-                        double A1[12], A2[12], B1[6], B2[6];
-                        jac_pose(K, ra.x, ra.y, ra.z, A1);
-                        jac_point(A1, &sm.Rt[12 * k1], B1);
-                        jac_pose(K, rb.x, rb.y, rb.z, A2);
-                        jac_point(A2, &sm.Rt[12 * k2], B2);
-                        // M (2x2) = (w1 B1) Dinv (w2 B2)^T
-                        double BD[6];
+                    if (k1 == k2) { // every edge of keyframe k1 pairs with itself: one Jacobian, symmetric 2x2 core, upper triangle only
+                        // software-pipelined: the next hit's records are requested before the current hit is consumed
+                        const int jend = pair_ptr[p + 1];
+                        int j = pair_ptr[p] + lane;
+                        int4 h = hits[min(j, jend - 1)];
+                        double4 ra = recA[h.x];
+                        const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
+                        double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
+                        for (; j < jend; j += 64) {
+                            const int4 hn = hits[min(j + 64, jend - 1)];
+                            const double4 ran = recA[hn.x];
+                            const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.z);
+                            const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
+                            double A1[12], B1[6];
+                            jac_pose(K, ra.x, ra.y, ra.z, A1);
+                            jac_point(A1, &sm.Rt[12 * k1], B1);
+                            double BD[6];
 #pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            BD[3 * r] = B1[3 * r] * Da.x + B1[3 * r + 1] * Da.y + B1[3 * r + 2] * Db.x;
-                            BD[3 * r + 1] = B1[3 * r] * Da.y + B1[3 * r + 1] * Db.y + B1[3 * r + 2] * Dc.x;
-                            BD[3 * r + 2] = B1[3 * r] * Db.x + B1[3 * r + 1] * Dc.x + B1[3 * r + 2] * Dc.y;
+                            for (int r = 0; r < 2; ++r) {
+                                BD[3 * r] = B1[3 * r] * Da.x + B1[3 * r + 1] * Da.y + B1[3 * r + 2] * Db.x;
+                                BD[3 * r + 1] = B1[3 * r] * Da.y + B1[3 * r + 1] * Db.y + B1[3 * r + 2] * Dc.x;
+                                BD[3 * r + 2] = B1[3 * r] * Db.x + B1[3 * r + 1] * Dc.x + B1[3 * r + 2] * Dc.y;
+                            }
+                            const double ww = ra.w * ra.w;
+                            const double M00 = ww * (BD[0] * B1[0] + BD[1] * B1[1] + BD[2] * B1[2]);
+                            const double M01 = ww * (BD[0] * B1[3] + BD[1] * B1[4] + BD[2] * B1[5]);
+                            const double M11 = ww * (BD[3] * B1[3] + BD[4] * B1[4] + BD[5] * B1[5]);
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+                                const double m0 = A1[r] * M00 + A1[6 + r] * M01, m1 = A1[r] * M01 + A1[6 + r] * M11;
+#pragma unroll
+                                for (int c = r; c < 6; ++c) acc[6 * r + c] += m0 * A1[c] + m1 * A1[6 + c];
+                            }
+                            ra = ran; Da = Dan; Db = Dbn; Dc = Dcn;
                         }
-                        const double ww = ra.w * rb.w;
-                        double M[4];
 #pragma unroll
-                        for (int r = 0; r < 2; ++r)
+                        for (int r = 1; r < 6; ++r)
 #pragma unroll
-                            for (int c = 0; c < 2; ++c) M[2 * r + c] = ww * (BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]);
-                        // C = A1^T M A2
+                            for (int c = 0; c < r; ++c) acc[6 * r + c] = acc[6 * c + r];
+                    } else {
+                        const int jend = pair_ptr[p + 1];
+                        int j = pair_ptr[p] + lane;
+                        int4 h = hits[min(j, jend - 1)];
+                        double4 ra = recA[h.x], rb = recA[h.y];
+                        const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
+                        double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
+                        for (; j < jend; j += 64) {
+                            const int4 hn = hits[min(j + 64, jend - 1)];
+                            const double4 ran = recA[hn.x], rbn = recA[hn.y];
+                            const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.z);
+                            const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
+                            double A1[12], A2[12], B1[6], B2[6];
+                            jac_pose(K, ra.x, ra.y, ra.z, A1);
+                            jac_point(A1, &sm.Rt[12 * k1], B1);
+                            jac_pose(K, rb.x, rb.y, rb.z, A2);
+                            jac_point(A2, &sm.Rt[12 * k2], B2);
+                            double BD[6];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) {
-                            const double m0 = A1[r] * M[0] + A1[6 + r] * M[2], m1 = A1[r] * M[1] + A1[6 + r] * M[3];
+                            for (int r = 0; r < 2; ++r) {
+                                BD[3 * r] = B1[3 * r] * Da.x + B1[3 * r + 1] * Da.y + B1[3 * r + 2] * Db.x;
+                                BD[3 * r + 1] = B1[3 * r] * Da.y + B1[3 * r + 1] * Db.y + B1[3 * r + 2] * Dc.x;
+                                BD[3 * r + 2] = B1[3 * r] * Db.x + B1[3 * r + 1] * Dc.x + B1[3 * r + 2] * Dc.y;
+                            }
+                            const double ww = ra.w * rb.w;
+                            double M[4];
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) acc[6 * r + c] += m0 * A2[c] + m1 * A2[6 + c];
+                            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                                for (int c = 0; c < 2; ++c) M[2 * r + c] = ww * (BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]);
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+                                const double m0 = A1[r] * M[0] + A1[6 + r] * M[2], m1 = A1[r] * M[1] + A1[6 + r] * M[3];
+#pragma unroll
+                                for (int c = 0; c < 6; ++c) acc[6 * r + c] += m0 * A2[c] + m1 * A2[6 + c];
+                            }
+                            ra = ran; rb = rbn; Da = Dan; Db = Dbn; Dc = Dcn;
                         }
                     }
 #pragma unroll
