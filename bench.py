@@ -161,6 +161,13 @@ def main():
         alg, formula = algorithmic_bytes(dom, pipe, args.anms)
         per_bracket_s = dom_ms / 1e3 / max(dom_calls, 1)
         achieved = alg / per_bracket_s / 1e9 if per_bracket_s > 0 else 0.0
+        traffic = None
+        try:  # measured offline with rocprofv3 PMC passes (tools/profile_round.sh); only valid for the same kernel and batch
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("kernel") == dom and tj.get("batch") == B:
+                traffic = int(tj["hbm_bytes_per_launch_set"])
+        except Exception:
+            traffic = None
         res = {
             "metric": "stereo keyframes/sec (ORB+match+tri+local-BA), KITTI-00 1241x376",
             "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,7 +178,7 @@ def main():
                                    "(5+5+10 LM + 10 pose-only)%s" % (args.anms, args.landmarks, "" if not args.no_ba else " [BA disabled]"),
                        "batch_keyframes_per_gpu": B, "image": "1241x376 u8", "parallelism": "%d independent replicas, sharded keyframes" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch_set": int(alg), "formula": formula,
                          "avg_ms_per_launch_set": round(1e3 * per_bracket_s, 4), "kernel_launches_per_set": dom_launches // max(dom_calls, 1)},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kern},
