@@ -125,6 +125,19 @@ int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stri
                                const double* d_gap, int gate, int B, int max_rows,
                                vslam_dmatch* d_out, int out_capacity, int32_t* d_nout);
 
+/* ------------------------------------------------------------------ A6: dense stereo disparity --------- */
+/* Replaces VO::disparity_map (visual_odometry.cpp:159-174): cv::StereoSGBM::create(0, 96, 9, 8*9*9, 32*9*9, 1, 63, 10,
+ * 100, 32)->compute(left, right) followed by convertTo(CV_32F, 1/16).  left/right: h x w u8 (row stride in bytes);
+ * disparity: h x w f32, tightly packed (invalid pixels = -1.0, like the reference).  Optional outputs (may be NULL):
+ * disp_i16 = the CV_16S fixed-point map after median + speckle filtering, disp_raw_i16 = before them. */
+int vslam_disparity_map(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                        float* disparity, int16_t* disp_i16, int16_t* disp_raw_i16);
+
+/* Batched, device-resident: B stereo pairs at d_left/d_right + b*img_stride_bytes (row pitch in bytes); outputs
+ * B x h x w, tightly packed.  The SGBM working set (about 250 MB per 1241x376 pair) is grown on demand and kept. */
+int vslam_disparity_map_dev(vslam_ctx* ctx, const uint8_t* d_left, const uint8_t* d_right, size_t img_stride_bytes,
+                            int pitch, int w, int h, int B, float* d_disparity, int16_t* d_disp_i16, int16_t* d_disp_raw_i16);
+
 /* ------------------------------------------------------------------ A7: depth -> landmarks ------------ */
 /* Replaces Frame::find_3d (types_def.cpp:9-18) + the gating of VO::set_ref_3d_position
  * (visual_odometry.cpp:176-217) for a disparity map (h x w f32, row stride in elements).  No compaction:

@@ -29,7 +29,7 @@ class OrbLayout(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orb.c", "match.c", "geom.c", "lm.c", "vo_oracle.h", "orb_pattern.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb.c", "match.c", "geom.c", "lm.c", "sgbm.c", "vo_oracle.h", "orb_pattern.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -189,6 +189,28 @@ def feature_matching(q, t, frame_gap=1.0):
     out = np.zeros(max(len(q), 1), DMATCH_DTYPE)
     n = lib().vo_feature_matching(_p(q), len(q), _p(t), len(t), C.c_double(frame_gap), _p(out))
     return out[:n].copy()
+
+
+# ---------------------------------------------------------------- SGBM
+def sgbm_compute(left, right, num_disp=96, block=9, P1=648, P2=2592, disp12_max_diff=1, pre_filter_cap=63, uniqueness=10,
+                 speckle_window=100, speckle_range=32, return_raw=False):
+    left, right = _u8img(left), _u8img(right)
+    assert left.shape == right.shape
+    h, w = left.shape
+    disp = np.zeros((h, w), np.int16); raw = np.zeros((h, w), np.int16)
+    rc = lib().vo_sgbm_compute(_p(left), _p(right), w, h, left.strides[0], num_disp, block, P1, P2, disp12_max_diff, pre_filter_cap,
+                               uniqueness, speckle_window, speckle_range, _p(disp), _p(raw))
+    assert rc == 0, rc
+    return (disp, raw) if return_raw else disp
+
+
+def disparity_map(left, right):
+    left, right = _u8img(left), _u8img(right)
+    h, w = left.shape
+    out = np.zeros((h, w), np.float32)
+    rc = lib().vo_disparity_map(_p(left), _p(right), w, h, left.strides[0], _p(out))
+    assert rc == 0
+    return out
 
 
 # ---------------------------------------------------------------- geometry

@@ -123,6 +123,16 @@ int vo_bf_match_hamming_xcheck(const uint8_t* q, int nq, const uint8_t* t, int n
 /* VO::feature_matching (visual_odometry.cpp:219-251): cross-check match + gate d <= max(2*dmin, 30*gap). */
 int vo_feature_matching(const uint8_t* q, int nq, const uint8_t* t, int nt, double frame_gap, vo_dmatch* out);
 
+/* ------------------------------------------------------------------ stereo depth (A6) ---------------- */
+
+/* cv::StereoSGBM (MODE_SGBM) + medianBlur 3x3 + filterSpeckles; disp is h x w int16 in 1/16 px, invalid = -16.
+ * [UPSTREAM OpenCV 3.2 calib3d/src/stereosgbm.cpp]  disp_raw (optional) receives the map before median/speckle. */
+int vo_sgbm_compute(const uint8_t* left, const uint8_t* right, int w, int h, int stride, int num_disp, int block, int P1, int P2,
+                    int disp12_max_diff, int pre_filter_cap, int uniqueness, int speckle_window, int speckle_range, int16_t* disp,
+                    int16_t* disp_raw);
+/* VO::disparity_map (visual_odometry.cpp:159-174): SGBM(0,96,9,648,2592,1,63,10,100,32) -> f32 disparity, invalid = -1 */
+int vo_disparity_map(const uint8_t* left, const uint8_t* right, int w, int h, int stride, float* disparity);
+
 /* ------------------------------------------------------------------ geometry (A7, A9) ---------------- */
 
 /* SE3 stored as 7 doubles: unit quaternion (x,y,z,w) then translation (Sophus::SE3d memory order). */

@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
-    "vslam_profile_enable", "vslam_profile_read",
+    "vslam_profile_enable", "vslam_profile_read", "vslam_disparity_map", "vslam_disparity_map_dev",
 ]
 
 
@@ -238,6 +238,26 @@ class VO:
         self._chk(self.lib.vslam_feature_matching_dev(self.h, _p(d_q), C.c_size_t(q_stride), _p(d_nq), _p(d_t), C.c_size_t(t_stride),
                                                       _p(d_nt), _p(d_gap), int(gate), int(B), int(max_rows), _p(d_out), int(out_cap),
                                                       _p(d_nout)), "vslam_feature_matching_dev")
+
+    # ------------------------------------------------------------ VO::disparity_map (StereoSGBM + convertTo 1/16)
+    def disparity_map(self, left, right, return_i16=False):
+        """visual_odometry.cpp:159-174.  Returns the f32 disparity map (invalid = -1); with return_i16 also the CV_16S
+        map after median/speckle filtering and the raw SGBM output before them."""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        assert left.ndim == 2 and left.shape == right.shape
+        h, w = left.shape
+        out = np.zeros((h, w), np.float32)
+        i16 = np.zeros((h, w), np.int16) if return_i16 else None
+        raw = np.zeros((h, w), np.int16) if return_i16 else None
+        self._chk(self.lib.vslam_disparity_map(self.h, _p(left), _p(right), w, h, w, _p(out), _p(i16) if return_i16 else None,
+                                               _p(raw) if return_i16 else None), "vslam_disparity_map")
+        return (out, i16, raw) if return_i16 else out
+
+    def disparity_map_dev(self, d_left, d_right, img_stride_bytes, pitch, w, h, B, d_disp, d_i16=None, d_raw=None):
+        self._chk(self.lib.vslam_disparity_map_dev(self.h, _p(d_left), _p(d_right), C.c_size_t(int(img_stride_bytes)), int(pitch), int(w),
+                                                   int(h), int(B), _p(d_disp) if d_disp is not None else None,
+                                                   _p(d_i16) if d_i16 is not None else None,
+                                                   _p(d_raw) if d_raw is not None else None), "vslam_disparity_map_dev")
 
     # ------------------------------------------------------------ Frame::find_3d / VO::set_ref_3d_position
     def find_3d_disparity(self, kps, disparity, T_c_w):

@@ -150,7 +150,8 @@ const char* vslam_last_error(void) { return g_err; }
 const char* vslam_version(void) { return "vslam_hip 0.1 (gfx950)"; }
 const char* vslam_kernel_names(void) {
     return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_blur_kernel orb_describe_kernel match_train_nearest_kernel "
-           "match_finalize_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel";
+           "match_finalize_kernel sgbm_prefilter_kernel sgbm_pixcost_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_vertical_kernel "
+           "sgbm_horizontal_kernel sgbm_median3_kernel sgbm_ccl_union_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel";
 }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
@@ -193,6 +194,7 @@ void vslam_destroy(vslam_ctx* ctx) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     orb_tables_free(&c->tab);
+    if (c->d_sgbm) hipFree(c->d_sgbm);
     void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs,
                     c->match.d_train_best, c->d_stage};
     for (void* q : ptrs) if (q) hipFree(q);
@@ -378,6 +380,41 @@ int vslam_feature_matching(vslam_ctx* ctx, const uint8_t* q, int nq, const uint8
 }
 
 // ---------------------------------------------------------------------------------------------- geometry
+// ---------------------------------------------------------------------------------------------- SGBM
+int vslam_disparity_map_dev(vslam_ctx* ctx, const uint8_t* d_left, const uint8_t* d_right, size_t img_stride_bytes, int pitch, int w, int h,
+                            int B, float* d_disparity, int16_t* d_disp_i16, int16_t* d_disp_raw_i16) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_left || !d_right || w <= 0 || h <= 0 || pitch < w || B < 0 || img_stride_bytes < (size_t)pitch * h ||
+        (!d_disparity && !d_disp_i16 && !d_disp_raw_i16)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_HIP(hipSetDevice(c->device));
+    return launch_sgbm(d_left, d_right, img_stride_bytes, pitch, w, h, B, d_disparity, d_disp_i16, d_disp_raw_i16, &c->d_sgbm, &c->sgbm_bytes,
+                       &c->dev_bytes, c->stream);
+}
+
+int vslam_disparity_map(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, int stride, float* disparity, int16_t* disp_i16,
+                        int16_t* disp_raw_i16) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !left || !right || w <= 0 || h <= 0 || stride < w || (!disparity && !disp_i16 && !disp_raw_i16)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_HIP(hipSetDevice(c->device));
+    int rc;
+    const size_t npix = (size_t)w * h;
+    if ((rc = arena_reserve(c, 2 * al256((size_t)((w + 63) & ~63) * h) + al256(npix * 4) + 2 * al256(npix * 2) + 1024))) return rc;
+    Arena ar(c);
+    uint8_t *d_l, *d_r; int pl, pr;
+    if ((rc = upload_image(c, ar, left, w, h, stride, &d_l, &pl))) return rc;
+    if ((rc = upload_image(c, ar, right, w, h, stride, &d_r, &pr))) return rc;
+    float* d_f = arena_take<float>(ar, npix);
+    int16_t* d_i = arena_take<int16_t>(ar, npix);
+    int16_t* d_raw = arena_take<int16_t>(ar, npix);
+    if ((rc = launch_sgbm(d_l, d_r, (size_t)pl * h, pl, w, h, 1, d_f, d_i, disp_raw_i16 ? d_raw : nullptr, &c->d_sgbm, &c->sgbm_bytes, &c->dev_bytes,
+                          c->stream))) return rc;
+    if (disparity) VS_HIP(hipMemcpyAsync(disparity, d_f, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    if (disp_i16) VS_HIP(hipMemcpyAsync(disp_i16, d_i, npix * 2, hipMemcpyDeviceToHost, c->stream));
+    if (disp_raw_i16) VS_HIP(hipMemcpyAsync(disp_raw_i16, d_raw, npix * 2, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    return VSLAM_OK;
+}
+
 int vslam_find_3d_disparity(vslam_ctx* ctx, const vslam_keypoint* kps, int n, const float* disparity, int w, int h, int dstride,
                             const double T_c_w[7], float* xyz_w, uint8_t* valid, uint8_t* reliable, int* n_valid) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);

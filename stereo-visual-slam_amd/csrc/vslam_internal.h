@@ -171,6 +171,11 @@ struct LmWindowArgs {
     size_t total_lm, total_edge;
 };
 // mode 0 = optimize_map (EdgeProjection + Schur), 1 = optimize_pose_only.
+// sgbm_kernels.hip.  *scratch / *scratch_bytes: caller-owned growable device buffer.
+int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
+                int16_t* d_disp_i16, int16_t* d_disp_raw, uint8_t** scratch, size_t* scratch_bytes, size_t* dev_bytes, hipStream_t stream);
+size_t sgbm_scratch_bytes(int w, int h, int B);
+
 int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms,
                       hipStream_t stream);
 size_t lm_hits_per_edge();
@@ -197,6 +202,8 @@ struct Ctx {
     // staging for the host-buffer API (sized for one item)
     uint8_t* d_stage; size_t stage_bytes;
     uint8_t* h_pinned; size_t pinned_bytes;
+    // SGBM working set (cost volumes; grown on demand by vslam_disparity_map*)
+    uint8_t* d_sgbm; size_t sgbm_bytes;
 };
 
 } // namespace vslam
