@@ -108,163 +108,183 @@ __global__ __launch_bounds__(256) void sgbm_vsum_kernel(SgbmDims dm, const int16
     C[((size_t)b * dm.h + y) * dm.width1 * dm.D + idx] = (int16_t)s;
 }
 
-// ------------------------------------------------------------------------------------------- vertical paths
-// Lrow[buf][dir][x + 1][d]  (x = -1 and x = width1 are the zero borders), mrow[buf][dir][x + 1]
-constexpr int kVBlock = 1024;
+// ------------------------------------------------------------------------------------------- path aggregation
+// The five SGM paths of MODE_SGBM's single pass are independent 1-D recurrences along image lines:
+//   L_r(p, d) = C(p, d) + min(L_r(p-r, d), L_r(p-r, d-1) + P1, L_r(p-r, d+1) + P1, min_k L_r(p-r, k) + P2) - (min_k L_r(p-r, k) + P2)
+// with L_r = 0 (and its minimum 0) outside the cost volume.  One 16-lane DPP row owns one line and walks it with the
+// previous L in registers (6 disparities per lane, D = 96): neighbour disparities come from row_shr/row_shl, the
+// per-pixel minimum from a 4-step quad_perm/row_mirror reduction -- no LDS, no barriers, loads prefetched kPathPF steps ahead.
+// Accumulation keeps the reference's saturation order S = sat16(sat16(L0 + L1 + L2 + L3) + L4):
+//   MODE 0: T  = L + kTOffset           (first of the three paths from the previous row; u16, wrap-safe)
+//   MODE 1: T += L                      (the other two)
+//   MODE 2: S1 = sat16(L + T - kTOffset)     (left -> right, in place)
+//   MODE 3: S2 = sat16(S1 + L)               (right -> left, in place)
+constexpr int kPathPF = 4;
+constexpr int kSent = 30000; // out-of-range disparity neighbour: any value with kSent + P1 > max(delta) behaves like SHRT_MAX
+struct alignas(4) U3 { uint32_t a, b, c; };
 
-__global__ __launch_bounds__(kVBlock) void sgbm_vertical_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* __restrict__ T,
-                                                              int16_t* Lrow, int16_t* mrow) {
-    const int b = blockIdx.x;
-    const int D = dm.D, W1 = dm.width1;
-    const size_t lstride = (size_t)3 * (W1 + 2) * D; // one buffer
-    int16_t* Lb = Lrow + (size_t)b * 2 * lstride;
-    int16_t* mb = mrow + (size_t)b * 2 * 3 * (W1 + 2);
-    // previous row of row 0 = zeros; borders of both buffers = zeros
-    for (size_t i = threadIdx.x; i < 2 * lstride; i += kVBlock) Lb[i] = 0;
-    for (int i = threadIdx.x; i < 2 * 3 * (W1 + 2); i += kVBlock) mb[i] = 0;
-    __syncthreads();
-    const int grp = threadIdx.x >> 5, gl = threadIdx.x & 31, ngrp = kVBlock >> 5; // 32-lane group per pixel, lane = 3 disparities
-    const int d0 = 3 * gl;
-    const bool live = d0 < D; // D <= 96
-    for (int y = 0; y < dm.h; ++y) {
-        const int cur = y & 1, prv = cur ^ 1;
-        const int16_t* Lp = Lb + (size_t)prv * lstride;
-        int16_t* Lc = Lb + (size_t)cur * lstride;
-        const int16_t* mp = mb + (size_t)prv * 3 * (W1 + 2);
-        int16_t* mc = mb + (size_t)cur * 3 * (W1 + 2);
-        const int16_t* Crow = C + ((size_t)b * dm.h + y) * W1 * D;
-        uint16_t* Trow = T + ((size_t)b * dm.h + y) * W1 * D;
-        for (int x0 = 0; x0 < W1; x0 += ngrp) { // uniform trip count (group shuffles)
-            const int x = x0 + grp;
-            const bool on = x < W1 && live;
-            int sum[3] = {0, 0, 0};
-            int c[3] = {0, 0, 0};
-            if (on) { c[0] = Crow[(size_t)x * D + d0]; c[1] = Crow[(size_t)x * D + d0 + 1]; c[2] = Crow[(size_t)x * D + d0 + 2]; }
+template <int CTRL>
+__device__ inline int dpp_mov(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false); }
+__device__ inline int row16_min(int v) {
+    v = min(v, dpp_mov<0xB1>(v, v));  // quad_perm [1,0,3,2]
+    v = min(v, dpp_mov<0x4E>(v, v));  // quad_perm [2,3,0,1]
+    v = min(v, dpp_mov<0x141>(v, v)); // row_half_mirror
+    v = min(v, dpp_mov<0x140>(v, v)); // row_mirror
+    return v;
+}
+__device__ inline int row16_max(int v) {
+    v = max(v, dpp_mov<0xB1>(v, v));
+    v = max(v, dpp_mov<0x4E>(v, v));
+    v = max(v, dpp_mov<0x141>(v, v));
+    v = max(v, dpp_mov<0x140>(v, v));
+    return v;
+}
+__device__ inline int lo16s(uint32_t v) { return (int)(int16_t)(v & 0xFFFFu); }
+__device__ inline int hi16s(uint32_t v) { return (int)v >> 16; }
+__device__ inline uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+
+template <int DX, int DY, int MODE>
+__global__ __launch_bounds__(64) void sgbm_path_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* T, int nlines) {
+    const int b = blockIdx.y;
+    const int line = blockIdx.x * 4 + (threadIdx.x >> 4), r = threadIdx.x & 15;
+    if (line >= nlines) return; // whole DPP row leaves
+    const int W1 = dm.width1, h = dm.h;
+    int x0, y0, len;
+    if (DY == 0) { y0 = line; x0 = DX > 0 ? 0 : W1 - 1; len = W1; }
+    else if (DX == 0) { x0 = line; y0 = 0; len = h; }
+    else {
+        if (line < W1) { x0 = line; y0 = 0; } else { x0 = DX > 0 ? 0 : W1 - 1; y0 = line - W1 + 1; }
+        len = min(DX > 0 ? W1 - x0 : x0 + 1, h - y0);
+    }
+    const ptrdiff_t step = ((ptrdiff_t)DY * W1 + DX) * 96;
+    const size_t first = (((size_t)b * h + y0) * W1 + x0) * 96 + 6 * r;
+    const int16_t* cp = C + first;
+    uint16_t* tp = T + first;
+    U3 cq[kPathPF], tq[kPathPF];
 #pragma unroll
-            for (int dir = 0; dir < 3; ++dir) {
-                const int xp = x + dir - 1; // dir 0: from (x-1, y-1), 1: (x, y-1), 2: (x+1, y-1)  [reference directions 1, 2, 3]
-                int lm = kSgbmMaxCost, l0 = 0, l1 = 0, l2 = 0, lp = kSgbmMaxCost, delta = 0;
-                if (on) {
-                    const int16_t* q = Lp + ((size_t)dir * (W1 + 2) + (xp + 1)) * D;
-                    delta = mp[dir * (W1 + 2) + xp + 1] + dm.P2;
-                    l0 = q[d0]; l1 = q[d0 + 1]; l2 = q[d0 + 2];
-                    lm = d0 > 0 ? (int)q[d0 - 1] : kSgbmMaxCost;
-                    lp = d0 + 3 < D ? (int)q[d0 + 3] : kSgbmMaxCost;
+    for (int k = 0; k < kPathPF; ++k) {
+        cq[k] = U3{0, 0, 0}; tq[k] = U3{0, 0, 0};
+        if (k < len) {
+            cq[k] = *(const U3*)(cp + k * step);
+            if (MODE != 0) tq[k] = *(const U3*)(tp + k * step);
+        }
+    }
+    int l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, minPrev = 0;
+    const int P1 = dm.P1, P2 = dm.P2;
+    for (int s = 0; s < len; s += kPathPF) {
+#pragma unroll
+        for (int k = 0; k < kPathPF; ++k) {
+            if (s + k < len) {
+                const U3 c = cq[k], t = tq[k];
+                if (s + k + kPathPF < len) {
+                    cq[k] = *(const U3*)(cp + (ptrdiff_t)(s + k + kPathPF) * step);
+                    if (MODE != 0) tq[k] = *(const U3*)(tp + (ptrdiff_t)(s + k + kPathPF) * step);
                 }
-                const int L0 = c[0] + min(min(l0, lm + dm.P1), min(l1 + dm.P1, delta)) - delta;
-                const int L1 = c[1] + min(min(l1, l0 + dm.P1), min(l2 + dm.P1, delta)) - delta;
-                const int L2 = c[2] + min(min(l2, l1 + dm.P1), min(lp + dm.P1, delta)) - delta;
-                int mn = on ? min(L0, min(L1, L2)) : kSgbmMaxCost;
-                for (int o = 16; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
-                if (on) {
-                    int16_t* w = Lc + ((size_t)dir * (W1 + 2) + (x + 1)) * D;
-                    w[d0] = (int16_t)L0; w[d0 + 1] = (int16_t)L1; w[d0 + 2] = (int16_t)L2;
-                    if (gl == 0) mc[dir * (W1 + 2) + x + 1] = (int16_t)mn;
-                    sum[0] += L0; sum[1] += L1; sum[2] += L2;
+                const int lm = dpp_mov<0x111>(kSent, l5); // row_shr:1 -- lane r-1's last disparity (d0 - 1)
+                const int lp = dpp_mov<0x101>(kSent, l0); // row_shl:1 -- lane r+1's first disparity (d5 + 1)
+                const int delta = minPrev + P2;
+                const int n0 = lo16s(c.a) - delta + min(min(l0, min(lm, l1) + P1), delta);
+                const int n1 = hi16s(c.a) - delta + min(min(l1, min(l0, l2) + P1), delta);
+                const int n2 = lo16s(c.b) - delta + min(min(l2, min(l1, l3) + P1), delta);
+                const int n3 = hi16s(c.b) - delta + min(min(l3, min(l2, l4) + P1), delta);
+                const int n4 = lo16s(c.c) - delta + min(min(l4, min(l3, l5) + P1), delta);
+                const int n5 = hi16s(c.c) - delta + min(min(l5, min(l4, lp) + P1), delta);
+                l0 = n0; l1 = n1; l2 = n2; l3 = n3; l4 = n4; l5 = n5;
+                minPrev = row16_min(min(min(min(n0, n1), min(n2, n3)), min(n4, n5)));
+                U3 o;
+                if (MODE == 0) {
+                    o.a = pack16(n0 + kTOffset, n1 + kTOffset); o.b = pack16(n2 + kTOffset, n3 + kTOffset); o.c = pack16(n4 + kTOffset, n5 + kTOffset);
+                } else if (MODE == 1) { // u16 wrap-around add: the true sum (+offset) always fits
+                    o.a = pack16((int)(t.a & 0xFFFFu) + n0, (int)(t.a >> 16) + n1);
+                    o.b = pack16((int)(t.b & 0xFFFFu) + n2, (int)(t.b >> 16) + n3);
+                    o.c = pack16((int)(t.c & 0xFFFFu) + n4, (int)(t.c >> 16) + n5);
+                } else if (MODE == 2) {
+                    o.a = pack16(sat16_dev((int)(t.a & 0xFFFFu) - kTOffset + n0), sat16_dev((int)(t.a >> 16) - kTOffset + n1));
+                    o.b = pack16(sat16_dev((int)(t.b & 0xFFFFu) - kTOffset + n2), sat16_dev((int)(t.b >> 16) - kTOffset + n3));
+                    o.c = pack16(sat16_dev((int)(t.c & 0xFFFFu) - kTOffset + n4), sat16_dev((int)(t.c >> 16) - kTOffset + n5));
+                } else {
+                    o.a = pack16(sat16_dev(lo16s(t.a) + n0), sat16_dev(hi16s(t.a) + n1));
+                    o.b = pack16(sat16_dev(lo16s(t.b) + n2), sat16_dev(hi16s(t.b) + n3));
+                    o.c = pack16(sat16_dev(lo16s(t.c) + n4), sat16_dev(hi16s(t.c) + n5));
                 }
-            }
-            if (on) {
-                Trow[(size_t)x * D + d0] = (uint16_t)(sum[0] + kTOffset);
-                Trow[(size_t)x * D + d0 + 1] = (uint16_t)(sum[1] + kTOffset);
-                Trow[(size_t)x * D + d0 + 2] = (uint16_t)(sum[2] + kTOffset);
+                *(U3*)(tp + (ptrdiff_t)(s + k) * step) = o;
             }
         }
-        __syncthreads(); // the row is complete (global writes of this workgroup) before the next row reads it
     }
 }
 
-// ------------------------------------------------------------------------------------------- horizontal paths + winner
-constexpr int kHBlock = 128; // lanes 0..95 own one disparity each
-
-__device__ inline int block_min2(int v, int* s_red) { // min over the 2 waves of the block, all threads get the result
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return min(s_red[0], s_red[1]);
+// ------------------------------------------------------------------------------------------- winner-take-all
+// One DPP row per pixel over S (6 disparities per lane): first minimum, uniqueness, parabola sub-pixel.  Writes
+// disp1 (fixed-point, INVALID where the uniqueness test fails) and win = (minS + 32768) << 8 | d (or -1).
+__global__ __launch_bounds__(256) void sgbm_wta_kernel(SgbmDims dm, const uint16_t* __restrict__ S, int16_t* __restrict__ disp1, int* __restrict__ win) {
+    const int b = blockIdx.y;
+    const size_t pixel = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int r = threadIdx.x & 15;
+    const size_t npx = (size_t)dm.h * dm.width1;
+    if (pixel >= npx) return;
+    const U3 v = *(const U3*)(S + ((size_t)b * npx + pixel) * 96 + 6 * r);
+    const int s0 = lo16s(v.a), s1 = hi16s(v.a), s2 = lo16s(v.b), s3 = hi16s(v.b), s4 = lo16s(v.c), s5 = hi16s(v.c);
+    const int d0 = 6 * r;
+    int best = ((s0 + 32768) << 8) | d0;
+    best = min(best, ((s1 + 32768) << 8) | (d0 + 1)); best = min(best, ((s2 + 32768) << 8) | (d0 + 2));
+    best = min(best, ((s3 + 32768) << 8) | (d0 + 3)); best = min(best, ((s4 + 32768) << 8) | (d0 + 4));
+    best = min(best, ((s5 + 32768) << 8) | (d0 + 5));
+    best = row16_min(best);
+    const int minS = (best >> 8) - 32768, bd = best & 0xFF;
+    const int u = 100 - dm.uniq, lim = minS * 100;
+    int bad = ((s0 * u < lim && abs(bd - d0) > 1) || (s1 * u < lim && abs(bd - d0 - 1) > 1) || (s2 * u < lim && abs(bd - d0 - 2) > 1) ||
+               (s3 * u < lim && abs(bd - d0 - 3) > 1) || (s4 * u < lim && abs(bd - d0 - 4) > 1) || (s5 * u < lim && abs(bd - d0 - 5) > 1)) ? 1 : 0;
+    bad = row16_max(bad);
+    const int sm_in = dpp_mov<0x111>(0, s5), sp_in = dpp_mov<0x101>(0, s0);
+    const int j = bd - d0;
+    if (j >= 0 && j < 6) { // the lane holding the winner
+        const int y = (int)(pixel / dm.width1), x = (int)(pixel - (size_t)y * dm.width1);
+        const size_t o = ((size_t)b * dm.h + y) * dm.w + x + dm.minX1;
+        int dd = -16, wv = -1;
+        if (!bad) {
+            wv = best;
+            if (0 < bd && bd < dm.D - 1) {
+                const int a[8] = {sm_in, s0, s1, s2, s3, s4, s5, sp_in};
+                int sm = a[0], sc = a[1], sp = a[2];
+#pragma unroll
+                for (int q = 1; q < 6; ++q) if (j == q) { sm = a[q]; sc = a[q + 1]; sp = a[q + 2]; }
+                const int denom2 = max(sm + sp - 2 * sc, 1);
+                dd = bd * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
+            } else dd = bd * 16;
+        }
+        disp1[o] = (int16_t)dd;
+        win[o] = wv;
+    }
 }
 
-__global__ __launch_bounds__(kHBlock) void sgbm_horizontal_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* __restrict__ T,
-                                                                 int16_t* __restrict__ disp) {
-    const int y = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const int D = dm.D, W1 = dm.width1;
-    const bool live = d < D;
-    const int16_t* Crow = C + ((size_t)b * dm.h + y) * W1 * D;
-    uint16_t* Trow = T + ((size_t)b * dm.h + y) * W1 * D; // in: L1+L2+L3 (+offset); out: S1 (as int16 bits)
-    __shared__ int16_t Lp[kHBlock + 2]; // Lp[d + 1], sentinels at d = -1 and d = D
-    __shared__ int16_t Srow[kHBlock];
-    __shared__ int s_red[2];
-    __shared__ int s_flag;
-    extern __shared__ int16_t dsm[]; // disp2[w], disp2cost[w], disp1[w]
-    int16_t* disp2 = dsm; int16_t* disp2cost = dsm + dm.w; int16_t* disp1 = dsm + 2 * dm.w;
+// ------------------------------------------------------------------------------------------- left-right check
+// disp2[x2] = disparity of the cheapest winner landing on right-image column x2 = x - d (the reference scans x from the
+// right with a strict ">", so among equal costs the largest x wins): packed-key atomicMin in LDS, then the consistency test.
+constexpr int kLrBlock = 256;
+__global__ __launch_bounds__(kLrBlock) void sgbm_lrcheck_kernel(SgbmDims dm, const int16_t* __restrict__ disp1, const int* __restrict__ win,
+                                                              int16_t* __restrict__ disp) {
+    const int y = blockIdx.x, b = blockIdx.y;
+    extern __shared__ int keys[]; // w
+    const size_t row = ((size_t)b * dm.h + y) * dm.w;
+    for (int i = threadIdx.x; i < dm.w; i += kLrBlock) keys[i] = 0x7FFFFFFF;
+    __syncthreads();
+    for (int x = dm.minX1 + threadIdx.x; x < dm.w; x += kLrBlock) {
+        const int wv = win[row + x];
+        if (wv >= 0) atomicMin(&keys[x - (wv & 0xFF)], ((wv >> 8) << 12) | (4095 - x));
+    }
+    __syncthreads();
     const int INVALID = -16;
-    for (int i = threadIdx.x; i < dm.w; i += kHBlock) { disp2[i] = (int16_t)INVALID; disp2cost[i] = (int16_t)kSgbmMaxCost; disp1[i] = (int16_t)INVALID; }
-    // ---- left -> right
-    Lp[threadIdx.x + 1] = 0;
-    if (threadIdx.x == 0) { Lp[0] = (int16_t)kSgbmMaxCost; Lp[D + 1] = (int16_t)kSgbmMaxCost; }
-    int minPrev = 0; // border: min L = 0
-    __syncthreads();
-    for (int x = 0; x < W1; ++x) {
-        const int delta = minPrev + dm.P2;
-        int L = kSgbmMaxCost;
-        if (live) {
-            const int a = Lp[d + 1], bm = Lp[d] + dm.P1, bp = Lp[d + 2] + dm.P1;
-            L = Crow[(size_t)x * D + d] + min(min(a, bm), min(bp, delta)) - delta;
-        }
-        minPrev = block_min2(L, s_red); // (barrier inside: every lane has read Lp)
-        if (live) {
-            Lp[d + 1] = (int16_t)L;
-            const int t = (int)Trow[(size_t)x * D + d] - kTOffset;
-            Trow[(size_t)x * D + d] = (uint16_t)(int16_t)sat16_dev(L + t); // S1
-        }
-        __syncthreads();
-    }
-    // ---- right -> left + winner-take-all
-    if (live) Lp[d + 1] = 0;
-    minPrev = 0;
-    __syncthreads();
-    for (int x = W1 - 1; x >= 0; --x) {
-        const int delta = minPrev + dm.P2;
-        int L = kSgbmMaxCost, S = kSgbmMaxCost;
-        if (live) {
-            const int a = Lp[d + 1], bm = Lp[d] + dm.P1, bp = Lp[d + 2] + dm.P1;
-            L = Crow[(size_t)x * D + d] + min(min(a, bm), min(bp, delta)) - delta;
-            S = sat16_dev((int)(int16_t)Trow[(size_t)x * D + d] + L);
-        }
-        minPrev = block_min2(L, s_red);
-        if (live) { Lp[d + 1] = (int16_t)L; Srow[d] = (int16_t)S; }
-        if (threadIdx.x == 0) s_flag = 0;
-        // first minimum of S over d: key = (S + 32768) << 8 | d
-        const int key = live ? (((S + 32768) << 8) | d) : 0x7FFFFFFF;
-        const int best = block_min2(key, s_red); // (barriers inside also publish Lp, Srow, s_flag)
-        const int minS = (best >> 8) - 32768, bestD = best & 0xFF;
-        if (live && S * (100 - dm.uniq) < minS * 100 && abs(bestD - d) > 1) s_flag = 1;
-        __syncthreads();
-        if (threadIdx.x == 0 && !s_flag) {
-            int dd = bestD;
-            const int x2 = x + dm.minX1 - dd;
-            if (disp2cost[x2] > minS) { disp2cost[x2] = (int16_t)minS; disp2[x2] = (int16_t)dd; }
-            if (0 < dd && dd < D - 1) {
-                const int sm = Srow[dd - 1], sp = Srow[dd + 1], s0 = Srow[dd];
-                const int denom2 = max(sm + sp - 2 * s0, 1);
-                dd = dd * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
-            } else dd *= 16;
-            disp1[x + dm.minX1] = (int16_t)dd;
-        }
-        __syncthreads();
-    }
-    // ---- left-right consistency
-    int16_t* out = disp + ((size_t)b * dm.h + y) * dm.w;
-    for (int x = threadIdx.x; x < dm.w; x += kHBlock) {
-        int d1 = disp1[x];
-        if (x >= dm.minX1 && d1 != INVALID) {
+    for (int x = threadIdx.x; x < dm.w; x += kLrBlock) {
+        int d1 = x >= dm.minX1 ? (int)disp1[row + x] : INVALID;
+        if (d1 != INVALID) {
             const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
             const int _x = x - _d, x_ = x - d_;
-            if (0 <= _x && _x < dm.w && disp2[_x] >= 0 && abs(disp2[_x] - _d) > dm.disp12 && 0 <= x_ && x_ < dm.w && disp2[x_] >= 0 &&
-                abs(disp2[x_] - d_) > dm.disp12)
-                d1 = INVALID;
+            bool f1 = false, f2 = false;
+            if (0 <= _x && _x < dm.w && keys[_x] != 0x7FFFFFFF) { const int d2 = (4095 - (keys[_x] & 4095)) - _x; f1 = abs(d2 - _d) > dm.disp12; }
+            if (0 <= x_ && x_ < dm.w && keys[x_] != 0x7FFFFFFF) { const int d2 = (4095 - (keys[x_] & 4095)) - x_; f2 = abs(d2 - d_) > dm.disp12; }
+            if (f1 && f2) d1 = INVALID;
         }
-        out[x] = (int16_t)d1;
+        disp[row + x] = (int16_t)d1;
     }
 }
 
@@ -301,38 +321,61 @@ __device__ inline void ccl_union(int* parent, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void sgbm_ccl_init_kernel(int n, int* __restrict__ parent, int* __restrict__ count) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < (size_t)n) { parent[i] = (int)(i % 0x7FFFFFFF); count[i] = 0; }
-}
-// parent indices are image-local (p = y*w + x) inside each image's slice
-__global__ __launch_bounds__(256) void sgbm_ccl_local_init_kernel(int w, int h, int* __restrict__ parent, int* __restrict__ count) {
-    const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (p >= w * h) return;
-    parent[(size_t)b * w * h + p] = p;
-    count[(size_t)b * w * h + p] = 0;
+// parent indices are image-local (p = y*w + x) inside each image's slice.  Rows are pre-merged: every pixel starts out
+// pointing at the first pixel of its horizontal run, so the atomic union-find only has to stitch runs across rows.
+constexpr int kCclBlock = 256;
+__global__ __launch_bounds__(kCclBlock) void sgbm_ccl_rows_kernel(int w, int h, int maxDiff, int newVal, const int16_t* __restrict__ disp,
+                                                                int* __restrict__ parent, int* __restrict__ count) {
+    const int y = blockIdx.x, b = blockIdx.y;
+    extern __shared__ int runs[]; // 2 x w (ping-pong max-scan of run starts)
+    const int16_t* row = disp + ((size_t)b * h + y) * w;
+    for (int x = threadIdx.x; x < w; x += kCclBlock) {
+        const int d = row[x];
+        const bool joined = x > 0 && d != newVal && row[x - 1] != newVal && abs(d - row[x - 1]) <= maxDiff;
+        runs[x] = joined ? 0 : x;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int o = 1; o < w; o <<= 1) {
+        for (int x = threadIdx.x; x < w; x += kCclBlock) runs[(cur ^ 1) * w + x] = x >= o ? max(runs[cur * w + x], runs[cur * w + x - o]) : runs[cur * w + x];
+        cur ^= 1;
+        __syncthreads();
+    }
+    const size_t base = (size_t)b * w * h + (size_t)y * w;
+    for (int x = threadIdx.x; x < w; x += kCclBlock) { parent[base + x] = y * w + runs[cur * w + x]; count[base + x] = 0; }
 }
 __global__ __launch_bounds__(256) void sgbm_ccl_union_kernel(int w, int h, int maxDiff, int newVal, const int16_t* __restrict__ disp,
                                                             int* __restrict__ parent) {
     const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (p >= w * h) return;
+    if (p >= w * (h - 1)) return;
     const int16_t* dsp = disp + (size_t)b * w * h;
-    int* par = parent + (size_t)b * w * h;
-    const int dp = dsp[p];
-    if (dp == newVal) return;
-    const int x = p % w, y = p / w;
-    if (x + 1 < w) { const int dq = dsp[p + 1]; if (dq != newVal && abs(dp - dq) <= maxDiff) ccl_union(par, p, p + 1); }
-    if (y + 1 < h) { const int dq = dsp[p + w]; if (dq != newVal && abs(dp - dq) <= maxDiff) ccl_union(par, p, p + w); }
+    const int dp = dsp[p], dq = dsp[p + w];
+    if (dp == newVal || dq == newVal || abs(dp - dq) > maxDiff) return;
+    const int x = p % w;
+    if (x > 0) { // the same two runs were already joined one pixel to the left
+        const int dpl = dsp[p - 1], dql = dsp[p + w - 1];
+        if (dpl != newVal && dql != newVal && abs(dp - dpl) <= maxDiff && abs(dq - dql) <= maxDiff && abs(dpl - dql) <= maxDiff) return;
+    }
+    ccl_union(parent + (size_t)b * w * h, p, p + w);
 }
-__global__ __launch_bounds__(256) void sgbm_ccl_count_kernel(int w, int h, int newVal, const int16_t* __restrict__ disp, int* __restrict__ parent,
-                                                            int* __restrict__ count) {
+// component sizes, one atomic per horizontal run (the last pixel of a run adds the run length to its root), and
+// flattening of the run starts so that every pixel is at most two hops from its root
+__global__ __launch_bounds__(256) void sgbm_ccl_count_kernel(int w, int h, int maxDiff, int newVal, const int16_t* __restrict__ disp,
+                                                            int* __restrict__ parent, int* __restrict__ count) {
     const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (p >= w * h) return;
-    if (disp[(size_t)b * w * h + p] == newVal) return;
+    const int16_t* dsp = disp + (size_t)b * w * h;
+    const int d = dsp[p];
+    if (d == newVal) return;
+    const int x = p % w;
+    const bool run_ends = x == w - 1 || dsp[p + 1] == newVal || abs(d - dsp[p + 1]) > maxDiff;
+    if (!run_ends) return;
     int* par = parent + (size_t)b * w * h;
-    const int r = ccl_find(par, p);
-    par[p] = r; // flatten (monotone: roots only ever decrease, r is final after the union kernel completed)
-    atomicAdd(&count[(size_t)b * w * h + r], 1);
+    const bool joined = x > 0 && dsp[p - 1] != newVal && abs(d - dsp[p - 1]) <= maxDiff;
+    const int start = joined ? par[p] : p; // non-start pixels keep pointing at their run start
+    const int r = ccl_find(par, start);
+    if (r != start) par[start] = r;
+    atomicAdd(&count[(size_t)b * w * h + r], p - start + 1);
 }
 __global__ __launch_bounds__(256) void sgbm_ccl_apply_kernel(int w, int h, int newVal, int maxSize, const int* __restrict__ parent,
                                                             const int* __restrict__ count, const int16_t* __restrict__ disp,
@@ -341,7 +384,7 @@ __global__ __launch_bounds__(256) void sgbm_ccl_apply_kernel(int w, int h, int n
     if (p >= w * h) return;
     const size_t g = (size_t)b * w * h + p;
     int d = disp[g];
-    if (d != newVal && count[(size_t)b * w * h + parent[g]] <= maxSize) d = newVal;
+    if (d != newVal && count[(size_t)b * w * h + ccl_find(parent + (size_t)b * w * h, p)] <= maxSize) d = newVal;
     if (out_i16) out_i16[g] = (int16_t)d;
     if (out_f32) out_f32[g] = (float)d * 0.0625f; // convertTo(CV_32F, 1/16): exact
 }
@@ -353,7 +396,7 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     SgbmDims dm;
     dm.w = w; dm.h = h; dm.D = 96; dm.minX1 = 96; dm.width1 = w - 96; dm.P1 = 8 * 9 * 9; dm.P2 = 32 * 9 * 9; dm.SW2 = 4; dm.SH2 = 4; dm.uniq = 10;
     dm.disp12 = 1; dm.ftzero = 63; dm.pitch = pitch; dm.img_bytes = img_bytes; // visual_odometry.cpp:163-164
-    if (dm.width1 <= 0 || h <= 2 * dm.SH2 + 1) { set_error("image too small for 96 disparities / 9x9 blocks"); return VSLAM_ERR_ARG; }
+    if (dm.width1 <= 0 || h <= 2 * dm.SH2 + 1 || w > 4096) { set_error("image size unsupported (need 96 < w <= 4096, h > 9)"); return VSLAM_ERR_ARG; }
     const size_t vol = (size_t)h * dm.width1 * dm.D, npix = (size_t)w * h;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t need = 0;
@@ -362,8 +405,7 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     const size_t o_hs = need; need += al((size_t)B * vol * 2);
     const size_t o_C = need; need += al((size_t)B * vol * 2);
     const size_t o_T = o_hs; // hsum is dead once C exists: T reuses its storage
-    const size_t o_L = need; need += al((size_t)B * 2 * 3 * (dm.width1 + 2) * dm.D * 2);
-    const size_t o_m = need; need += al((size_t)B * 2 * 3 * (dm.width1 + 2) * 2);
+    const size_t o_win = need; need += al((size_t)B * npix * 4);
     const size_t o_d0 = need; need += al((size_t)B * npix * 2);
     const size_t o_d1 = need; need += al((size_t)B * npix * 2);
     const size_t o_par = need; need += al((size_t)B * npix * 4);
@@ -377,23 +419,32 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     }
     uint8_t* base = *scratch;
     uint8_t* pre = base + o_pre; uint8_t* pix = base + o_pix; int16_t* hsum = (int16_t*)(base + o_hs); int16_t* C = (int16_t*)(base + o_C);
-    uint16_t* T = (uint16_t*)(base + o_T); int16_t* Lrow = (int16_t*)(base + o_L); int16_t* mrow = (int16_t*)(base + o_m);
+    uint16_t* T = (uint16_t*)(base + o_T); int* win = (int*)(base + o_win);
     int16_t* d0 = (int16_t*)(base + o_d0); int16_t* d1 = (int16_t*)(base + o_d1); int* par = (int*)(base + o_par); int* cnt = (int*)(base + o_cnt);
     const int vblocks = (dm.width1 * dm.D + 255) / 256;
     { ProfScope p(stream, "sgbm_prefilter_kernel"); hipLaunchKernelGGL(sgbm_prefilter_kernel, dim3((w + 255) / 256, h, 2 * B), dim3(256), 0, stream, dm, d_left, d_right, pre); }
     { ProfScope p(stream, "sgbm_pixcost_kernel"); hipLaunchKernelGGL(sgbm_pixcost_kernel, dim3(vblocks, h, B), dim3(256), 0, stream, dm, pre, pix); }
     { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3(vblocks, h, B), dim3(256), 0, stream, dm, pix, hsum); }
     { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3(vblocks, h, B), dim3(256), 0, stream, dm, hsum, C); }
-    { ProfScope p(stream, "sgbm_vertical_kernel"); hipLaunchKernelGGL(sgbm_vertical_kernel, dim3(B), dim3(kVBlock), 0, stream, dm, C, T, Lrow, mrow); }
-    { ProfScope p(stream, "sgbm_horizontal_kernel"); hipLaunchKernelGGL(sgbm_horizontal_kernel, dim3(h, B), dim3(kHBlock), (size_t)3 * w * sizeof(int16_t), stream, dm, C, T, d0); }
+    { ProfScope p(stream, "sgbm_path_kernel", 5);
+      const int nv = dm.width1, nd = dm.width1 + h - 1;
+      hipLaunchKernelGGL((sgbm_path_kernel<0, 1, 0>), dim3((nv + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nv);
+      hipLaunchKernelGGL((sgbm_path_kernel<1, 1, 1>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd);
+      hipLaunchKernelGGL((sgbm_path_kernel<-1, 1, 1>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd);
+      hipLaunchKernelGGL((sgbm_path_kernel<1, 0, 2>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h);
+      hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 3>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h); }
+    { ProfScope p(stream, "sgbm_wta_kernel");
+      hipLaunchKernelGGL(sgbm_wta_kernel, dim3((unsigned)(((size_t)h * dm.width1 + 15) / 16), B), dim3(256), 0, stream, dm, T, d1, win); }
+    { ProfScope p(stream, "sgbm_lrcheck_kernel");
+      hipLaunchKernelGGL(sgbm_lrcheck_kernel, dim3(h, B), dim3(kLrBlock), (size_t)w * sizeof(int), stream, dm, d1, win, d0); }
     if (d_disp_raw) VS_HIP(hipMemcpyAsync(d_disp_raw, d0, (size_t)B * npix * 2, hipMemcpyDeviceToDevice, stream));
     { ProfScope p(stream, "sgbm_median3_kernel"); hipLaunchKernelGGL(sgbm_median3_kernel, dim3((w + 255) / 256, h, B), dim3(256), 0, stream, w, h, d0, d1); }
     const int pblocks = (int)((npix + 255) / 256);
     const int newVal = -16, maxDiff = 16 * 32, maxSize = 100; // speckleWindowSize 100, speckleRange 32
     { ProfScope p(stream, "sgbm_ccl_kernels", 4);
-      hipLaunchKernelGGL(sgbm_ccl_local_init_kernel, dim3(pblocks, B), dim3(256), 0, stream, w, h, par, cnt);
+      hipLaunchKernelGGL(sgbm_ccl_rows_kernel, dim3(h, B), dim3(kCclBlock), (size_t)2 * w * sizeof(int), stream, w, h, maxDiff, newVal, d1, par, cnt);
       hipLaunchKernelGGL(sgbm_ccl_union_kernel, dim3(pblocks, B), dim3(256), 0, stream, w, h, maxDiff, newVal, d1, par);
-      hipLaunchKernelGGL(sgbm_ccl_count_kernel, dim3(pblocks, B), dim3(256), 0, stream, w, h, newVal, d1, par, cnt);
+      hipLaunchKernelGGL(sgbm_ccl_count_kernel, dim3(pblocks, B), dim3(256), 0, stream, w, h, maxDiff, newVal, d1, par, cnt);
       hipLaunchKernelGGL(sgbm_ccl_apply_kernel, dim3(pblocks, B), dim3(256), 0, stream, w, h, newVal, maxSize, par, cnt, d1, d_disp_f32, d_disp_i16); }
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
