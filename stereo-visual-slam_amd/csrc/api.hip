@@ -150,8 +150,8 @@ const char* vslam_last_error(void) { return g_err; }
 const char* vslam_version(void) { return "vslam_hip 0.1 (gfx950)"; }
 const char* vslam_kernel_names(void) {
     return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_blur_kernel orb_describe_kernel match_train_nearest_kernel "
-           "match_finalize_kernel sgbm_prefilter_kernel sgbm_pixcost_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_vertical_kernel "
-           "sgbm_horizontal_kernel sgbm_median3_kernel sgbm_ccl_union_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel";
+           "match_finalize_kernel sgbm_prefilter_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel sgbm_lrcheck_kernel "
+           "sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel sgbm_ccl_apply_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel";
 }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {

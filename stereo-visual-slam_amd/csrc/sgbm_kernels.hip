@@ -34,78 +34,116 @@ constexpr int kTOffset = 8192; // L1+L2+L3 lies in [-7776, 46k]: stored as u16 w
 __device__ inline int sat16_dev(int v) { return min(max(v, -32768), 32767); }
 
 // ------------------------------------------------------------------------------------------- prefilter
-// pre[(b*2+side)][y][ch][x]: ch 0 = clipped x-Sobel + ftzero, ch 1 = raw (ends replaced by ftzero, like the reference buffers)
+// pre[(b*2+side)][y][6][w]: planes {val, lo, hi} of channel 0 (x-Sobel clipped to [0, 2*ftzero]) and channel 1 (raw intensity;
+// both channels have their two end pixels replaced by ftzero, like the reference row buffers).  lo / hi are the min / max
+// of the pixel and its two half-pixel interpolants: the Birchfield-Tomasi operands of calcPixelCostBT, shared by both views.
+__device__ inline void prefilter_px(const uint8_t* row, int pitch, int w, int h, int x, int y, int ftzero, int& g, int& r) {
+    g = ftzero; r = ftzero;
+    if (x >= 1 && x < w - 1) {
+        const int n = y > 0 ? -pitch : 0, s = y < h - 1 ? pitch : 0;
+        const int v = (row[x + 1] - row[x - 1]) * 2 + row[x + n + 1] - row[x + n - 1] + row[x + s + 1] - row[x + s - 1];
+        g = min(max(v, -ftzero), ftzero) + ftzero;
+        r = row[x];
+    }
+}
 __global__ __launch_bounds__(256) void sgbm_prefilter_kernel(SgbmDims dm, const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                             uint8_t* __restrict__ pre) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, ii = blockIdx.z;
     if (x >= dm.w) return;
     const int b = ii >> 1, side = ii & 1;
-    const uint8_t* img = (side ? right : left) + (size_t)b * dm.img_bytes;
-    const uint8_t* row = img + (size_t)y * dm.pitch;
-    uint8_t* out = pre + (((size_t)ii * dm.h + y) * 2) * dm.w;
-    int g = dm.ftzero, r = dm.ftzero;
-    if (x >= 1 && x < dm.w - 1) {
-        const int n = y > 0 ? -dm.pitch : 0, s = y < dm.h - 1 ? dm.pitch : 0;
-        const int v = (row[x + 1] - row[x - 1]) * 2 + row[x + n + 1] - row[x + n - 1] + row[x + s + 1] - row[x + s - 1];
-        g = min(max(v, -dm.ftzero), dm.ftzero) + dm.ftzero;
-        r = row[x];
-    }
-    out[x] = (uint8_t)g;
-    out[dm.w + x] = (uint8_t)r;
+    const uint8_t* row = (side ? right : left) + (size_t)b * dm.img_bytes + (size_t)y * dm.pitch;
+    uint8_t* out = pre + (((size_t)ii * dm.h + y) * 6) * dm.w;
+    int g, r, gl = 0, rl = 0, gr = 0, rr = 0;
+    prefilter_px(row, dm.pitch, dm.w, dm.h, x, y, dm.ftzero, g, r);
+    if (x > 0) prefilter_px(row, dm.pitch, dm.w, dm.h, x - 1, y, dm.ftzero, gl, rl);
+    if (x < dm.w - 1) prefilter_px(row, dm.pitch, dm.w, dm.h, x + 1, y, dm.ftzero, gr, rr);
+    const int ga = x > 0 ? (g + gl) >> 1 : g, gb = x < dm.w - 1 ? (g + gr) >> 1 : g;
+    const int ra = x > 0 ? (r + rl) >> 1 : r, rb = x < dm.w - 1 ? (r + rr) >> 1 : r;
+    out[x] = (uint8_t)g; out[dm.w + x] = (uint8_t)min(min(ga, gb), g); out[2 * dm.w + x] = (uint8_t)max(max(ga, gb), g);
+    out[3 * dm.w + x] = (uint8_t)r; out[4 * dm.w + x] = (uint8_t)min(min(ra, rb), r); out[5 * dm.w + x] = (uint8_t)max(max(ra, rb), r);
 }
 
-// ------------------------------------------------------------------------------------------- pixel cost
-__device__ inline void halfpix_minmax(const uint8_t* p, int x, int w, int& v, int& lo, int& hi) {
-    v = p[x];
-    const int vl = x > 0 ? (v + p[x - 1]) >> 1 : v;
-    const int vr = x < w - 1 ? (v + p[x + 1]) >> 1 : v;
-    lo = min(min(vl, vr), v);
-    hi = max(max(vl, vr), v);
-}
+// ------------------------------------------------------------------------------------------- block cost, horizontal part
+// One workgroup = one image row x kHsSeg pixels.  Phase 1 evaluates the Birchfield-Tomasi pixel cost (both channels)
+// once per (pixel, disparity) of the segment plus a 4-pixel halo (columns clamped to the volume, like the reference's
+// box sums) into an LDS tile, four disparities per work item through unaligned dword loads of the right-view planes.
+// Phase 2 forms the 9-tap horizontal sums, 8 disparities per work item (ds_read_b64, byte lanes accumulated as two
+// packed u16 pairs), and stores them as int16.
+constexpr int kHsSeg = 64, kHsBlock = 256;
+__device__ inline uint32_t ld_u32_unaligned(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
-__global__ __launch_bounds__(256) void sgbm_pixcost_kernel(SgbmDims dm, const uint8_t* __restrict__ pre, uint8_t* __restrict__ pix) {
-    const int b = blockIdx.z, y = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x; // (j, d), d fastest
-    if (idx >= dm.width1 * dm.D) return;
-    const int j = idx / dm.D, d = idx - j * dm.D;
-    const int x = dm.minX1 + j, xr = x - d;
-    const uint8_t* L = pre + (((size_t)(2 * b) * dm.h + y) * 2) * dm.w;
-    const uint8_t* R = pre + (((size_t)(2 * b + 1) * dm.h + y) * 2) * dm.w;
-    int cost = 0;
+__global__ __launch_bounds__(kHsBlock) void sgbm_hsum_kernel(SgbmDims dm, const uint8_t* __restrict__ pre, int16_t* __restrict__ hsum) {
+    const int b = blockIdx.z, y = blockIdx.y, j0 = blockIdx.x * kHsSeg;
+    __shared__ alignas(16) uint8_t tile[(kHsSeg + 8) * 96];
+    const uint8_t* L = pre + (((size_t)(2 * b) * dm.h + y) * 6) * dm.w;
+    const uint8_t* R = pre + (((size_t)(2 * b + 1) * dm.h + y) * 6) * dm.w;
+    const int W1 = dm.width1, w = dm.w;
+    for (int it = threadIdx.x; it < (kHsSeg + 8) * 24; it += kHsBlock) {
+        const int t = it / 24, q = it - t * 24, d = 4 * q;
+        const int jj = min(max(j0 - 4 + t, 0), W1 - 1), x = dm.minX1 + jj;
+        uint32_t out = 0;
+        uint32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        int u, u0, u1, v, v0, v1;
-        halfpix_minmax(L + c * dm.w, x, dm.w, u, u0, u1);
-        halfpix_minmax(R + c * dm.w, xr, dm.w, v, v0, v1);
-        const int c0 = max(max(0, u - v1), v0 - u);
-        const int c1 = max(max(0, v - u1), u0 - v);
-        cost += min(c0, c1) >> (c == 0 ? 0 : 2);
+        for (int c = 0; c < 2; ++c) {
+            const uint8_t* lp = L + 3 * c * w; const uint8_t* rp = R + 3 * c * w;
+            const int u = lp[x], u0 = lp[w + x], u1 = lp[2 * w + x];
+            const uint32_t vv = ld_u32_unaligned(rp + x - d - 3), v0v = ld_u32_unaligned(rp + w + x - d - 3), v1v = ld_u32_unaligned(rp + 2 * w + x - d - 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { // disparity d + i <-> byte 3 - i
+                const int sh = 8 * (3 - i);
+                const int v = (vv >> sh) & 255, v0 = (v0v >> sh) & 255, v1 = (v1v >> sh) & 255;
+                const int c0 = max(max(0, u - v1), v0 - u), c1 = max(max(0, v - u1), u0 - v);
+                acc[i] += (uint32_t)(min(c0, c1) >> (c == 0 ? 0 : 2));
+            }
+        }
+        out = acc[0] | (acc[1] << 8) | (acc[2] << 16) | (acc[3] << 24); // each <= 126 + 63
+        *(uint32_t*)(tile + t * 96 + d) = out;
     }
-    pix[((size_t)b * dm.h + y) * dm.width1 * dm.D + idx] = (uint8_t)cost;
+    __syncthreads();
+    for (int it = threadIdx.x; it < kHsSeg * 12; it += kHsBlock) {
+        const int t = it / 12, g = it - t * 12;
+        if (j0 + t >= W1) continue;
+        uint32_t e0 = 0, o0 = 0, e1 = 0, o1 = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const uint2 v = *(const uint2*)(tile + (t + i) * 96 + 8 * g);
+            e0 += v.x & 0x00FF00FFu; o0 += (v.x >> 8) & 0x00FF00FFu;
+            e1 += v.y & 0x00FF00FFu; o1 += (v.y >> 8) & 0x00FF00FFu;
+        }
+        uint4 o;
+        o.x = (e0 & 0xFFFFu) | (o0 << 16); o.y = (e0 >> 16) | (o0 & 0xFFFF0000u);
+        o.z = (e1 & 0xFFFFu) | (o1 << 16); o.w = (e1 >> 16) | (o1 & 0xFFFF0000u);
+        *(uint4*)(hsum + (((size_t)b * dm.h + y) * W1 + j0 + t) * 96 + 8 * g) = o;
+    }
 }
 
-__global__ __launch_bounds__(256) void sgbm_hsum_kernel(SgbmDims dm, const uint8_t* __restrict__ pix, int16_t* __restrict__ hsum) {
-    const int b = blockIdx.z, y = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= dm.width1 * dm.D) return;
-    const int j = idx / dm.D, d = idx - j * dm.D;
-    const uint8_t* row = pix + ((size_t)b * dm.h + y) * dm.width1 * dm.D;
-    int s = 0;
-    for (int i = -dm.SW2; i <= dm.SW2; ++i) s += row[(size_t)min(max(j + i, 0), dm.width1 - 1) * dm.D + d];
-    hsum[((size_t)b * dm.h + y) * dm.width1 * dm.D + idx] = (int16_t)s;
-}
+// ------------------------------------------------------------------------------------------- block cost, vertical part
+// C(y) = sum of hsum over rows y-4..y+4 (rows above the image replicate row 0); the reference stops sliding SH2 rows
+// above the bottom (the last rows repeat C(h-1-SH2)) and never updates column 0 after the first row.  Each work item owns
+// (column, 8 disparities) and slides down a chunk of rows with packed int16 adds: 2 loads + 1 store per row.
+typedef short short2v __attribute__((ext_vector_type(2)));
+struct alignas(16) S8 { short2v a, b, c, d; };
+__device__ inline S8 s8_add(S8 p, S8 q) { return S8{p.a + q.a, p.b + q.b, p.c + q.c, p.d + q.d}; }
+__device__ inline S8 s8_sub(S8 p, S8 q) { return S8{p.a - q.a, p.b - q.b, p.c - q.c, p.d - q.d}; }
+constexpr int kVsChunk = 47;
 
 __global__ __launch_bounds__(256) void sgbm_vsum_kernel(SgbmDims dm, const int16_t* __restrict__ hsum, int16_t* __restrict__ C) {
-    const int b = blockIdx.z, y = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= dm.width1 * dm.D) return;
-    const int j = idx / dm.D;
-    // the reference never updates column 0 after the first row and stops sliding SH2 rows above the bottom
-    const int yy = j == 0 ? 0 : min(y, dm.h - 1 - dm.SH2);
-    const int16_t* base = hsum + (size_t)b * dm.h * dm.width1 * dm.D + idx;
-    int s = 0;
-    for (int k = yy - dm.SH2; k <= yy + dm.SH2; ++k) s += base[(size_t)min(max(k, 0), dm.h - 1) * dm.width1 * dm.D];
-    C[((size_t)b * dm.h + y) * dm.width1 * dm.D + idx] = (int16_t)s;
+    const int b = blockIdx.z, ya = blockIdx.y * kVsChunk, yb = min(ya + kVsChunk, dm.h);
+    const int it = blockIdx.x * 256 + threadIdx.x; // (j, g): 8 disparities
+    if (it >= dm.width1 * 12) return;
+    const int j = it / 12;
+    const size_t rs = (size_t)dm.width1 * 96; // row stride (elements)
+    const int16_t* hp = hsum + (size_t)b * dm.h * rs + (size_t)it * 8;
+    int16_t* cp = C + (size_t)b * dm.h * rs + (size_t)it * 8;
+    const int ylast = j == 0 ? 0 : dm.h - 1 - dm.SH2; // last row whose window is evaluated
+    const int yy = min(ya, ylast);
+    S8 acc = *(const S8*)(hp + (size_t)max(yy - dm.SH2, 0) * rs);
+    for (int k = yy - dm.SH2 + 1; k <= yy + dm.SH2; ++k) acc = s8_add(acc, *(const S8*)(hp + (size_t)max(k, 0) * rs));
+#pragma unroll 4
+    for (int y = ya; y < yb; ++y) {
+        *(S8*)(cp + (size_t)y * rs) = acc;
+        if (y + 1 <= ylast) acc = s8_sub(s8_add(acc, *(const S8*)(hp + (size_t)(y + 1 + dm.SH2) * rs)), *(const S8*)(hp + (size_t)max(y - dm.SH2, 0) * rs));
+    }
 }
 
 // ------------------------------------------------------------------------------------------- path aggregation
@@ -118,8 +156,9 @@ __global__ __launch_bounds__(256) void sgbm_vsum_kernel(SgbmDims dm, const int16
 //   MODE 0: T  = L + kTOffset           (first of the three paths from the previous row; u16, wrap-safe)
 //   MODE 1: T += L                      (the other two)
 //   MODE 2: S1 = sat16(L + T - kTOffset)     (left -> right, in place)
-//   MODE 3: S2 = sat16(S1 + L)               (right -> left, in place)
-constexpr int kPathPF = 4;
+//   MODE 3: S  = sat16(S1 + L)               (right -> left, in place; winner-take-all in its own kernel: small batches,
+//                                              where the extra instructions on the sequential chain cost more than the traffic)
+//   MODE 4: same, but S is consumed on the spot by the winner-take-all and never stored (large batches, HBM-bound)
 constexpr int kSent = 30000; // out-of-range disparity neighbour: any value with kSent + P1 > max(delta) behaves like SHRT_MAX
 struct alignas(4) U3 { uint32_t a, b, c; };
 
@@ -143,8 +182,36 @@ __device__ inline int lo16s(uint32_t v) { return (int)(int16_t)(v & 0xFFFFu); }
 __device__ inline int hi16s(uint32_t v) { return (int)v >> 16; }
 __device__ inline uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 
-template <int DX, int DY, int MODE>
-__global__ __launch_bounds__(64) void sgbm_path_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* T, int nlines) {
+// winner-take-all for one pixel held by a DPP row (6 disparities per lane): first minimum and the uniqueness test.
+// The lane holding the winner writes rec = {(minS + 32768) << 8 | d  (or -1 when not unique), S[d-1] | S[d] << 16, S[d+1]};
+// the parabola sub-pixel step (an integer division) is left to the left-right kernel, off this sequential chain.
+__device__ inline void wta_row16(const SgbmDims& dm, int s0, int s1, int s2, int s3, int s4, int s5, int r, size_t out_index,
+                                 int4* __restrict__ rec, bool active) {
+    const int d0 = 6 * r;
+    int best = ((s0 + 32768) << 8) | d0;
+    best = min(best, ((s1 + 32768) << 8) | (d0 + 1)); best = min(best, ((s2 + 32768) << 8) | (d0 + 2));
+    best = min(best, ((s3 + 32768) << 8) | (d0 + 3)); best = min(best, ((s4 + 32768) << 8) | (d0 + 4));
+    best = min(best, ((s5 + 32768) << 8) | (d0 + 5));
+    best = row16_min(best);
+    const int minS = (best >> 8) - 32768, bd = best & 0xFF;
+    const int u = 100 - dm.uniq, lim = __mul24(minS, 100); // |S| < 2^15: 24-bit multiplies are exact (and full rate)
+    int bad = ((__mul24(s0, u) < lim && abs(bd - d0) > 1) || (__mul24(s1, u) < lim && abs(bd - d0 - 1) > 1) ||
+               (__mul24(s2, u) < lim && abs(bd - d0 - 2) > 1) || (__mul24(s3, u) < lim && abs(bd - d0 - 3) > 1) ||
+               (__mul24(s4, u) < lim && abs(bd - d0 - 4) > 1) || (__mul24(s5, u) < lim && abs(bd - d0 - 5) > 1)) ? 1 : 0;
+    bad = row16_max(bad);
+    const int sm_in = dpp_mov<0x111>(0, s5), sp_in = dpp_mov<0x101>(0, s0);
+    const int j = bd - d0;
+    if (active && j >= 0 && j < 6) { // the lane holding the winner
+        const int a[8] = {sm_in, s0, s1, s2, s3, s4, s5, sp_in};
+        int sm = a[0], sc = a[1], sp = a[2];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) if (j == q) { sm = a[q]; sc = a[q + 1]; sp = a[q + 2]; }
+        rec[out_index] = make_int4(bad ? -1 : best, (int)pack16(sm, sc), sp, 0);
+    }
+}
+
+template <int DX, int DY, int MODE, int kPathPF>
+__global__ __launch_bounds__(64) void sgbm_path_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* T, int nlines, int4* __restrict__ rec) {
     const int b = blockIdx.y;
     const int line = blockIdx.x * 4 + (threadIdx.x >> 4), r = threadIdx.x & 15;
     if (line >= nlines) return; // whole DPP row leaves
@@ -160,25 +227,25 @@ __global__ __launch_bounds__(64) void sgbm_path_kernel(SgbmDims dm, const int16_
     const size_t first = (((size_t)b * h + y0) * W1 + x0) * 96 + 6 * r;
     const int16_t* cp = C + first;
     uint16_t* tp = T + first;
+    // prefetch queue: loads are unconditional (indices clamped to the line) so that no wait is forced at the load site
     U3 cq[kPathPF], tq[kPathPF];
 #pragma unroll
     for (int k = 0; k < kPathPF; ++k) {
-        cq[k] = U3{0, 0, 0}; tq[k] = U3{0, 0, 0};
-        if (k < len) {
-            cq[k] = *(const U3*)(cp + k * step);
-            if (MODE != 0) tq[k] = *(const U3*)(tp + k * step);
-        }
+        const ptrdiff_t o = (ptrdiff_t)min(k, len - 1) * step;
+        cq[k] = *(const U3*)(cp + o);
+        tq[k] = MODE != 0 ? *(const U3*)(tp + o) : U3{0, 0, 0};
     }
     int l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, minPrev = 0;
     const int P1 = dm.P1, P2 = dm.P2;
     for (int s = 0; s < len; s += kPathPF) {
 #pragma unroll
         for (int k = 0; k < kPathPF; ++k) {
-            if (s + k < len) {
+            {
                 const U3 c = cq[k], t = tq[k];
-                if (s + k + kPathPF < len) {
-                    cq[k] = *(const U3*)(cp + (ptrdiff_t)(s + k + kPathPF) * step);
-                    if (MODE != 0) tq[k] = *(const U3*)(tp + (ptrdiff_t)(s + k + kPathPF) * step);
+                {
+                    const ptrdiff_t o = (ptrdiff_t)min(s + k + kPathPF, len - 1) * step;
+                    cq[k] = *(const U3*)(cp + o);
+                    if (MODE != 0) tq[k] = *(const U3*)(tp + o);
                 }
                 const int lm = dpp_mov<0x111>(kSent, l5); // row_shr:1 -- lane r-1's last disparity (d0 - 1)
                 const int lp = dpp_mov<0x101>(kSent, l0); // row_shl:1 -- lane r+1's first disparity (d5 + 1)
@@ -203,79 +270,61 @@ __global__ __launch_bounds__(64) void sgbm_path_kernel(SgbmDims dm, const int16_
                     o.b = pack16(sat16_dev((int)(t.b & 0xFFFFu) - kTOffset + n2), sat16_dev((int)(t.b >> 16) - kTOffset + n3));
                     o.c = pack16(sat16_dev((int)(t.c & 0xFFFFu) - kTOffset + n4), sat16_dev((int)(t.c >> 16) - kTOffset + n5));
                 } else {
-                    o.a = pack16(sat16_dev(lo16s(t.a) + n0), sat16_dev(hi16s(t.a) + n1));
-                    o.b = pack16(sat16_dev(lo16s(t.b) + n2), sat16_dev(hi16s(t.b) + n3));
-                    o.c = pack16(sat16_dev(lo16s(t.c) + n4), sat16_dev(hi16s(t.c) + n5));
+                    const int f0 = sat16_dev(lo16s(t.a) + n0), f1 = sat16_dev(hi16s(t.a) + n1), f2 = sat16_dev(lo16s(t.b) + n2);
+                    const int f3 = sat16_dev(hi16s(t.b) + n3), f4 = sat16_dev(lo16s(t.c) + n4), f5 = sat16_dev(hi16s(t.c) + n5);
+                    if (MODE == 3) { o.a = pack16(f0, f1); o.b = pack16(f2, f3); o.c = pack16(f4, f5); }
+                    else // last path: S is complete -- pick the winner here instead of storing it
+                        wta_row16(dm, f0, f1, f2, f3, f4, f5, r, ((size_t)b * h + y0) * dm.w + dm.minX1 + x0 + (s + k) * DX, rec, s + k < len);
                 }
-                *(U3*)(tp + (ptrdiff_t)(s + k) * step) = o;
+                if (MODE != 4 && s + k < len) *(U3*)(tp + (ptrdiff_t)(s + k) * step) = o;
             }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------- winner-take-all
-// One DPP row per pixel over S (6 disparities per lane): first minimum, uniqueness, parabola sub-pixel.  Writes
-// disp1 (fixed-point, INVALID where the uniqueness test fails) and win = (minS + 32768) << 8 | d (or -1).
-__global__ __launch_bounds__(256) void sgbm_wta_kernel(SgbmDims dm, const uint16_t* __restrict__ S, int16_t* __restrict__ disp1, int* __restrict__ win) {
+// stand-alone winner-take-all over a stored S volume (MODE 3): one DPP row per pixel
+__global__ __launch_bounds__(256) void sgbm_wta_kernel(SgbmDims dm, const uint16_t* __restrict__ S, int4* __restrict__ rec) {
     const int b = blockIdx.y;
     const size_t pixel = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int r = threadIdx.x & 15;
     const size_t npx = (size_t)dm.h * dm.width1;
     if (pixel >= npx) return;
     const U3 v = *(const U3*)(S + ((size_t)b * npx + pixel) * 96 + 6 * r);
-    const int s0 = lo16s(v.a), s1 = hi16s(v.a), s2 = lo16s(v.b), s3 = hi16s(v.b), s4 = lo16s(v.c), s5 = hi16s(v.c);
-    const int d0 = 6 * r;
-    int best = ((s0 + 32768) << 8) | d0;
-    best = min(best, ((s1 + 32768) << 8) | (d0 + 1)); best = min(best, ((s2 + 32768) << 8) | (d0 + 2));
-    best = min(best, ((s3 + 32768) << 8) | (d0 + 3)); best = min(best, ((s4 + 32768) << 8) | (d0 + 4));
-    best = min(best, ((s5 + 32768) << 8) | (d0 + 5));
-    best = row16_min(best);
-    const int minS = (best >> 8) - 32768, bd = best & 0xFF;
-    const int u = 100 - dm.uniq, lim = minS * 100;
-    int bad = ((s0 * u < lim && abs(bd - d0) > 1) || (s1 * u < lim && abs(bd - d0 - 1) > 1) || (s2 * u < lim && abs(bd - d0 - 2) > 1) ||
-               (s3 * u < lim && abs(bd - d0 - 3) > 1) || (s4 * u < lim && abs(bd - d0 - 4) > 1) || (s5 * u < lim && abs(bd - d0 - 5) > 1)) ? 1 : 0;
-    bad = row16_max(bad);
-    const int sm_in = dpp_mov<0x111>(0, s5), sp_in = dpp_mov<0x101>(0, s0);
-    const int j = bd - d0;
-    if (j >= 0 && j < 6) { // the lane holding the winner
-        const int y = (int)(pixel / dm.width1), x = (int)(pixel - (size_t)y * dm.width1);
-        const size_t o = ((size_t)b * dm.h + y) * dm.w + x + dm.minX1;
-        int dd = -16, wv = -1;
-        if (!bad) {
-            wv = best;
-            if (0 < bd && bd < dm.D - 1) {
-                const int a[8] = {sm_in, s0, s1, s2, s3, s4, s5, sp_in};
-                int sm = a[0], sc = a[1], sp = a[2];
-#pragma unroll
-                for (int q = 1; q < 6; ++q) if (j == q) { sm = a[q]; sc = a[q + 1]; sp = a[q + 2]; }
-                const int denom2 = max(sm + sp - 2 * sc, 1);
-                dd = bd * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
-            } else dd = bd * 16;
-        }
-        disp1[o] = (int16_t)dd;
-        win[o] = wv;
-    }
+    const int y = (int)(pixel / dm.width1), x = (int)(pixel - (size_t)y * dm.width1);
+    wta_row16(dm, lo16s(v.a), hi16s(v.a), lo16s(v.b), hi16s(v.b), lo16s(v.c), hi16s(v.c), r, ((size_t)b * dm.h + y) * dm.w + x + dm.minX1, rec, true);
 }
 
 // ------------------------------------------------------------------------------------------- left-right check
 // disp2[x2] = disparity of the cheapest winner landing on right-image column x2 = x - d (the reference scans x from the
 // right with a strict ">", so among equal costs the largest x wins): packed-key atomicMin in LDS, then the consistency test.
 constexpr int kLrBlock = 256;
-__global__ __launch_bounds__(kLrBlock) void sgbm_lrcheck_kernel(SgbmDims dm, const int16_t* __restrict__ disp1, const int* __restrict__ win,
-                                                              int16_t* __restrict__ disp) {
+__global__ __launch_bounds__(kLrBlock) void sgbm_lrcheck_kernel(SgbmDims dm, const int4* __restrict__ rec, int16_t* __restrict__ disp) {
     const int y = blockIdx.x, b = blockIdx.y;
-    extern __shared__ int keys[]; // w
+    extern __shared__ int keys[]; // w keys + w/2 words of disp1
+    int16_t* disp1 = (int16_t*)(keys + dm.w);
     const size_t row = ((size_t)b * dm.h + y) * dm.w;
+    const int INVALID = -16;
     for (int i = threadIdx.x; i < dm.w; i += kLrBlock) keys[i] = 0x7FFFFFFF;
     __syncthreads();
-    for (int x = dm.minX1 + threadIdx.x; x < dm.w; x += kLrBlock) {
-        const int wv = win[row + x];
-        if (wv >= 0) atomicMin(&keys[x - (wv & 0xFF)], ((wv >> 8) << 12) | (4095 - x));
+    for (int x = threadIdx.x; x < dm.w; x += kLrBlock) {
+        int dd = INVALID;
+        if (x >= dm.minX1) {
+            const int4 rc = rec[row + x];
+            if (rc.x >= 0) {
+                const int bd = rc.x & 0xFF;
+                atomicMin(&keys[x - bd], ((rc.x >> 8) << 12) | (4095 - x));
+                if (0 < bd && bd < dm.D - 1) {
+                    const int sm = lo16s((uint32_t)rc.y), sc = hi16s((uint32_t)rc.y), sp = rc.z;
+                    const int denom2 = max(sm + sp - 2 * sc, 1);
+                    dd = bd * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
+                } else dd = bd * 16;
+            }
+        }
+        disp1[x] = (int16_t)dd;
     }
     __syncthreads();
-    const int INVALID = -16;
     for (int x = threadIdx.x; x < dm.w; x += kLrBlock) {
-        int d1 = x >= dm.minX1 ? (int)disp1[row + x] : INVALID;
+        int d1 = disp1[x];
         if (d1 != INVALID) {
             const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
             const int _x = x - _d, x_ = x - d_;
@@ -400,12 +449,11 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     const size_t vol = (size_t)h * dm.width1 * dm.D, npix = (size_t)w * h;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t need = 0;
-    const size_t o_pre = need; need += al((size_t)2 * B * h * 2 * w);
-    const size_t o_pix = need; need += al((size_t)B * vol);
+    const size_t o_pre = need; need += al((size_t)2 * B * h * 6 * w);
     const size_t o_hs = need; need += al((size_t)B * vol * 2);
     const size_t o_C = need; need += al((size_t)B * vol * 2);
     const size_t o_T = o_hs; // hsum is dead once C exists: T reuses its storage
-    const size_t o_win = need; need += al((size_t)B * npix * 4);
+    const size_t o_rec = need; need += al((size_t)B * npix * 16);
     const size_t o_d0 = need; need += al((size_t)B * npix * 2);
     const size_t o_d1 = need; need += al((size_t)B * npix * 2);
     const size_t o_par = need; need += al((size_t)B * npix * 4);
@@ -418,25 +466,25 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
         *scratch_bytes = need; *dev_bytes += need;
     }
     uint8_t* base = *scratch;
-    uint8_t* pre = base + o_pre; uint8_t* pix = base + o_pix; int16_t* hsum = (int16_t*)(base + o_hs); int16_t* C = (int16_t*)(base + o_C);
-    uint16_t* T = (uint16_t*)(base + o_T); int* win = (int*)(base + o_win);
+    uint8_t* pre = base + o_pre; int16_t* hsum = (int16_t*)(base + o_hs); int16_t* C = (int16_t*)(base + o_C);
+    uint16_t* T = (uint16_t*)(base + o_T); int4* rec = (int4*)(base + o_rec);
     int16_t* d0 = (int16_t*)(base + o_d0); int16_t* d1 = (int16_t*)(base + o_d1); int* par = (int*)(base + o_par); int* cnt = (int*)(base + o_cnt);
     const int vblocks = (dm.width1 * dm.D + 255) / 256;
     { ProfScope p(stream, "sgbm_prefilter_kernel"); hipLaunchKernelGGL(sgbm_prefilter_kernel, dim3((w + 255) / 256, h, 2 * B), dim3(256), 0, stream, dm, d_left, d_right, pre); }
-    { ProfScope p(stream, "sgbm_pixcost_kernel"); hipLaunchKernelGGL(sgbm_pixcost_kernel, dim3(vblocks, h, B), dim3(256), 0, stream, dm, pre, pix); }
-    { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3(vblocks, h, B), dim3(256), 0, stream, dm, pix, hsum); }
-    { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3(vblocks, h, B), dim3(256), 0, stream, dm, hsum, C); }
-    { ProfScope p(stream, "sgbm_path_kernel", 5);
-      const int nv = dm.width1, nd = dm.width1 + h - 1;
-      hipLaunchKernelGGL((sgbm_path_kernel<0, 1, 0>), dim3((nv + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nv);
-      hipLaunchKernelGGL((sgbm_path_kernel<1, 1, 1>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd);
-      hipLaunchKernelGGL((sgbm_path_kernel<-1, 1, 1>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd);
-      hipLaunchKernelGGL((sgbm_path_kernel<1, 0, 2>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h);
-      hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 3>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h); }
-    { ProfScope p(stream, "sgbm_wta_kernel");
-      hipLaunchKernelGGL(sgbm_wta_kernel, dim3((unsigned)(((size_t)h * dm.width1 + 15) / 16), B), dim3(256), 0, stream, dm, T, d1, win); }
+    { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3((dm.width1 + kHsSeg - 1) / kHsSeg, h, B), dim3(kHsBlock), 0, stream, dm, pre, hsum); }
+    { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3((dm.width1 * 12 + 255) / 256, (h + kVsChunk - 1) / kVsChunk, B), dim3(256), 0, stream, dm, hsum, C); }
+    { const int nv = dm.width1, nd = dm.width1 + h - 1;
+      { ProfScope p(stream, "sgbm_path_kernel<0,1>"); hipLaunchKernelGGL((sgbm_path_kernel<0, 1, 0, 8>), dim3((nv + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nv, (int4*)nullptr); }
+      { ProfScope p(stream, "sgbm_path_kernel<1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 1, 1, 8>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd, (int4*)nullptr); }
+      { ProfScope p(stream, "sgbm_path_kernel<-1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 1, 1, 8>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd, (int4*)nullptr); }
+      { ProfScope p(stream, "sgbm_path_kernel<1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 0, 2, 16>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h, (int4*)nullptr); }
+      if (B >= 4) { ProfScope p(stream, "sgbm_path_kernel<-1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 4, 16>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h, rec); }
+      else {
+        { ProfScope p(stream, "sgbm_path_kernel<-1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 3, 16>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h, (int4*)nullptr); }
+        { ProfScope p(stream, "sgbm_wta_kernel"); hipLaunchKernelGGL(sgbm_wta_kernel, dim3((unsigned)(((size_t)h * dm.width1 + 15) / 16), B), dim3(256), 0, stream, dm, T, rec); }
+      } }
     { ProfScope p(stream, "sgbm_lrcheck_kernel");
-      hipLaunchKernelGGL(sgbm_lrcheck_kernel, dim3(h, B), dim3(kLrBlock), (size_t)w * sizeof(int), stream, dm, d1, win, d0); }
+      hipLaunchKernelGGL(sgbm_lrcheck_kernel, dim3(h, B), dim3(kLrBlock), (size_t)(w + (w + 1) / 2) * sizeof(int), stream, dm, rec, d0); }
     if (d_disp_raw) VS_HIP(hipMemcpyAsync(d_disp_raw, d0, (size_t)B * npix * 2, hipMemcpyDeviceToDevice, stream));
     { ProfScope p(stream, "sgbm_median3_kernel"); hipLaunchKernelGGL(sgbm_median3_kernel, dim3((w + 255) / 256, h, B), dim3(256), 0, stream, w, h, d0, d1); }
     const int pblocks = (int)((npix + 255) / 256);

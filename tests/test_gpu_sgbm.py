@@ -60,7 +60,7 @@ def test_sgbm_flat_and_saturated(vo, oracle):
 
 def test_sgbm_batched_device_path(vo, oracle, synth):
     import torch
-    w, h, B = 500, 90, 3
+    w, h, B = 500, 90, 5   # B >= 4 takes the fused winner-take-all path
     pairs = [_rendered(synth, 20 + b, w, h, noise=6 * b)[:2] for b in range(B)]
     pitch = 512
     buf = np.zeros((2, B, h, pitch), np.uint8)
