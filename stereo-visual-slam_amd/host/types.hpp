@@ -88,6 +88,7 @@ struct Feature {
 struct Frame {
     int frame_id_ = 0;
     Image left_img_, right_img_;
+    std::vector<float> disparity_; // h x w f32, -1 = invalid (cv::Mat disparity_, types_def.hpp)
     SE3 T_c_w_;
     bool is_keyframe_ = false;
     int keyframe_id_ = 0;

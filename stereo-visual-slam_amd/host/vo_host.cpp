@@ -86,11 +86,39 @@ int VO::feature_matching(const DescriptorMat& d1, const DescriptorMat& d2, std::
     return 0;
 }
 
-// VO::set_ref_3d_position (:176-217) with the depth source swapped for the north_star stage: right-image ORB, L/R
-// cross-check match, rectified DLT.  Same outputs: pts_3d (world), keypoints/descriptors compacted in place, reliable flags.
+// VO::disparity_map (:159-174): StereoSGBM(0, 96, 9, 648, 2592, 1, 63, 10, 100, 32) + convertTo(CV_32F, 1/16) on the device
+int VO::disparity_map(const Frame& frame, std::vector<float>& disparity) {
+    const Image& l = frame.left_img_; const Image& r = frame.right_img_;
+    disparity.assign((size_t)l.cols * l.rows, -1.0f);
+    check(vslam_disparity_map(ctx_, l.data.data(), r.data.data(), l.cols, l.rows, l.cols, disparity.data(), nullptr, nullptr), "disparity_map");
+    return 0;
+}
+
+// VO::set_ref_3d_position (:176-217).  DepthSGBM: the reference's own loop -- Frame::find_3d on the dense disparity map,
+// keep 10 < Z < 400, reliable when Z < 40.  DepthStereoMatch: the depth source swapped for the north_star stage (right-image
+// ORB, L/R cross-check match, rectified DLT).  Same outputs either way: pts_3d (world), keypoints/descriptors compacted in
+// place, reliable flags.
 std::vector<bool> VO::set_ref_3d_position(std::vector<Point3f>& pts_3d, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors, Frame& frame) {
     pts_3d.clear();
     std::vector<bool> reliable_depth;
+    if (depth_source_ == DepthSGBM) {
+        disparity_map(frame, frame.disparity_); // :377 / :505
+        const size_t n = keypoints.size();
+        std::vector<float> xyz(3 * std::max<size_t>(n, 1));
+        std::vector<uint8_t> valid(std::max<size_t>(n, 1)), rel(std::max<size_t>(n, 1));
+        if (n) check(vslam_find_3d_disparity(ctx_, reinterpret_cast<const vslam_keypoint*>(keypoints.data()), (int)n, frame.disparity_.data(), frame.left_img_.cols,
+                                            frame.left_img_.rows, frame.left_img_.cols, frame.T_c_w_.data(), xyz.data(), valid.data(), rel.data(), nullptr), "find_3d");
+        std::vector<KeyPoint> kept_k; DescriptorMat kept_d;
+        for (size_t i = 0; i < n; ++i) {
+            if (!valid[i]) continue;
+            pts_3d.emplace_back(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+            kept_k.push_back(keypoints[i]);
+            kept_d.push_back(descriptors.row((int)i));
+            reliable_depth.push_back(rel[i] != 0);
+        }
+        keypoints.swap(kept_k); descriptors = kept_d;
+        return reliable_depth;
+    }
     std::vector<KeyPoint> kps_r; DescriptorMat desc_r;
     if (feature_detection(frame.right_img_, kps_r, desc_r) != 0 || descriptors.rows == 0) { keypoints.clear(); descriptors.clear(); return reliable_depth; }
     std::vector<DMatch> lr((size_t)descriptors.rows);

@@ -1,7 +1,8 @@
 // vo_host.hpp -- C++ mirror of vslam::VO (/root/reference/include/stereo_visual_slam_main/visual_odometry.hpp:27-185)
 // on top of the C-ABI.  Same public state and method names; OpenCV/ROS types are replaced by the PODs in types.hpp and
-// every arithmetic-heavy step is one C-ABI call into libvslam_hip.so.  Stereo depth uses the north_star stage
-// (L/R match + DLT) because SGBM is not built yet.
+// every arithmetic-heavy step is one C-ABI call into libvslam_hip.so.  Stereo depth has two sources: the reference's
+// own (dense SGBM disparity + Frame::find_3d, depth_source_ = DepthSGBM) and the north_star stage (right-image ORB,
+// L/R cross-check match, rectified DLT: depth_source_ = DepthStereoMatch, the default the headline bench measures).
 #pragma once
 #include <string>
 #include <vector>
@@ -12,6 +13,7 @@
 namespace vslam {
 
 enum TrackState { Init, Track, Lost };
+enum DepthSource { DepthStereoMatch = 0, DepthSGBM = 1 };
 
 // replaces cv::imread on `dataset + "image_0/%06d.png"` (visual_odometry.cpp:37-68): binary PGM (P5) files
 struct ImageSource {
@@ -37,6 +39,7 @@ public:
     int curr_keyframe_id_ = 0;
     int curr_landmark_id_ = 0;
     int pnp_iterations_ = 10;
+    DepthSource depth_source_ = DepthStereoMatch;
 
     VO(std::string dataset, vslam_ctx* ctx, Map& map) : my_map_(map), source_(std::move(dataset)), ctx_(ctx) {}
 
@@ -44,6 +47,7 @@ public:
     int feature_detection(const Image& img, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors);
     void adaptive_non_maximal_suppresion(std::vector<KeyPoint>& keypoints, const int num);
     int feature_matching(const DescriptorMat& descriptors_1, const DescriptorMat& descriptors_2, std::vector<DMatch>& feature_matches);
+    int disparity_map(const Frame& frame, std::vector<float>& disparity);
     std::vector<bool> set_ref_3d_position(std::vector<Point3f>& pts_3d, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors, Frame& frame);
     void motion_estimation(Frame& frame);
     bool check_motion_estimation();

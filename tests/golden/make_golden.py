@@ -51,6 +51,12 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ba_10x200.npz"), T0=w["T0"], xyz=w["xyz"], kf_idx=w["kf_idx"], lm_idx=w["lm_idx"], uv=w["uv"],
                         T_ba=Tb, xyz_ba=xb, chi2_ba=chi2, chi2_iter_ba=np.array(st["chi2_iter"]), thr_ba=th, inlier_ba=inlb,
                         T_po=To, chi2_po=chi2o, chi2_iter_po=np.array(sto["chi2_iter"]))
+    # dense stereo: rendered 360x120 pair with sensor noise on the right view (speckles, LR rejections)
+    sc = synth.Scene(71); Tc = synth.trajectory(1, 71)[0]
+    L, _ = sc.render(Tc, 360, 120); R, _ = sc.render(Tc, 360, 120, x_offset=synth.BASELINE)
+    R = np.clip(R.astype(int) + np.random.default_rng(71).integers(-8, 9, R.shape), 0, 255).astype(np.uint8)
+    d16, raw = O.sgbm_compute(L, R, return_raw=True)
+    np.savez_compressed(os.path.join(HERE, "sgbm_360x120.npz"), left=L, right=R, disp16=d16, raw16=raw, disparity=O.disparity_map(L, R))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -44,6 +44,14 @@ def test_oracle_reproduces_golden_match_geom_lm(oracle):
     assert np.allclose(T, g["T_po"], rtol=1e-8, atol=1e-10)
 
 
+def test_oracle_reproduces_golden_sgbm(oracle):
+    g = _load("sgbm_360x120.npz")
+    d16, raw = oracle.sgbm_compute(g["left"], g["right"], return_raw=True)
+    assert np.array_equal(d16, g["disp16"]) and np.array_equal(raw, g["raw16"])
+    assert np.array_equal(oracle.disparity_map(g["left"], g["right"]), g["disparity"])
+    assert (g["disp16"] != g["raw16"]).any() and (g["disp16"][:, 96:] >= 0).mean() > 0.5  # the fixture exercises the post-filters
+
+
 # ---------------------------------------------------------------- GPU: HIP path vs the committed vectors
 @pytest.mark.gpu
 def test_hip_reproduces_golden_orb(pkg):
@@ -77,3 +85,10 @@ def test_hip_reproduces_golden_match_geom_lm(vo):
     assert r["threshold"] == float(g["thr_ba"]) and np.array_equal(r["lm_inlier"], g["inlier_ba"])
     r = vo.optimize_pose_only(g["T0"], g["xyz"], g["kf_idx"], g["lm_idx"], g["uv"], True, 10)
     assert np.allclose(r["T"], g["T_po"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_sgbm(vo):
+    g = _load("sgbm_360x120.npz")
+    f, d16, raw = vo.disparity_map(g["left"], g["right"], return_i16=True)
+    assert np.array_equal(raw, g["raw16"]) and np.array_equal(d16, g["disp16"]) and np.array_equal(f, g["disparity"])

@@ -42,3 +42,24 @@ def test_run_vslam_driver_recovers_trajectory(synth):
             else:         # reference-faithful quirk Q1 (feature_id used as an index): BA edges can pair a landmark with the
                           # wrong pixel, so single keyframes may be pulled away; the trajectory as a whole still holds
                 assert np.median(err) < 0.05 * path_len + 0.2, (err, path_len)
+
+
+def test_run_vslam_driver_with_sgbm_depth(synth):
+    """same loop with the reference's own depth source: VO::disparity_map (SGBM on the device) + Frame::find_3d"""
+    subprocess.check_call(["make", "-C", HOST, "-s", "-j8"])
+    n = 24
+    with tempfile.TemporaryDirectory() as d:
+        gt = synth.write_pgm_sequence(d + "/", n, seed=6)
+        path_len = np.linalg.norm(-synth.R_from_quat(gt[-1][:4]).T @ gt[-1][4:])
+        traj = os.path.join(d, "traj_sgbm.txt")
+        out = subprocess.run([os.path.join(HOST, "run_vslam"), d + "/", str(n), "1", "1500", traj, "0", "1"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "VO IS LOST" not in out.stdout
+        rows = np.loadtxt(traj)
+        assert rows.shape[1] == 13 and len(rows) >= 8
+        err = []
+        for r in rows:
+            T = gt[int(r[0])]
+            pos = -synth.R_from_quat(T[:4]).T @ T[4:]
+            err.append(np.linalg.norm(r[1:].reshape(3, 4)[:, 3] - pos))
+        assert np.median(err) < 0.05 * path_len + 0.2 and max(err) < 0.1 * path_len + 0.3, (err, path_len)
