@@ -31,6 +31,9 @@ namespace vslam {
 #ifndef VSLAM_LM_BLOCK
 #define VSLAM_LM_BLOCK 512
 #endif
+#ifndef VSLAM_LM_MIN_WAVES
+#define VSLAM_LM_MIN_WAVES 2 // waves per SIMD the register allocation must leave room for
+#endif
 constexpr int kLmBlock = VSLAM_LM_BLOCK;
 constexpr int kLmWaves = kLmBlock / 64;
 constexpr int kMaxKf = VSLAM_MAX_KF;
@@ -140,6 +143,18 @@ __device__ inline void project_err(const double* Rt, const double* K, double px,
     ey = (double)v - (K[1] * Y * rz + K[3]);
 }
 
+// linearisation record of one observation at (pose Rt, point p): camera-frame X, Y, the reciprocal depth the Jacobians use,
+// the Huber weight and the error.  Shared by the evaluation pass (which stores it keyframe-major for the pose-wise and Schur
+// phases) and by the landmark-wise phases, which recompute it from the landmark position instead of gathering it.
+__device__ inline void lin_record(const double* Rt, const double* K, double px, double py, double pz, float2 z, double delta, bool with_lm,
+                                  double& X, double& Y, double& Zi, double& wgt, double& ex, double& ey, double& chi, double& rho) {
+    double Z;
+    project_err(Rt, K, px, py, pz, z.x, z.y, X, Y, Z, ex, ey);
+    chi = ex * ex + ey * ey;
+    huber(chi, delta, rho, wgt);
+    Zi = with_lm ? 1.0 / (Z + 1e-18) : 1.0 / Z; // optimization.cpp:66 vs :96-100
+}
+
 __device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double Di[6]) {
     // symmetric [[a b c],[b d e],[c e f]] -> unique entries of the inverse (00 01 02 11 12 22)
     const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
@@ -194,7 +209,7 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
 }
 
 template <bool IMPL>
-__global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, int mode, int iters, int update_poses, int update_lms,
+__global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel(LmKernelArgs ka, int mode, int iters, int update_poses, int update_lms,
                                                             int classify) {
     const LmWindowArgs& a = ka.a;
     __shared__ LmShared sm;
@@ -396,26 +411,40 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
     vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
 
     // error evaluation at (Rt, Pcur); store_lin also records the linearisation point (X, Y, 1/Z, w, e, B)
+    // Every phase below is a chain of dependent gathers out of a per-window working set that lives in HBM (1.5 MB x
+    // hundreds of windows), so each loop is written as batches: all loads of one dependency level for kEvalU items first,
+    // then the arithmetic -- the per-thread summation order is unchanged.
+    const float2* uv2 = reinterpret_cast<const float2*>(uv);
+    constexpr int kEvalU = 4;
+    constexpr int kLmU = 2, kLmE = 4; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
     auto eval = [&](const double* Rt, const double* Pcur, bool store_lin) -> double {
         double part = 0;
-#pragma unroll 2
-        for (int e = tid; e < ne; e += kLmBlock) {
-            const int l = ELM(e);
-            if (!act[l]) continue;
-            const int k = EKF(e);
-            double X, Y, Z, ex, ey;
-            const float2 z = reinterpret_cast<const float2*>(uv)[e];
-            project_err(&Rt[12 * k], K, PC(Pcur, 0, l), PC(Pcur, 1, l), PC(Pcur, 2, l), z.x, z.y, X, Y, Z, ex, ey);
-            const double c = ex * ex + ey * ey;
-            chi2[e] = c;
-            double rho, wgt;
-            huber(c, delta, rho, wgt);
-            part += rho;
-            if (store_lin) {
-                const double Zi = with_lm ? 1.0 / (Z + 1e-18) : 1.0 / Z; // optimization.cpp:66 vs :96-100
-                const int ps = POS(e);
-                recA[ps] = make_double4(X, Y, Zi, wgt);
-                recB[ps] = make_double2(ex, ey);
+        for (int base = tid; base < ne; base += kEvalU * kLmBlock) {
+            int l[kEvalU], k[kEvalU], ps[kEvalU];
+            float2 z[kEvalU];
+#pragma unroll
+            for (int u = 0; u < kEvalU; ++u) {
+                const int e = min(base + u * kLmBlock, ne - 1);
+                l[u] = ELM(e); k[u] = EKF(e); z[u] = uv2[e]; ps[u] = store_lin ? POS(e) : 0;
+            }
+            double px[kEvalU], py[kEvalU], pz[kEvalU];
+            bool on[kEvalU];
+#pragma unroll
+            for (int u = 0; u < kEvalU; ++u) {
+                on[u] = act[l[u]] != 0 && base + u * kLmBlock < ne;
+                px[u] = PC(Pcur, 0, l[u]); py[u] = PC(Pcur, 1, l[u]); pz[u] = PC(Pcur, 2, l[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kEvalU; ++u) {
+                if (!on[u]) continue;
+                double X, Y, Zi, wgt, ex, ey, c, rho;
+                lin_record(&Rt[12 * k[u]], K, px[u], py[u], pz[u], z[u], delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
+                chi2[base + u * kLmBlock] = c;
+                part += rho;
+                if (store_lin) {
+                    recA[ps[u]] = make_double4(X, Y, Zi, wgt);
+                    recB[ps[u]] = make_double2(ex, ey);
+                }
             }
         }
         return block_sum(part, sm.red);
@@ -428,26 +457,45 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
         // ---- buildSystem: landmark blocks
         double maxdiag = 0;
         if (with_lm) {
-            for (int l = tid; l < nl; l += kLmBlock) {
-                if (!act[l]) continue;
-                double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-                for (int e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
-                    const int ps = kf_pos[e];
-                    const double4 ra = recA[ps];
-                    const double2 rb = recB[ps];
-                    double A[12], B[6];
-                    jac_pose(K, ra.x, ra.y, ra.z, A);
-                    jac_point(A, &sm.Rt[12 * EKF(e)], B);
-                    const double wg = ra.w, ex = rb.x, ey = rb.y;
-                    h[0] += wg * (B[0] * B[0] + B[3] * B[3]); h[1] += wg * (B[0] * B[1] + B[3] * B[4]); h[2] += wg * (B[0] * B[2] + B[3] * B[5]);
-                    h[3] += wg * (B[1] * B[1] + B[4] * B[4]); h[4] += wg * (B[1] * B[2] + B[4] * B[5]); h[5] += wg * (B[2] * B[2] + B[5] * B[5]);
-                    g[0] -= wg * (B[0] * ex + B[3] * ey); g[1] -= wg * (B[1] * ex + B[4] * ey); g[2] -= wg * (B[2] * ex + B[5] * ey);
+            for (int l0 = tid; l0 < nl; l0 += kLmU * kLmBlock) {
+                int b0[kLmU], b1[kLmU];
+                double px[kLmU], py[kLmU], pz[kLmU];
+                bool on[kLmU];
+#pragma unroll
+                for (int u = 0; u < kLmU; ++u) {
+                    const int l = min(l0 + u * kLmBlock, nl - 1);
+                    on[u] = act[l] != 0 && l0 + u * kLmBlock < nl;
+                    b0[u] = lm_ptr[l]; b1[u] = lm_ptr[l + 1];
+                    px[u] = PC(P, 0, l); py[u] = PC(P, 1, l); pz[u] = PC(P, 2, l);
                 }
+                int kk[kLmU][kLmE]; float2 zz[kLmU][kLmE];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) PC(Hll, i, l) = h[i];
+                for (int u = 0; u < kLmU; ++u)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) PC(bl, i, l) = g[i];
-                maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
+                    for (int q = 0; q < kLmE; ++q) { const int e = max(min(b0[u] + q, ne - 1), 0); kk[u][q] = ne > 0 ? kfi[e] : 0; zz[u][q] = ne > 0 ? uv2[e] : make_float2(0.f, 0.f); }
+#pragma unroll
+                for (int u = 0; u < kLmU; ++u) {
+                    if (!on[u]) continue;
+                    const int l = l0 + u * kLmBlock;
+                    double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+                    auto add_edge = [&](int k, float2 z) {
+                        double X, Y, Zi, wg, ex, ey, c, rho, A[12], B[6];
+                        lin_record(&sm.Rt[12 * k], K, px[u], py[u], pz[u], z, delta, true, X, Y, Zi, wg, ex, ey, c, rho);
+                        jac_pose(K, X, Y, Zi, A);
+                        jac_point(A, &sm.Rt[12 * k], B);
+                        h[0] += wg * (B[0] * B[0] + B[3] * B[3]); h[1] += wg * (B[0] * B[1] + B[3] * B[4]); h[2] += wg * (B[0] * B[2] + B[3] * B[5]);
+                        h[3] += wg * (B[1] * B[1] + B[4] * B[4]); h[4] += wg * (B[1] * B[2] + B[4] * B[5]); h[5] += wg * (B[2] * B[2] + B[5] * B[5]);
+                        g[0] -= wg * (B[0] * ex + B[3] * ey); g[1] -= wg * (B[1] * ex + B[4] * ey); g[2] -= wg * (B[2] * ex + B[5] * ey);
+                    };
+#pragma unroll
+                    for (int q = 0; q < kLmE; ++q) if (b0[u] + q < b1[u]) add_edge(kk[u][q], zz[u][q]);
+                    for (int e = b0[u] + kLmE; e < b1[u]; ++e) add_edge(kfi[e], uv2[e]); // rare: more than kLmE observations
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) PC(Hll, i, l) = h[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) PC(bl, i, l) = g[i];
+                    maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
+                }
             }
         }
         PH(2);
@@ -566,12 +614,13 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                         // software-pipelined: the next hit's records are requested before the current hit is consumed
                         const int jend = pair_ptr[p + 1];
                         int j = pair_ptr[p] + lane;
-                        int4 h = hits[min(j, jend - 1)];
+                        int4 h = hits[max(min(j, jend - 1), 0)];
+                        int4 hn = hits[max(min(j + 64, jend - 1), 0)]; // hit indices run two steps ahead of the arithmetic, records one step
                         double4 ra = recA[h.x];
                         const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
                         double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
                         for (; j < jend; j += 64) {
-                            const int4 hn = hits[min(j + 64, jend - 1)];
+                            const int4 hnn = hits[max(min(j + 128, jend - 1), 0)];
                             const double4 ran = recA[hn.x];
                             const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.z);
                             const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
@@ -595,7 +644,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
 #pragma unroll
                                 for (int c = r; c < 6; ++c) acc[6 * r + c] += m0 * A1[c] + m1 * A1[6 + c];
                             }
-                            ra = ran; Da = Dan; Db = Dbn; Dc = Dcn;
+                            ra = ran; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
                         }
 #pragma unroll
                         for (int r = 1; r < 6; ++r)
@@ -604,12 +653,13 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
                     } else {
                         const int jend = pair_ptr[p + 1];
                         int j = pair_ptr[p] + lane;
-                        int4 h = hits[min(j, jend - 1)];
+                        int4 h = hits[max(min(j, jend - 1), 0)];
+                        int4 hn = hits[max(min(j + 64, jend - 1), 0)];
                         double4 ra = recA[h.x], rb = recA[h.y];
                         const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
                         double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
                         for (; j < jend; j += 64) {
-                            const int4 hn = hits[min(j + 64, jend - 1)];
+                            const int4 hnn = hits[max(min(j + 128, jend - 1), 0)];
                             const double4 ran = recA[hn.x], rbn = recA[hn.y];
                             const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.z);
                             const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
@@ -637,7 +687,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
 #pragma unroll
                                 for (int c = 0; c < 6; ++c) acc[6 * r + c] += m0 * A2[c] + m1 * A2[6 + c];
                             }
-                            ra = ran; rb = rbn; Da = Dan; Db = Dbn; Dc = Dcn;
+                            ra = ran; rb = rbn; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
                         }
                     }
 #pragma unroll
@@ -772,30 +822,54 @@ __global__ __launch_bounds__(kLmBlock) void lm_window_kernel(LmKernelArgs ka, in
             // ---- update: landmarks (back-substitution) and poses; computeScale
             double scale_part = 0;
             if (with_lm) {
-                for (int l = tid; l < nl; l += kLmBlock) {
-                    if (!act[l]) { PC(Pt, 0, l) = PC(P, 0, l); PC(Pt, 1, l) = PC(P, 1, l); PC(Pt, 2, l) = PC(P, 2, l); continue; }
-                    const double g[3] = {PC(bl, 0, l), PC(bl, 1, l), PC(bl, 2, l)};
-                    double c0 = g[0], c1 = g[1], c2 = g[2];
-                    for (int e = lm_ptr[l]; e < lm_ptr[l + 1]; ++e) {
-                        const int k = kfi[e];
-                        const double4 ra = recA[kf_pos[e]];
-                        double A[12], B[6];
-                        jac_pose(K, ra.x, ra.y, ra.z, A);
-                        jac_point(A, &sm.Rt[12 * k], B);
-                        // W^T xp = w B^T (A xp_k)
-                        double a0 = 0, a1 = 0;
+                for (int l0 = tid; l0 < nl; l0 += kLmU * kLmBlock) {
+                    int b0[kLmU], b1[kLmU];
+                    double px[kLmU], py[kLmU], pz[kLmU], g0[kLmU], g1[kLmU], g2[kLmU], Dq[kLmU][6];
+                    bool on[kLmU], in[kLmU];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) { a0 += A[r] * sm.xp[6 * k + r]; a1 += A[6 + r] * sm.xp[6 * k + r]; }
-                        a0 *= ra.w; a1 *= ra.w;
-                        c0 -= B[0] * a0 + B[3] * a1; c1 -= B[1] * a0 + B[4] * a1; c2 -= B[2] * a0 + B[5] * a1;
+                    for (int u = 0; u < kLmU; ++u) {
+                        const int l = min(l0 + u * kLmBlock, nl - 1);
+                        in[u] = l0 + u * kLmBlock < nl;
+                        on[u] = act[l] != 0 && in[u];
+                        b0[u] = lm_ptr[l]; b1[u] = lm_ptr[l + 1];
+                        px[u] = PC(P, 0, l); py[u] = PC(P, 1, l); pz[u] = PC(P, 2, l);
+                        g0[u] = PC(bl, 0, l); g1[u] = PC(bl, 1, l); g2[u] = PC(bl, 2, l);
+                        const double2* Dp = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)l);
+                        const double2 da = Dp[0], dbb = Dp[1], dc = Dp[2];
+                        Dq[u][0] = da.x; Dq[u][1] = da.y; Dq[u][2] = dbb.x; Dq[u][3] = dbb.y; Dq[u][4] = dc.x; Dq[u][5] = dc.y;
                     }
-                    const double* Dq = Dinv + 6 * (size_t)l;
-                    const double D0 = Dq[0], D1 = Dq[1], D2 = Dq[2], D3 = Dq[3], D4 = Dq[4], D5 = Dq[5];
-                    const double x0 = D0 * c0 + D1 * c1 + D2 * c2;
-                    const double x1 = D1 * c0 + D3 * c1 + D4 * c2;
-                    const double x2 = D2 * c0 + D4 * c1 + D5 * c2;
-                    PC(Pt, 0, l) = PC(P, 0, l) + x0; PC(Pt, 1, l) = PC(P, 1, l) + x1; PC(Pt, 2, l) = PC(P, 2, l) + x2;
-                    scale_part += x0 * (lambda * x0 + g[0]) + x1 * (lambda * x1 + g[1]) + x2 * (lambda * x2 + g[2]);
+                    int kk[kLmU][kLmE]; float2 zz[kLmU][kLmE];
+#pragma unroll
+                    for (int u = 0; u < kLmU; ++u)
+#pragma unroll
+                        for (int q = 0; q < kLmE; ++q) { const int e = max(min(b0[u] + q, ne - 1), 0); kk[u][q] = ne > 0 ? kfi[e] : 0; zz[u][q] = ne > 0 ? uv2[e] : make_float2(0.f, 0.f); }
+#pragma unroll
+                    for (int u = 0; u < kLmU; ++u) {
+                        if (!in[u]) continue;
+                        const int l = l0 + u * kLmBlock;
+                        if (!on[u]) { PC(Pt, 0, l) = px[u]; PC(Pt, 1, l) = py[u]; PC(Pt, 2, l) = pz[u]; continue; }
+                        double c0 = g0[u], c1 = g1[u], c2 = g2[u];
+                        auto sub_edge = [&](int k, float2 z) {
+                            double X, Y, Zi, wg, ex, ey, c, rho, A[12], B[6];
+                            lin_record(&sm.Rt[12 * k], K, px[u], py[u], pz[u], z, delta, true, X, Y, Zi, wg, ex, ey, c, rho);
+                            jac_pose(K, X, Y, Zi, A);
+                            jac_point(A, &sm.Rt[12 * k], B);
+                            // W^T xp = w B^T (A xp_k)
+                            double a0 = 0, a1 = 0;
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) { a0 += A[r] * sm.xp[6 * k + r]; a1 += A[6 + r] * sm.xp[6 * k + r]; }
+                            a0 *= wg; a1 *= wg;
+                            c0 -= B[0] * a0 + B[3] * a1; c1 -= B[1] * a0 + B[4] * a1; c2 -= B[2] * a0 + B[5] * a1;
+                        };
+#pragma unroll
+                        for (int q = 0; q < kLmE; ++q) if (b0[u] + q < b1[u]) sub_edge(kk[u][q], zz[u][q]);
+                        for (int e = b0[u] + kLmE; e < b1[u]; ++e) sub_edge(kfi[e], uv2[e]);
+                        const double x0 = Dq[u][0] * c0 + Dq[u][1] * c1 + Dq[u][2] * c2;
+                        const double x1 = Dq[u][1] * c0 + Dq[u][3] * c1 + Dq[u][4] * c2;
+                        const double x2 = Dq[u][2] * c0 + Dq[u][4] * c1 + Dq[u][5] * c2;
+                        PC(Pt, 0, l) = px[u] + x0; PC(Pt, 1, l) = py[u] + x1; PC(Pt, 2, l) = pz[u] + x2;
+                        scale_part += x0 * (lambda * x0 + g0[u]) + x1 * (lambda * x1 + g1[u]) + x2 * (lambda * x2 + g2[u]);
+                    }
                 }
             }
             if (tid < np) scale_part += sm.xp[tid] * (lambda * sm.xp[tid] + sm.bp[tid]);
