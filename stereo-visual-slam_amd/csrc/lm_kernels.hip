@@ -495,6 +495,12 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                     for (int i = 0; i < 3; ++i) PC(bl, i, l) = g[i];
                     maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
+                    if (it > 0) { // lambda of the first trial is already known: invert here and skip that trial's pass over Hll
+                        double Di[6];
+                        if (!inv3_sym(h[0] + lambda, h[1], h[2], h[3] + lambda, h[4], h[5] + lambda, Di)) sm.flag[1] = 1;
+                        double2* Dp = reinterpret_cast<double2*>(Dinv + 6 * (size_t)l);
+                        Dp[0] = make_double2(Di[0], Di[1]); Dp[1] = make_double2(Di[2], Di[3]); Dp[2] = make_double2(Di[4], Di[5]);
+                    }
                 }
             }
         }
@@ -553,54 +559,21 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         while (again) {
             bool ok2 = true;
             if (with_lm) {
-                // Dinv, db per landmark
-                int bad = 0;
-                for (int l = tid; l < nl; l += kLmBlock) {
-                    if (!act[l]) continue;
-                    double Di[6];
-                    if (!inv3_sym(PC(Hll, 0, l) + lambda, PC(Hll, 1, l), PC(Hll, 2, l), PC(Hll, 3, l) + lambda, PC(Hll, 4, l), PC(Hll, 5, l) + lambda, Di)) bad = 1;
-                    const double g[3] = {PC(bl, 0, l), PC(bl, 1, l), PC(bl, 2, l)};
-                    double2* Dp = reinterpret_cast<double2*>(Dinv + 6 * (size_t)l);
-                    Dp[0] = make_double2(Di[0], Di[1]); Dp[1] = make_double2(Di[2], Di[3]); Dp[2] = make_double2(Di[4], Di[5]);
-                    PC(db, 0, l) = Di[0] * g[0] + Di[1] * g[1] + Di[2] * g[2];
-                    PC(db, 1, l) = Di[1] * g[0] + Di[3] * g[1] + Di[4] * g[2];
-                    PC(db, 2, l) = Di[2] * g[0] + Di[4] * g[1] + Di[5] * g[2];
-                }
-                if (bad) sm.flag[1] = 1;
-                for (int i = tid; i < np * np; i += kLmBlock) sm.S[i] = 0;
-                __syncthreads(); // Dinv/db visible (global, same workgroup) + S zeroed
-                PH(4);
-                // bs[k] = bp[k] - sum_e W_e db_l   (item = (pose, part))
-                for (int item = wave; item < nk * nparts; item += kLmWaves) {
-                    const int k = item / nparts, part = item - k * nparts;
-                    double acc[6] = {0, 0, 0, 0, 0, 0};
-                    const int b0 = kf_ptr[k], b1 = kf_ptr[k + 1];
-                    const int s0 = b0 + (int)((long long)(b1 - b0) * part / nparts), s1 = b0 + (int)((long long)(b1 - b0) * (part + 1) / nparts);
-                    for (int j = s0 + lane; j < s1; j += 64) {
-                        const int l = kf_lm[j];
-                        const double4 ra = recA[j];
-                        double A[12], B[6];
-                        jac_pose(K, ra.x, ra.y, ra.z, A);
-                        jac_point(A, &sm.Rt[12 * k], B);
-                        const double d0 = PC(db, 0, l), d1 = PC(db, 1, l), d2 = PC(db, 2, l), wg = ra.w;
-                        const double m0 = wg * (B[0] * d0 + B[1] * d1 + B[2] * d2);
-                        const double m1 = wg * (B[3] * d0 + B[4] * d1 + B[5] * d2);
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) acc[r] += A[r] * m0 + A[6 + r] * m1;
+                // Dinv = (Hll + lambda I)^-1 per landmark (the first trial of iterations > 0 got it from the landmark-block pass)
+                if (it == 0 || qmax > 0) {
+                    int bad = 0;
+                    for (int l = tid; l < nl; l += kLmBlock) {
+                        if (!act[l]) continue;
+                        double Di[6];
+                        if (!inv3_sym(PC(Hll, 0, l) + lambda, PC(Hll, 1, l), PC(Hll, 2, l), PC(Hll, 3, l) + lambda, PC(Hll, 4, l), PC(Hll, 5, l) + lambda, Di)) bad = 1;
+                        double2* Dp = reinterpret_cast<double2*>(Dinv + 6 * (size_t)l);
+                        Dp[0] = make_double2(Di[0], Di[1]); Dp[1] = make_double2(Di[2], Di[3]); Dp[2] = make_double2(Di[4], Di[5]);
                     }
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
-                    if (lane == 0)
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) sm.part[item * 27 + r] = acc[r];
+                    if (bad) sm.flag[1] = 1;
                 }
-                __syncthreads();
-                if (tid < np) {
-                    const int k = tid / 6, r = tid - 6 * k;
-                    double v = sm.bp[tid];
-                    for (int part = 0; part < nparts; ++part) v -= sm.part[(k * nparts + part) * 27 + r];
-                    sm.bs[tid] = v;
-                }
+                for (int i = tid; i < np * np; i += kLmBlock) sm.S[i] = 0;
+                __syncthreads(); // Dinv visible (global, same workgroup) + S zeroed
+                PH(4);
                 PH(5);
                 // Schur blocks: S[k1][k2] = [k1==k2](Hpp + lambda I) - sum_hits W1 Dinv W2^T.  item = (pair, row half), owned by one wave
                 for (int slot = 0; slot < kItemSlots; ++slot) {
@@ -614,16 +587,20 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         // software-pipelined: the next hit's records are requested before the current hit is consumed
                         const int jend = pair_ptr[p + 1];
                         int j = pair_ptr[p] + lane;
-                        int4 h = hits[max(min(j, jend - 1), 0)];
-                        int4 hn = hits[max(min(j + 64, jend - 1), 0)]; // hit indices run two steps ahead of the arithmetic, records one step
+                        double accb[6] = {0, 0, 0, 0, 0, 0}; // this keyframe's share of W Dinv b_l (reduced right-hand side)
+                        if (pair_ptr[p] < jend) { // (an empty list has no valid record to prefetch)
+                        int4 h = hits[min(j, jend - 1)];
+                        int4 hn = hits[min(j + 64, jend - 1)]; // hit indices run two steps ahead of the arithmetic, records one step
                         double4 ra = recA[h.x];
                         const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
                         double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
+                        double g0 = PC(bl, 0, h.z), g1 = PC(bl, 1, h.z), g2 = PC(bl, 2, h.z);
                         for (; j < jend; j += 64) {
-                            const int4 hnn = hits[max(min(j + 128, jend - 1), 0)];
+                            const int4 hnn = hits[min(j + 128, jend - 1)];
                             const double4 ran = recA[hn.x];
                             const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.z);
                             const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
+                            const double g0n = PC(bl, 0, hn.z), g1n = PC(bl, 1, hn.z), g2n = PC(bl, 2, hn.z);
                             double A1[12], B1[6];
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
                             jac_point(A1, &sm.Rt[12 * k1], B1);
@@ -633,6 +610,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 BD[3 * r] = B1[3 * r] * Da.x + B1[3 * r + 1] * Da.y + B1[3 * r + 2] * Db.x;
                                 BD[3 * r + 1] = B1[3 * r] * Da.y + B1[3 * r + 1] * Db.y + B1[3 * r + 2] * Dc.x;
                                 BD[3 * r + 2] = B1[3 * r] * Db.x + B1[3 * r + 1] * Dc.x + B1[3 * r + 2] * Dc.y;
+                            }
+                            {
+                                const double m0 = ra.w * (BD[0] * g0 + BD[1] * g1 + BD[2] * g2), m1 = ra.w * (BD[3] * g0 + BD[4] * g1 + BD[5] * g2);
+#pragma unroll
+                                for (int r = 0; r < 6; ++r) accb[r] += A1[r] * m0 + A1[6 + r] * m1;
                             }
                             const double ww = ra.w * ra.w;
                             const double M00 = ww * (BD[0] * B1[0] + BD[1] * B1[1] + BD[2] * B1[2]);
@@ -644,22 +626,29 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                                 for (int c = r; c < 6; ++c) acc[6 * r + c] += m0 * A1[c] + m1 * A1[6 + c];
                             }
-                            ra = ran; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
+                            ra = ran; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn; g0 = g0n; g1 = g1n; g2 = g2n;
+                        }
                         }
 #pragma unroll
                         for (int r = 1; r < 6; ++r)
 #pragma unroll
                             for (int c = 0; c < r; ++c) acc[6 * r + c] = acc[6 * c + r];
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) accb[r] = wave_sum(accb[r]);
+                        if (lane == 0)
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) sm.bs[6 * k1 + r] = sm.bp[6 * k1 + r] - accb[r];
                     } else {
                         const int jend = pair_ptr[p + 1];
                         int j = pair_ptr[p] + lane;
-                        int4 h = hits[max(min(j, jend - 1), 0)];
-                        int4 hn = hits[max(min(j + 64, jend - 1), 0)];
+                        if (pair_ptr[p] < jend) {
+                        int4 h = hits[min(j, jend - 1)];
+                        int4 hn = hits[min(j + 64, jend - 1)];
                         double4 ra = recA[h.x], rb = recA[h.y];
                         const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
                         double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
                         for (; j < jend; j += 64) {
-                            const int4 hnn = hits[max(min(j + 128, jend - 1), 0)];
+                            const int4 hnn = hits[min(j + 128, jend - 1)];
                             const double4 ran = recA[hn.x], rbn = recA[hn.y];
                             const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.z);
                             const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
@@ -688,6 +677,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 for (int c = 0; c < 6; ++c) acc[6 * r + c] += m0 * A2[c] + m1 * A2[6 + c];
                             }
                             ra = ran; rb = rbn; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
+                        }
                         }
                     }
 #pragma unroll
