@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     int32_t* kf_lm = a.kf_edges + e0;   // landmark of the edge stored at by-pose position j
     int32_t* kf_pos = ka.kf_pos + e0;    // by-pose (keyframe-major) position of edge e: where its linearisation record lives
     int32_t* pair_ptr = a.pair_ptr + (size_t)w * (kMaxPairs + 1);
-    int4* hits = reinterpret_cast<int4*>(a.pair_hits) + (size_t)e0 * kHitsPerEdge;
+    int2* hits = reinterpret_cast<int2*>(a.pair_hits) + (size_t)e0 * kHitsPerEdge; // off-diagonal pairs only: {pos1 | pos2 << 16, landmark}
     uint8_t* act = ka.act + lm0;
     uint8_t* eo = ka.eo + (size_t)lm0 * kMaxKf;
     const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
@@ -280,6 +280,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         }
         if (ne == 0) for (int x = tid; x <= nl; x += kLmBlock) lm_ptr[x] = 0;
     }
+    __syncthreads();
+    if (!IMPL && ne > 0xFFFF && tid == 0) sm.flag[7] = 1; // Schur hit records pack two 16-bit record positions
     __syncthreads();
     if (sm.flag[7]) { // uniform
         if (tid == 0) ka.status[w] = VSLAM_ERR_ARG;
@@ -367,13 +369,14 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     }
                     for (int p = 0; p < npairs; ++p) {
                         const int k1 = sm.pk1[p], k2 = sm.pk2[p];
+                        if (k1 == k2) continue; // the diagonal pass streams the keyframe's own record list
                         const uint32_t wa = k1 < 4 ? w0 : (k1 < 8 ? w1 : w2), wb = k2 < 4 ? w0 : (k2 < 8 ? w1 : w2);
                         const uint32_t o1 = (wa >> (8 * (k1 & 3))) & 0xFFu, o2 = (wb >> (8 * (k2 & 3))) & 0xFFu;
                         const bool hit = o1 != 0xFFu && o2 != 0xFFu;
                         const unsigned long long m = __ballot(hit);
                         if (m == 0) continue; // uniform
                         const int cur = sm.cnt[wave * kCntStride + p];
-                        if (pass && hit) hits[cur + __popcll(m & lt_mask)] = make_int4(kf_pos[eb0 + (int)o1], kf_pos[eb0 + (int)o2], l, 0);
+                        if (pass && hit) hits[cur + __popcll(m & lt_mask)] = make_int2(kf_pos[eb0 + (int)o1] | (kf_pos[eb0 + (int)o2] << 16), l);
                         __builtin_amdgcn_wave_barrier();
                         if (lane == 0) sm.cnt[wave * kCntStride + p] = (uint16_t)0 + cur + __popcll(m);
                         __builtin_amdgcn_wave_barrier();
@@ -394,9 +397,10 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             for (int i = tid; i < kLmWaves * kItemSlots; i += kLmBlock) sm.item[i] = 0xFF;
             __syncthreads();
             if (tid < nitems) {
-                const int mine = sm.ptot[tid];
+                auto work = [&](int q) -> int { const int a1 = sm.pk1[q]; return a1 == sm.pk2[q] ? kf_ptr[a1 + 1] - kf_ptr[a1] : (int)sm.ptot[q]; };
+                const int mine = work(tid);
                 int rank = 0;
-                for (int j = 0; j < nitems; ++j) { const int c = sm.ptot[j]; rank += (c > mine) || (c == mine && j < tid); }
+                for (int j = 0; j < nitems; ++j) { const int c = work(j); rank += (c > mine) || (c == mine && j < tid); }
                 const int row = rank / kLmWaves, col = rank % kLmWaves;
                 sm.item[((row & 1) ? kLmWaves - 1 - col : col) * kItemSlots + row] = (uint8_t)tid;
             }
@@ -585,22 +589,22 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     for (int i = 0; i < 36; ++i) acc[i] = 0;
                     if (k1 == k2) { // every edge of keyframe k1 pairs with itself: one Jacobian, symmetric 2x2 core, upper triangle only
                         // software-pipelined: the next hit's records are requested before the current hit is consumed
-                        const int jend = pair_ptr[p + 1];
-                        int j = pair_ptr[p] + lane;
+                        // streams the keyframe's own records (j) with the landmark ids two steps and Dinv / b_l one step ahead
+                        const int jbeg = kf_ptr[k1], jend = kf_ptr[k1 + 1];
+                        int j = jbeg + lane;
                         double accb[6] = {0, 0, 0, 0, 0, 0}; // this keyframe's share of W Dinv b_l (reduced right-hand side)
-                        if (pair_ptr[p] < jend) { // (an empty list has no valid record to prefetch)
-                        int4 h = hits[min(j, jend - 1)];
-                        int4 hn = hits[min(j + 64, jend - 1)]; // hit indices run two steps ahead of the arithmetic, records one step
-                        double4 ra = recA[h.x];
-                        const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
+                        if (jbeg < jend) { // (an empty list has no valid record to prefetch)
+                        int ln = kf_lm[min(j, jend - 1)], lnn = kf_lm[min(j + 64, jend - 1)];
+                        double4 ra = recA[min(j, jend - 1)];
+                        const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)ln);
                         double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
-                        double g0 = PC(bl, 0, h.z), g1 = PC(bl, 1, h.z), g2 = PC(bl, 2, h.z);
+                        double g0 = PC(bl, 0, ln), g1 = PC(bl, 1, ln), g2 = PC(bl, 2, ln);
                         for (; j < jend; j += 64) {
-                            const int4 hnn = hits[min(j + 128, jend - 1)];
-                            const double4 ran = recA[hn.x];
-                            const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.z);
+                            const int lnnn = kf_lm[min(j + 128, jend - 1)];
+                            const double4 ran = recA[min(j + 64, jend - 1)];
+                            const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)lnn);
                             const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
-                            const double g0n = PC(bl, 0, hn.z), g1n = PC(bl, 1, hn.z), g2n = PC(bl, 2, hn.z);
+                            const double g0n = PC(bl, 0, lnn), g1n = PC(bl, 1, lnn), g2n = PC(bl, 2, lnn);
                             double A1[12], B1[6];
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
                             jac_point(A1, &sm.Rt[12 * k1], B1);
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                                 for (int c = r; c < 6; ++c) acc[6 * r + c] += m0 * A1[c] + m1 * A1[6 + c];
                             }
-                            ra = ran; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn; g0 = g0n; g1 = g1n; g2 = g2n;
+                            ra = ran; Da = Dan; Db = Dbn; Dc = Dcn; lnn = lnnn; g0 = g0n; g1 = g1n; g2 = g2n;
                         }
                         }
 #pragma unroll
@@ -642,15 +646,15 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         const int jend = pair_ptr[p + 1];
                         int j = pair_ptr[p] + lane;
                         if (pair_ptr[p] < jend) {
-                        int4 h = hits[min(j, jend - 1)];
-                        int4 hn = hits[min(j + 64, jend - 1)];
-                        double4 ra = recA[h.x], rb = recA[h.y];
-                        const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.z);
+                        int2 h = hits[min(j, jend - 1)];
+                        int2 hn = hits[min(j + 64, jend - 1)];
+                        double4 ra = recA[h.x & 0xFFFF], rb = recA[(unsigned)h.x >> 16];
+                        const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.y);
                         double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
                         for (; j < jend; j += 64) {
-                            const int4 hnn = hits[min(j + 128, jend - 1)];
-                            const double4 ran = recA[hn.x], rbn = recA[hn.y];
-                            const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.z);
+                            const int2 hnn = hits[min(j + 128, jend - 1)];
+                            const double4 ran = recA[hn.x & 0xFFFF], rbn = recA[(unsigned)hn.x >> 16];
+                            const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.y);
                             const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
                             double A1[12], A2[12], B1[6], B2[6];
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
@@ -989,7 +993,7 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     const size_t o_kfptr = need; need += al((size_t)n_windows * (kMaxKf + 1) * 4);
     const size_t o_kfe = need; need += al(total_edge * 4);
     const size_t o_pp = need; need += al((size_t)n_windows * (kMaxPairs + 1) * 4);
-    const size_t o_hits = need; need += with_lm ? al(total_edge * kHitsPerEdge * 16) : 256;
+    const size_t o_hits = need; need += with_lm ? al(total_edge * kHitsPerEdge * 8) : 256;
     const size_t o_act = need; need += al(total_lm);
     const size_t o_eo = need; need += with_lm ? al(total_lm * kMaxKf) : 256;
     const size_t o_kpos = need; need += al(total_edge * 4);
