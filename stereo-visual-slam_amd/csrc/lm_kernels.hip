@@ -86,6 +86,40 @@ __device__ inline double wave_max(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
+// Sum N per-lane values over the 64 lanes of a wave with a halving butterfly: at every step a lane sends one half of its
+// values to its partner and keeps (and accumulates) the other half, so N values cost about N shuffles instead of 6 N.
+// On return v[0] holds the wave-wide sum of value wave_slot<N>(lane) (a fixed tree: deterministic).
+template <int N>
+__device__ inline void wave_reduce_scatter(double (&v)[N], int lane) {
+    int n = N;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const int h = (n + 1) / 2;
+        const bool upper = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+            const double a = v[i], b = (i + h < n) ? v[i + h] : 0.0;
+            const double send = upper ? a : b, keep = upper ? b : a;
+            v[i] = keep + __shfl_xor(send, m);
+        }
+        n = h;
+    }
+}
+// which of the N values lane `lane` ends up with (-1: none)
+template <int N>
+__device__ inline int wave_slot(int lane) {
+    int sizes[7];
+    sizes[0] = N;
+    for (int k = 1; k <= 6; ++k) sizes[k] = (sizes[k - 1] + 1) / 2;
+    int pos = 0;
+    bool ok = true;
+    for (int k = 6; k >= 1; --k) { // undo the steps, last first: step k used mask 64 >> k and half size sizes[k]
+        if (lane & (64 >> k)) pos += sizes[k];
+        if (pos >= sizes[k - 1]) ok = false;
+    }
+    return ok ? pos : -1;
+}
+
 // deterministic block sum: per-thread partial -> wave butterfly -> waves summed in order
 __device__ inline double block_sum(double v, double* red) {
     v = wave_sum(v);
@@ -244,6 +278,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const int npairs = nk * (nk + 1) / 2;
     const int nparts = nk == 1 ? kLmWaves : kPoseParts; // a pose's edge list is split over `nparts` waves
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int slot27 = wave_slot<27>(lane), slot36 = wave_slot<36>(lane); // which butterfly sum this lane ends up holding
     long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + 16 * (size_t)w : nullptr;
     long long t_ph = cyc ? clock64() : 0;
 #define PH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); cyc[i] += t1__ - t_ph; t_ph = t1__; } } while (0)
@@ -522,20 +557,20 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 const double2 rb = recB[j];
                 double A[12];
                 jac_pose(K, ra.x, ra.y, ra.z, A);
-                const double wg = ra.w, ex = rb.x, ey = rb.y;
+                const double ex = rb.x, ey = rb.y;
+                double wA[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) wA[i] = ra.w * A[i];
                 int idx = 0;
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
-                    for (int c = r; c < 6; ++c) acc[idx++] += wg * (A[r] * A[c] + A[6 + r] * A[6 + c]);
+                    for (int c = r; c < 6; ++c) { acc[idx] = fma(wA[r], A[c], fma(wA[6 + r], A[6 + c], acc[idx])); ++idx; }
 #pragma unroll
-                for (int r = 0; r < 6; ++r) acc[21 + r] -= wg * (A[r] * ex + A[6 + r] * ey);
+                for (int r = 0; r < 6; ++r) acc[21 + r] = fma(-wA[r], ex, fma(-wA[6 + r], ey, acc[21 + r]));
             }
-#pragma unroll
-            for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-            if (lane == 0)
-#pragma unroll
-                for (int i = 0; i < 27; ++i) sm.part[item * 27 + i] = acc[i];
+            wave_reduce_scatter<27>(acc, lane);
+            if (slot27 >= 0) sm.part[item * 27 + slot27] = acc[0];
         }
         __syncthreads();
         for (int t = tid; t < nk * 27; t += kLmBlock) { // parts summed in a fixed order
@@ -628,20 +663,33 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             for (int r = 0; r < 6; ++r) {
                                 const double m0 = A1[r] * M00 + A1[6 + r] * M01, m1 = A1[r] * M01 + A1[6 + r] * M11;
 #pragma unroll
-                                for (int c = r; c < 6; ++c) acc[6 * r + c] += m0 * A1[c] + m1 * A1[6 + c];
+                                for (int c = r; c < 6; ++c) acc[6 * r + c] = fma(m0, A1[c], fma(m1, A1[6 + c], acc[6 * r + c]));
                             }
                             ra = ran; Da = Dan; Db = Dbn; Dc = Dcn; lnn = lnnn; g0 = g0n; g1 = g1n; g2 = g2n;
                         }
                         }
+                        // 21 upper-triangle sums + the 6 right-hand-side sums, one value per lane after the butterfly
+                        double red[27];
+                        {
+                            int idx = 0;
 #pragma unroll
-                        for (int r = 1; r < 6; ++r)
+                            for (int r = 0; r < 6; ++r)
 #pragma unroll
-                            for (int c = 0; c < r; ++c) acc[6 * r + c] = acc[6 * c + r];
+                                for (int c = r; c < 6; ++c) red[idx++] = acc[6 * r + c];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) accb[r] = wave_sum(accb[r]);
-                        if (lane == 0)
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) sm.bs[6 * k1 + r] = sm.bp[6 * k1 + r] - accb[r];
+                            for (int r = 0; r < 6; ++r) red[21 + r] = accb[r];
+                        }
+                        wave_reduce_scatter<27>(red, lane);
+                        if (slot27 >= 21) sm.bs[6 * k1 + slot27 - 21] = sm.bp[6 * k1 + slot27 - 21] - red[0];
+                        else if (slot27 >= 0) {
+                            int r = 0, rem = slot27;
+                            while (rem >= 6 - r) { rem -= 6 - r; ++r; }
+                            const int c = r + rem;
+                            const double v = sm.Hpp[36 * k1 + 6 * r + c] + (r == c ? lambda : 0.0) - red[0];
+                            sm.S[(6 * k1 + r) * np + 6 * k1 + c] = v;
+                            sm.S[(6 * k1 + c) * np + 6 * k1 + r] = v;
+                        }
+                        continue;
                     } else {
                         const int jend = pair_ptr[p + 1];
                         int j = pair_ptr[p] + lane;
@@ -678,24 +726,17 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             for (int r = 0; r < 6; ++r) {
                                 const double m0 = A1[r] * M[0] + A1[6 + r] * M[2], m1 = A1[r] * M[1] + A1[6 + r] * M[3];
 #pragma unroll
-                                for (int c = 0; c < 6; ++c) acc[6 * r + c] += m0 * A2[c] + m1 * A2[6 + c];
+                                for (int c = 0; c < 6; ++c) acc[6 * r + c] = fma(m0, A2[c], fma(m1, A2[6 + c], acc[6 * r + c]));
                             }
                             ra = ran; rb = rbn; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
                         }
                         }
                     }
-#pragma unroll
-                    for (int i = 0; i < 36; ++i) acc[i] = wave_sum(acc[i]);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) {
-                                double v = -acc[6 * r + c];
-                                if (k1 == k2) v += sm.Hpp[36 * k1 + 6 * r + c] + (r == c ? lambda : 0.0);
-                                sm.S[(6 * k1 + r) * np + 6 * k2 + c] = v;
-                                if (k1 != k2) sm.S[(6 * k2 + c) * np + 6 * k1 + r] = v;
-                            }
+                    wave_reduce_scatter<36>(acc, lane);
+                    if (slot36 >= 0) {
+                        const int r = slot36 / 6, c = slot36 - 6 * r;
+                        sm.S[(6 * k1 + r) * np + 6 * k2 + c] = -acc[0];
+                        sm.S[(6 * k2 + c) * np + 6 * k1 + r] = -acc[0];
                     }
                 }
                 __syncthreads();
