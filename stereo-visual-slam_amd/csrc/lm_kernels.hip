@@ -762,6 +762,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                             for (int j = 0; j <= i; ++j) D[i * (i + 1) / 2 + j] = sm.S[(6 * J + i) * np + 6 * J + j];
                         bool good = true;
+                        double rd[6];
 #pragma unroll
                         for (int j = 0; j < 6; ++j) {
                             double d = D[j * (j + 1) / 2 + j];
@@ -770,12 +771,13 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             if (!(d > 0.0) || !isfinite(d)) good = false;
                             d = sqrt(d);
                             D[j * (j + 1) / 2 + j] = d;
+                            rd[j] = 1.0 / d; // one division per column; everything below multiplies
 #pragma unroll
                             for (int i = j + 1; i < 6; ++i) {
                                 double v = D[i * (i + 1) / 2 + j];
 #pragma unroll
                                 for (int kk = 0; kk < j; ++kk) v -= D[i * (i + 1) / 2 + kk] * D[j * (j + 1) / 2 + kk];
-                                D[i * (i + 1) / 2 + j] = v / d;
+                                D[i * (i + 1) / 2 + j] = v * rd[j];
                             }
                         }
                         double x[6];
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 double v = sm.S[row * np + 6 * J + c];
 #pragma unroll
                                 for (int kk = 0; kk < c; ++kk) v -= x[kk] * D[c * (c + 1) / 2 + kk];
-                                x[c] = v / D[c * (c + 1) / 2 + c];
+                                x[c] = v * rd[c];
                             }
                         }
                         if (tid == 0 && !good) sm.flag[1] = 1;
@@ -812,26 +814,50 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 __syncthreads();
                 if (tid == 0) sm.flag[1] = 0;
                 if (ok2) {
-                    // forward / backward substitution by wave 0 (column-oriented, no reductions)
+                    // forward / backward substitution by wave 0, blocked by pose: the 6x6 triangle is solved by every lane
+                    // redundantly in registers (no intra-block synchronisation), the rows outside the block are updated in parallel
                     if (wave == 0) {
                         for (int i = lane; i < np; i += 64) sm.xp[i] = sm.bs[i];
-                        for (int j = 0; j < np; ++j) {
-                            __builtin_amdgcn_wave_barrier();
-                            const double yj = sm.xp[j] / sm.S[j * np + j];
-                            __builtin_amdgcn_wave_barrier();
-                            for (int i = lane; i < np; i += 64) {
-                                if (i == j) sm.xp[i] = yj;
-                                else if (i > j) sm.xp[i] -= sm.S[i * np + j] * yj;
+                        __builtin_amdgcn_wave_barrier();
+                        for (int J = 0; J < nk; ++J) { // L y = bs
+                            double y[6];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) y[c] = sm.xp[6 * J + c];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) {
+#pragma unroll
+                                for (int kk = 0; kk < c; ++kk) y[c] -= sm.S[(6 * J + c) * np + 6 * J + kk] * y[kk];
+                                y[c] /= sm.S[(6 * J + c) * np + 6 * J + c];
                             }
+                            __builtin_amdgcn_wave_barrier(); // every lane has read xp[6J..] before it is overwritten
+                            if (lane < 6) sm.xp[6 * J + lane] = lane == 0 ? y[0] : lane == 1 ? y[1] : lane == 2 ? y[2] : lane == 3 ? y[3] : lane == 4 ? y[4] : y[5];
+                            for (int i = 6 * (J + 1) + lane; i < np; i += 64) {
+                                double v = sm.xp[i];
+#pragma unroll
+                                for (int c = 0; c < 6; ++c) v -= sm.S[i * np + 6 * J + c] * y[c];
+                                sm.xp[i] = v;
+                            }
+                            __builtin_amdgcn_wave_barrier();
                         }
-                        for (int j = np - 1; j >= 0; --j) {
-                            __builtin_amdgcn_wave_barrier();
-                            const double xj = sm.xp[j] / sm.S[j * np + j];
-                            __builtin_amdgcn_wave_barrier();
-                            for (int i = lane; i < np; i += 64) {
-                                if (i == j) sm.xp[i] = xj;
-                                else if (i < j) sm.xp[i] -= sm.S[j * np + i] * xj;
+                        for (int J = nk - 1; J >= 0; --J) { // L^T x = y
+                            double x[6];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) x[c] = sm.xp[6 * J + c];
+#pragma unroll
+                            for (int c = 5; c >= 0; --c) {
+#pragma unroll
+                                for (int kk = c + 1; kk < 6; ++kk) x[c] -= sm.S[(6 * J + kk) * np + 6 * J + c] * x[kk];
+                                x[c] /= sm.S[(6 * J + c) * np + 6 * J + c];
                             }
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < 6) sm.xp[6 * J + lane] = lane == 0 ? x[0] : lane == 1 ? x[1] : lane == 2 ? x[2] : lane == 3 ? x[3] : lane == 4 ? x[4] : x[5];
+                            for (int i = lane; i < 6 * J; i += 64) {
+                                double v = sm.xp[i];
+#pragma unroll
+                                for (int c = 0; c < 6; ++c) v -= sm.S[(6 * J + c) * np + i] * x[c];
+                                sm.xp[i] = v;
+                            }
+                            __builtin_amdgcn_wave_barrier();
                         }
                     }
                 } else {
