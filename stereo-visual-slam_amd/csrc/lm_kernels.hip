@@ -40,7 +40,7 @@ constexpr int kMaxKf = VSLAM_MAX_KF;
 constexpr int kMaxNp = 6 * kMaxKf;
 constexpr int kMaxPairs = kMaxKf * (kMaxKf + 1) / 2;
 constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
-constexpr int kLin = 8;        // doubles per edge of linearisation scratch: {X, Y, 1/Z, w} + {ex, ey} (+2 pad: 64-B aligned windows)
+constexpr int kLin = 12;       // doubles per edge of linearisation scratch: two sets of {X, Y, 1/Z, w} + {ex, ey} (current state / trial state)
 constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
 constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
 constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work items (keyframe pairs) per wave
@@ -284,8 +284,12 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #define PH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); cyc[i] += t1__ - t_ph; t_ph = t1__; } } while (0)
     // component-major (SoA) scratch: consecutive lanes touch consecutive addresses in every edge- or landmark-ordered loop
     // per-edge linearisation records, AoS so that gathers (by-pose lists, Schur hits) fetch one 32-B chunk per edge:
-    double4* recA = reinterpret_cast<double4*>(lin);                 // {X, Y, 1/Z, w}
-    double2* recB = reinterpret_cast<double2*>(lin + 4 * (size_t)ne); // {ex, ey}
+    // Two sets: every trial evaluation also records its state into the spare set; an accepted trial makes that set current,
+    // so the next iteration starts without re-evaluating the state it already evaluated.
+    double4* recA = reinterpret_cast<double4*>(lin);                       // {X, Y, 1/Z, w}
+    double4* recA_alt = reinterpret_cast<double4*>(lin + 4 * (size_t)ne);
+    double2* recB = reinterpret_cast<double2*>(lin + 8 * (size_t)ne);      // {ex, ey}
+    double2* recB_alt = reinterpret_cast<double2*>(lin + 10 * (size_t)ne);
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
     auto EKF = [&](int e) -> int { return IMPL ? 0 : kfi[e]; };
     auto ELM = [&](int e) -> int { return IMPL ? e : lmi[e]; };
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     }
     __syncthreads();
     if (!IMPL) {
+        PH(13);
         // ---- keyframe-major positions (ascending edge id inside a pose).  The per-edge linearisation records are STORED in this
         // order: pose-wise phases stream them, Schur hits of a keyframe pair read two nearly contiguous runs, and landmark-wise
         // phases stay coalesced because neighbouring landmarks (creation order) sit at neighbouring positions of the same pose.
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         }
         __syncthreads();
         if (with_lm) {
+            PH(14);
             // ---- per-landmark edge offset table eo[l][k] (0xFF = keyframe k does not see landmark l)
             for (int l = tid; l < nl; l += kLmBlock) {
                 uint32_t wds[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -446,6 +452,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     PH(0);
     // ------------------------------------------------------------------ LM iterations
     double lambda = 0, ni = 2, currentChi = 0;
+    bool have_lin = false;
     int it = 0, total_trials = 0;
     vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
 
@@ -456,7 +463,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const float2* uv2 = reinterpret_cast<const float2*>(uv);
     constexpr int kEvalU = 4;
     constexpr int kLmU = 2, kLmE = 4; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
-    auto eval = [&](const double* Rt, const double* Pcur, bool store_lin) -> double {
+    auto eval = [&](const double* Rt, const double* Pcur, double4* dstA, double2* dstB) -> double {
+        const bool store_lin = true;
         double part = 0;
         for (int base = tid; base < ne; base += kEvalU * kLmBlock) {
             int l[kEvalU], k[kEvalU], ps[kEvalU];
@@ -481,8 +489,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 chi2[base + u * kLmBlock] = c;
                 part += rho;
                 if (store_lin) {
-                    recA[ps[u]] = make_double4(X, Y, Zi, wgt);
-                    recB[ps[u]] = make_double2(ex, ey);
+                    dstA[ps[u]] = make_double4(X, Y, Zi, wgt);
+                    dstB[ps[u]] = make_double2(ex, ey);
                 }
             }
         }
@@ -490,7 +498,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     };
 
     for (it = 0; it < iters; ++it) {
-        currentChi = eval(sm.Rt, P, true);
+        if (!have_lin) currentChi = eval(sm.Rt, P, recA, recB); // (an accepted trial already evaluated and recorded this state)
+        have_lin = false;
         PH(1);
         if (it == 0 && st && tid == 0) st->chi2_init = currentChi;
         // ---- buildSystem: landmark blocks
@@ -942,7 +951,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             }
             const double scale = block_sum(scale_part, sm.red) + 1e-3;
             PH(9);
-            double tempChi = eval(sm.RtTrial, with_lm ? Pt : P, false);
+            double tempChi = eval(sm.RtTrial, with_lm ? Pt : P, recA_alt, recB_alt);
             PH(10);
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho_gain = (currentChi - tempChi) / scale;
@@ -957,6 +966,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = sm.TTrial[i];
                 for (int i = tid; i < nk * 12; i += kLmBlock) sm.Rt[i] = sm.RtTrial[i];
                 if (with_lm) { double* t = P; P = Pt; Pt = t; }
+                { double4* ta = recA; recA = recA_alt; recA_alt = ta; double2* tb = recB; recB = recB_alt; recB_alt = tb; have_lin = true; }
                 __syncthreads();
             } else {
                 lambda *= ni;
@@ -1110,7 +1120,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipStreamSynchronize(stream);
         std::vector<long long> h(16 * (size_t)a.n_windows);
         hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        static const char* names[15] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(schur hits w0)", "(schur reduce w0)"};
+        static const char* names[15] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)"};
         double tot = 0;
         for (int i = 0; i < 15; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
         fprintf(stderr, "  [lm profile] total %.0f ticks (clock64 = 100 MHz s_memtime units)\n", tot);
