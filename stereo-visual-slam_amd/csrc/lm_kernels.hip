@@ -59,6 +59,7 @@ struct LmShared {
     uint16_t cnt[kLmWaves * kCntStride];   // per-wave counters / running offsets of the list builders
     uint8_t item[kLmWaves * kItemSlots];   // Schur work items (pair << 1 | row half) dealt to waves, 0xFF = none
     uint8_t pk1[kCntStride], pk2[kCntStride];
+    int kfp[kMaxKf + 4];                   // kf_ptr (keyframe-major range starts), for the per-edge keyframe lookup
     int flag[8];
 };
 static_assert(kMaxKf * kPoseParts >= kLmWaves, "part[] must hold one slot per wave for single-pose problems");
@@ -73,6 +74,8 @@ struct LmKernelArgs {
     uint8_t* act;     // total_lm
     uint8_t* eo;      // total_lm x kMaxKf
     int32_t* kf_pos;  // total_edge
+    double* chi2k;    // total_edge: chi2 per edge in keyframe-major order (scattered to the caller's order at the end)
+    float* uvk;       // 2 x total_edge: observations in keyframe-major order
     int32_t* status;  // n_windows
     long long* dbg_cycles; // tuning aid (VSLAM_LM_PROFILE=1): 16 phase cycle counters per window, thread 0
     int dbg_skip;     // tuning aid (VSLAM_LM_SKIP): bit0 Schur hits, bit1 Cholesky, bit2 pose blocks, bit3 landmark blocks, bit4 eval, bit5 back-subst, bit6 setup lists
@@ -264,6 +267,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     double* db = a.db + 3 * (size_t)lm0;
     double* lin = a.lin + kLin * (size_t)e0;
     double* chi2 = a.chi2 + e0;
+    double* chi2k = IMPL ? chi2 : ka.chi2k + e0;                       // keyframe-major (identity for the single-pose problem)
+    float2* uvk2 = IMPL ? const_cast<float2*>(reinterpret_cast<const float2*>(uv)) : reinterpret_cast<float2*>(ka.uvk) + e0;
     int32_t* lm_ptr = a.lm_ptr + lm0 + w;
     int32_t* kf_ptr = a.kf_ptr + (size_t)w * (kMaxKf + 1);
     int32_t* kf_lm = a.kf_edges + e0;   // landmark of the edge stored at by-pose position j
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int kk = 0; kk < kMaxKf; ++kk) {
                     if (kk < nk) {
                         const unsigned long long m = __ballot(k == kk);
-                        if (pass && k == kk) { const int slot = run[kk] + __popcll(m & lt_mask); kf_pos[e] = slot; kf_lm[slot] = lmi[e]; }
+                        if (pass && k == kk) { const int slot = run[kk] + __popcll(m & lt_mask); kf_pos[e] = slot; kf_lm[slot] = lmi[e]; uvk2[slot] = reinterpret_cast<const float2*>(uv)[e]; }
                         run[kk] += __popcll(m);
                     }
                 }
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     kf_ptr[nk] = acc;
                 }
                 __syncthreads();
+                if (tid <= nk) sm.kfp[tid] = kf_ptr[tid];
             }
         }
         __syncthreads();
@@ -463,35 +469,36 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const float2* uv2 = reinterpret_cast<const float2*>(uv);
     constexpr int kEvalU = 4;
     constexpr int kLmU = 2, kLmE = 4; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
+    // Error evaluation at (Rt, Pcur), walking the edges in keyframe-major order: the landmark ids, observations, chi2 and
+    // the linearisation records {X, Y, 1/Z, w}, {ex, ey} are all streamed, only the landmark positions are gathered.
+    const int ntot = IMPL ? ne : sm.kfp[nk]; // active edges
     auto eval = [&](const double* Rt, const double* Pcur, double4* dstA, double2* dstB) -> double {
-        const bool store_lin = true;
         double part = 0;
-        for (int base = tid; base < ne; base += kEvalU * kLmBlock) {
-            int l[kEvalU], k[kEvalU], ps[kEvalU];
+        for (int base = tid; base < ntot; base += kEvalU * kLmBlock) {
+            int l[kEvalU], k[kEvalU];
             float2 z[kEvalU];
 #pragma unroll
             for (int u = 0; u < kEvalU; ++u) {
-                const int e = min(base + u * kLmBlock, ne - 1);
-                l[u] = ELM(e); k[u] = EKF(e); z[u] = uv2[e]; ps[u] = store_lin ? POS(e) : 0;
+                const int j = min(base + u * kLmBlock, ntot - 1);
+                l[u] = IMPL ? j : kf_lm[j]; z[u] = uvk2[j];
+                int kk = 0;
+                if (!IMPL)
+                    for (int q = 1; q < nk; ++q) kk += j >= sm.kfp[q];
+                k[u] = kk;
             }
             double px[kEvalU], py[kEvalU], pz[kEvalU];
-            bool on[kEvalU];
+#pragma unroll
+            for (int u = 0; u < kEvalU; ++u) { px[u] = PC(Pcur, 0, l[u]); py[u] = PC(Pcur, 1, l[u]); pz[u] = PC(Pcur, 2, l[u]); }
 #pragma unroll
             for (int u = 0; u < kEvalU; ++u) {
-                on[u] = act[l[u]] != 0 && base + u * kLmBlock < ne;
-                px[u] = PC(Pcur, 0, l[u]); py[u] = PC(Pcur, 1, l[u]); pz[u] = PC(Pcur, 2, l[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < kEvalU; ++u) {
-                if (!on[u]) continue;
+                const int j = base + u * kLmBlock;
+                if (j >= ntot) continue;
                 double X, Y, Zi, wgt, ex, ey, c, rho;
                 lin_record(&Rt[12 * k[u]], K, px[u], py[u], pz[u], z[u], delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
-                chi2[base + u * kLmBlock] = c;
+                chi2k[j] = c;
                 part += rho;
-                if (store_lin) {
-                    dstA[ps[u]] = make_double4(X, Y, Zi, wgt);
-                    dstB[ps[u]] = make_double2(ex, ey);
-                }
+                dstA[j] = make_double4(X, Y, Zi, wgt);
+                dstB[j] = make_double2(ex, ey);
             }
         }
         return block_sum(part, sm.red);
@@ -987,9 +994,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         double th = 5.991;
         for (int iteration = 0; iteration < 5; ++iteration) {
             double out = 0, in = 0;
-            for (int e = tid; e < ne; e += kLmBlock) {
-                if (!act[lmi[e]]) continue;
-                if (chi2[e] > th) out += 1; else in += 1;
+            for (int j = tid; j < ntot; j += kLmBlock) {
+                if (chi2k[j] > th) out += 1; else in += 1;
             }
             out = block_sum(out, sm.red);
             in = block_sum(in, sm.red);
@@ -998,12 +1004,14 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             th *= 2;
         }
         for (int l = tid; l < nl; l += kLmBlock)
-            if (act[l]) a.lm_inlier[lm0 + l] = !(chi2[lm_ptr[l + 1] - 1] > th); // last edge of the landmark wins (ascending edge order)
+            if (act[l]) a.lm_inlier[lm0 + l] = !(chi2k[kf_pos[lm_ptr[l + 1] - 1]] > th); // last edge of the landmark wins (ascending edge order)
         if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
     }
     // ------------------------------------------------------------------ write-back (:272-287, :429-435)
     __syncthreads();
     if (update_poses) for (int i = tid; i < nk * 7; i += kLmBlock) a.T[(size_t)w * nk * 7 + i] = sm.T[i];
+    if (!IMPL) // chi2 back to the caller's edge order (edges of excluded landmarks: 0)
+        for (int e = tid; e < ne; e += kLmBlock) chi2[e] = act[lmi[e]] ? chi2k[kf_pos[e]] : 0.0;
     if (with_lm && update_lms)
         for (int l = tid; l < nl; l += kLmBlock)
             if (act[l]) { a.xyz[3 * ((size_t)lm0 + l)] = (float)PC(P, 0, l); a.xyz[3 * ((size_t)lm0 + l) + 1] = (float)PC(P, 1, l); a.xyz[3 * ((size_t)lm0 + l) + 2] = (float)PC(P, 2, l); }
@@ -1076,6 +1084,8 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     const size_t o_kpos = need; need += al(total_edge * 4);
     const size_t o_st = need; need += al((size_t)n_windows * 4);
     const size_t o_chi = need; need += al(total_edge * 8);
+    const size_t o_chik = need; need += al(total_edge * 8);
+    const size_t o_uvk = need; need += al(total_edge * 8);
     // hipFree/hipMalloc are synchronising; growth only happens on the first call of a given size
     if (g_lm.bytes < need) { hipStreamSynchronize(stream); int rc = ensure(&g_lm.buf, &g_lm.bytes, need); if (rc) return rc; }
     uint8_t* base = (uint8_t*)g_lm.buf;
@@ -1086,6 +1096,7 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     ka.act = base + o_act; ka.eo = base + o_eo; ka.kf_pos = (int32_t*)(base + o_kpos); ka.status = (int32_t*)(base + o_st);
     g_lm.status = ka.status; g_lm.status_n = n_windows;
     if (!ka.a.chi2) ka.a.chi2 = (double*)(base + o_chi);
+    ka.chi2k = (double*)(base + o_chik); ka.uvk = (float*)(base + o_uvk);
     return VSLAM_OK;
 }
 
