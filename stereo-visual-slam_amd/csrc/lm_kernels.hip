@@ -40,7 +40,7 @@ constexpr int kMaxKf = VSLAM_MAX_KF;
 constexpr int kMaxNp = 6 * kMaxKf;
 constexpr int kMaxPairs = kMaxKf * (kMaxKf + 1) / 2;
 constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
-constexpr int kLin = 12;       // doubles per edge of linearisation scratch: two sets of {X, Y, 1/Z, w} + {ex, ey} (current state / trial state)
+constexpr int kLin = 8;        // doubles per edge of linearisation scratch: two sets of {X, Y, 1/Z, w} (current state / trial state)
 constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
 constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
 constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work items (keyframe pairs) per wave
@@ -49,8 +49,8 @@ size_t lm_hits_per_edge() { return kHitsPerEdge; }
 
 struct LmShared {
     double S[kMaxNp * kMaxNp];
-    double Hpp[kMaxKf * 36];
-    double bp[kMaxNp], bs[kMaxNp], xp[kMaxNp];
+    double Hpp[kMaxKf * 36], HppT[kMaxKf * 36]; // pose blocks at the current state / at the state of the latest trial
+    double bp[kMaxNp], bpT[kMaxNp], bs[kMaxNp], xp[kMaxNp];
     double Rt[kMaxKf * 12], RtTrial[kMaxKf * 12];
     double T[kMaxKf * 7], TTrial[kMaxKf * 7];
     double red[kLmWaves * 2];
@@ -293,8 +293,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // so the next iteration starts without re-evaluating the state it already evaluated.
     double4* recA = reinterpret_cast<double4*>(lin);                       // {X, Y, 1/Z, w}
     double4* recA_alt = reinterpret_cast<double4*>(lin + 4 * (size_t)ne);
-    double2* recB = reinterpret_cast<double2*>(lin + 8 * (size_t)ne);      // {ex, ey}
-    double2* recB_alt = reinterpret_cast<double2*>(lin + 10 * (size_t)ne);
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
     auto EKF = [&](int e) -> int { return IMPL ? 0 : kfi[e]; };
     auto ELM = [&](int e) -> int { return IMPL ? e : lmi[e]; };
@@ -469,18 +467,77 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const float2* uv2 = reinterpret_cast<const float2*>(uv);
     constexpr int kEvalU = 4;
     constexpr int kLmU = 2, kLmE = 4; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
-    // Error evaluation at (Rt, Pcur), walking the edges in keyframe-major order: the landmark ids, observations, chi2 and
-    // the linearisation records {X, Y, 1/Z, w}, {ex, ey} are all streamed, only the landmark positions are gathered.
+    // Evaluation + linearisation at (Rt, Pcur) in one keyframe-major pass.  item = (pose, part): a wave streams its share of
+    // the pose's edge list (landmark ids and observations two steps ahead, landmark positions one step ahead), writes the
+    // records {X, Y, 1/Z, w} for the Schur phase and accumulates the pose blocks (H_pp upper triangle, b_p) on the fly, so the
+    // errors never have to be stored.  Returns the robust chi2.  Trial states go through the same pass into the spare
+    // buffers: an accepted trial is already linearised.
     const int ntot = IMPL ? ne : sm.kfp[nk]; // active edges
-    auto eval = [&](const double* Rt, const double* Pcur, double4* dstA, double2* dstB) -> double {
+    auto LMJ = [&](int j) -> int { return IMPL ? j : kf_lm[j]; };
+    auto eval = [&](const double* Rt, const double* Pcur, double4* dstA, double* Hdst, double* bdst) -> double {
         double part = 0;
+        for (int item = wave; item < nk * nparts; item += kLmWaves) {
+            const int k = item / nparts, pt = item - k * nparts;
+            double acc[27];
+#pragma unroll
+            for (int i = 0; i < 27; ++i) acc[i] = 0;
+            const int b0 = IMPL ? 0 : sm.kfp[k], b1 = IMPL ? ne : sm.kfp[k + 1];
+            const int s0 = b0 + (int)((long long)(b1 - b0) * pt / nparts), s1 = b0 + (int)((long long)(b1 - b0) * (pt + 1) / nparts);
+            if (s0 < s1) {
+                const double* R = &Rt[12 * k];
+                const int jl = s1 - 1;
+                int j = s0 + lane;
+                int l1 = LMJ(min(j, jl)), l2 = LMJ(min(j + 64, jl));
+                float2 z1 = uvk2[min(j, jl)], z2 = uvk2[min(j + 64, jl)];
+                double px = PC(Pcur, 0, l1), py = PC(Pcur, 1, l1), pz = PC(Pcur, 2, l1);
+                for (; j < s1; j += 64) {
+                    const int l3 = LMJ(min(j + 128, jl));
+                    const float2 z3 = uvk2[min(j + 128, jl)];
+                    const double pxn = PC(Pcur, 0, l2), pyn = PC(Pcur, 1, l2), pzn = PC(Pcur, 2, l2);
+                    double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
+                    lin_record(R, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
+                    part += rho;
+                    dstA[j] = make_double4(X, Y, Zi, wgt);
+                    jac_pose(K, X, Y, Zi, A);
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
+                    int idx = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int cc = r; cc < 6; ++cc) { acc[idx] = fma(wA[r], A[cc], fma(wA[6 + r], A[6 + cc], acc[idx])); ++idx; }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc[21 + r] = fma(-wA[r], ex, fma(-wA[6 + r], ey, acc[21 + r]));
+                    px = pxn; py = pyn; pz = pzn; l2 = l3; z1 = z2; z2 = z3;
+                }
+            }
+            wave_reduce_scatter<27>(acc, lane);
+            if (slot27 >= 0) sm.part[item * 27 + slot27] = acc[0];
+        }
+        const double total = block_sum(part, sm.red); // (its barriers also publish sm.part)
+        for (int t = tid; t < nk * 27; t += kLmBlock) { // parts summed in a fixed order
+            const int k = t / 27, i = t - k * 27;
+            double v = 0;
+            for (int pp = 0; pp < nparts; ++pp) v += sm.part[(k * nparts + pp) * 27 + i];
+            if (i < 21) {
+                int r = 0, rem = i;
+                while (rem >= 6 - r) { rem -= 6 - r; ++r; }
+                const int c = r + rem;
+                Hdst[36 * k + 6 * r + c] = v; Hdst[36 * k + 6 * c + r] = v;
+            } else bdst[6 * k + i - 21] = v;
+        }
+        __syncthreads();
+        return total;
+    };
+    // chi2 of every active edge at (Rt, Pcur), keyframe-major: only needed once, for the classification / the caller
+    auto chi_pass = [&](const double* Rt, const double* Pcur) {
         for (int base = tid; base < ntot; base += kEvalU * kLmBlock) {
             int l[kEvalU], k[kEvalU];
             float2 z[kEvalU];
 #pragma unroll
             for (int u = 0; u < kEvalU; ++u) {
                 const int j = min(base + u * kLmBlock, ntot - 1);
-                l[u] = IMPL ? j : kf_lm[j]; z[u] = uvk2[j];
+                l[u] = LMJ(j); z[u] = uvk2[j];
                 int kk = 0;
                 if (!IMPL)
                     for (int q = 1; q < nk; ++q) kk += j >= sm.kfp[q];
@@ -493,19 +550,17 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             for (int u = 0; u < kEvalU; ++u) {
                 const int j = base + u * kLmBlock;
                 if (j >= ntot) continue;
-                double X, Y, Zi, wgt, ex, ey, c, rho;
-                lin_record(&Rt[12 * k[u]], K, px[u], py[u], pz[u], z[u], delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
-                chi2k[j] = c;
-                part += rho;
-                dstA[j] = make_double4(X, Y, Zi, wgt);
-                dstB[j] = make_double2(ex, ey);
+                double X, Y, Z, ex, ey;
+                project_err(&Rt[12 * k[u]], K, px[u], py[u], pz[u], z[u].x, z[u].y, X, Y, Z, ex, ey);
+                chi2k[j] = ex * ex + ey * ey;
             }
         }
-        return block_sum(part, sm.red);
+        __syncthreads();
     };
+    bool last_trial_is_current = true; // g2o leaves the edge errors of the LAST EVALUATED trial behind (accepted or not)
 
     for (it = 0; it < iters; ++it) {
-        if (!have_lin) currentChi = eval(sm.Rt, P, recA, recB); // (an accepted trial already evaluated and recorded this state)
+        if (!have_lin) currentChi = eval(sm.Rt, P, recA, sm.Hpp, sm.bp); // (an accepted trial already evaluated and linearised this state)
         have_lin = false;
         PH(1);
         if (it == 0 && st && tid == 0) st->chi2_init = currentChi;
@@ -560,47 +615,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             }
         }
         PH(2);
-        // ---- buildSystem: pose blocks.  item = (pose, part): one wave sums a third of the pose's edge list
-        for (int item = wave; item < nk * nparts; item += kLmWaves) {
-            const int k = item / nparts, part = item - k * nparts;
-            double acc[27];
-#pragma unroll
-            for (int i = 0; i < 27; ++i) acc[i] = 0;
-            const int b0 = IMPL ? 0 : kf_ptr[k], b1 = IMPL ? ne : kf_ptr[k + 1];
-            const int s0 = b0 + (int)((long long)(b1 - b0) * part / nparts), s1 = b0 + (int)((long long)(b1 - b0) * (part + 1) / nparts);
-            for (int j = s0 + lane; j < s1; j += 64) {
-                const double4 ra = recA[j];
-                const double2 rb = recB[j];
-                double A[12];
-                jac_pose(K, ra.x, ra.y, ra.z, A);
-                const double ex = rb.x, ey = rb.y;
-                double wA[12];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) wA[i] = ra.w * A[i];
-                int idx = 0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = r; c < 6; ++c) { acc[idx] = fma(wA[r], A[c], fma(wA[6 + r], A[6 + c], acc[idx])); ++idx; }
-#pragma unroll
-                for (int r = 0; r < 6; ++r) acc[21 + r] = fma(-wA[r], ex, fma(-wA[6 + r], ey, acc[21 + r]));
-            }
-            wave_reduce_scatter<27>(acc, lane);
-            if (slot27 >= 0) sm.part[item * 27 + slot27] = acc[0];
-        }
-        __syncthreads();
-        for (int t = tid; t < nk * 27; t += kLmBlock) { // parts summed in a fixed order
-            const int k = t / 27, i = t - k * 27;
-            double v = 0;
-            for (int part = 0; part < nparts; ++part) v += sm.part[(k * nparts + part) * 27 + i];
-            if (i < 21) {
-                int r = 0, rem = i;
-                while (rem >= 6 - r) { rem -= 6 - r; ++r; }
-                const int c = r + rem;
-                sm.Hpp[36 * k + 6 * r + c] = v; sm.Hpp[36 * k + 6 * c + r] = v;
-            } else sm.bp[6 * k + i - 21] = v;
-        }
-        __syncthreads();
         PH(3);
         if (it == 0) { // computeLambdaInit: tau * max |H_jj| over every vertex
             if (tid < np) maxdiag = fmax(maxdiag, fabs(sm.Hpp[36 * (tid / 6) + 7 * (tid % 6)]));
@@ -958,7 +972,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             }
             const double scale = block_sum(scale_part, sm.red) + 1e-3;
             PH(9);
-            double tempChi = eval(sm.RtTrial, with_lm ? Pt : P, recA_alt, recB_alt);
+            double tempChi = eval(sm.RtTrial, with_lm ? Pt : P, recA_alt, sm.HppT, sm.bpT);
+            last_trial_is_current = false;
             PH(10);
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho_gain = (currentChi - tempChi) / scale;
@@ -973,7 +988,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = sm.TTrial[i];
                 for (int i = tid; i < nk * 12; i += kLmBlock) sm.Rt[i] = sm.RtTrial[i];
                 if (with_lm) { double* t = P; P = Pt; Pt = t; }
-                { double4* ta = recA; recA = recA_alt; recA_alt = ta; double2* tb = recB; recB = recB_alt; recB_alt = tb; have_lin = true; }
+                { double4* ta = recA; recA = recA_alt; recA_alt = ta; have_lin = true; last_trial_is_current = true; }
+                for (int i = tid; i < nk * 36; i += kLmBlock) sm.Hpp[i] = sm.HppT[i];
+                for (int i = tid; i < np; i += kLmBlock) sm.bp[i] = sm.bpT[i];
                 __syncthreads();
             } else {
                 lambda *= ni;
@@ -989,6 +1006,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     if (st && tid == 0) { st->iterations = it; st->total_trials = total_trials; st->chi2_final = currentChi; st->lambda_final = lambda; }
 
     PH(11);
+    if (last_trial_is_current) chi_pass(sm.Rt, P); else chi_pass(sm.RtTrial, with_lm ? Pt : P);
     // ------------------------------------------------------------------ chi2 classification (optimization.cpp:224-266)
     if (classify && !IMPL) {
         double th = 5.991;
