@@ -56,7 +56,7 @@ struct LmShared {
     double red[kLmWaves * 2];
     double part[kMaxKf * kPoseParts * 27]; // per (pose, part) partial sums of the pose blocks
     int ptot[kCntStride];                  // hits per keyframe pair
-    uint16_t cnt[kLmWaves * kCntStride];   // per-wave counters / running offsets of the list builders
+    int cnt[kLmWaves * kCntStride];        // per-wave counters / running offsets of the list builders
     uint8_t item[kLmWaves * kItemSlots];   // Schur work items (pair << 1 | row half) dealt to waves, 0xFF = none
     uint8_t pk1[kCntStride], pk2[kCntStride];
     int kfp[kMaxKf + 4];                   // kf_ptr (keyframe-major range starts), for the per-edge keyframe lookup
@@ -349,15 +349,23 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             int run[kMaxKf];
 #pragma unroll
             for (int kk = 0; kk < kMaxKf; ++kk) run[kk] = pass ? (int)sm.cnt[wave * kCntStride + kk] : 0;
+            // landmark / keyframe ids are requested two batches ahead, the activity flag (a dependent gather) one batch ahead
+            const int el = max(e_hi - 1, 0);
+            int l1 = lmi[min(e_lo + lane, el)], l2 = lmi[min(e_lo + lane + 64, el)];
+            int k1v = kfi[min(e_lo + lane, el)], k2v = kfi[min(e_lo + lane + 64, el)];
+            int a1 = act[l1];
             for (int base = e_lo; base < e_hi; base += 64) {
                 const int e = base + lane;
-                int k = -1;
-                if (e < e_hi && act[lmi[e]]) k = kfi[e];
+                const int l3 = lmi[min(e + 128, el)], k3v = kfi[min(e + 128, el)];
+                const int a2 = act[l2];
+                const int k = (e < e_hi && a1) ? k1v : -1;
+                const int lcur = l1;
+                l1 = l2; l2 = l3; k1v = k2v; k2v = k3v; a1 = a2;
 #pragma unroll
                 for (int kk = 0; kk < kMaxKf; ++kk) {
                     if (kk < nk) {
                         const unsigned long long m = __ballot(k == kk);
-                        if (pass && k == kk) { const int slot = run[kk] + __popcll(m & lt_mask); kf_pos[e] = slot; kf_lm[slot] = lmi[e]; uvk2[slot] = reinterpret_cast<const float2*>(uv)[e]; }
+                        if (pass && k == kk) { const int slot = run[kk] + __popcll(m & lt_mask); kf_pos[e] = slot; kf_lm[slot] = lcur; uvk2[slot] = reinterpret_cast<const float2*>(uv)[e]; }
                         run[kk] += __popcll(m);
                     }
                 }
@@ -382,50 +390,70 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         __syncthreads();
         if (with_lm) {
             PH(14);
-            // ---- per-landmark edge offset table eo[l][k] (0xFF = keyframe k does not see landmark l)
-            for (int l = tid; l < nl; l += kLmBlock) {
-                uint32_t wds[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                if (act[l]) {
-                    const int b0 = lm_ptr[l], b1 = lm_ptr[l + 1];
-                    for (int e = b0; e < b1; ++e) {
-                        const int k = kfi[e];
-                        const uint32_t cur = (wds[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                        if (cur != 0xFFu || e - b0 >= 0xFF) sm.flag[7] = 2; // duplicate (keyframe, landmark) edge
-                        wds[k >> 2] = (wds[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)(e - b0) << (8 * (k & 3)));
-                    }
-                }
-                uint32_t* dst = reinterpret_cast<uint32_t*>(eo + (size_t)l * kMaxKf);
-                dst[0] = wds[0]; dst[1] = wds[1]; dst[2] = wds[2];
-            }
+            // ---- Schur hit lists per off-diagonal keyframe pair, landmark-ordered: wave = contiguous landmark range, 2 passes
+            // (count, then write).  A lane packs the 16-bit record position of its landmark in every keyframe into six words
+            // (0xFFFF = not observed); the pair loop is unrolled over compile-time (k1, k2), so the membership tests are register
+            // bit-field compares and the per-pair running offsets stay in registers.
             for (int i = tid; i < kLmWaves * kCntStride; i += kLmBlock) sm.cnt[i] = 0;
             __syncthreads();
-            if (sm.flag[7]) { if (tid == 0) ka.status[w] = VSLAM_ERR_ARG; return; }
-            // ---- Schur hit lists per keyframe pair, landmark-ordered: wave = contiguous landmark range, 2 passes
             const int l_lo = (int)((long long)nl * wave / kLmWaves), l_hi = (int)((long long)nl * (wave + 1) / kLmWaves);
             for (int pass = 0; pass < 2; ++pass) {
+                int run[kMaxKf * (kMaxKf - 1) / 2];
+                {
+                    int idx = 0;
+#pragma unroll
+                    for (int K1 = 0; K1 < kMaxKf - 1; ++K1)
+#pragma unroll
+                        for (int K2 = K1 + 1; K2 < kMaxKf; ++K2) {
+                            run[idx] = (pass && K2 < nk) ? (int)sm.cnt[wave * kCntStride + K1 * nk - K1 * (K1 - 1) / 2 + (K2 - K1)] : 0;
+                            ++idx;
+                        }
+                }
                 for (int base = l_lo; base < l_hi; base += 64) {
                     const int l = base + lane;
-                    uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu;
-                    int eb0 = 0;
-                    if (l < l_hi) {
-                        const uint32_t* src = reinterpret_cast<const uint32_t*>(eo + (size_t)l * kMaxKf);
-                        w0 = src[0]; w1 = src[1]; w2 = src[2];
-                        eb0 = lm_ptr[l];
+                    uint32_t w6[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                    if (l < l_hi && act[l]) {
+                        const int b0 = lm_ptr[l], b1 = lm_ptr[l + 1];
+                        auto put = [&](int k, int ps) {
+                            const int wi = k >> 1, sh = 16 * (k & 1);
+#pragma unroll
+                            for (int i = 0; i < 6; ++i)
+                                if (i == wi) {
+                                    if (((w6[i] >> sh) & 0xFFFFu) != 0xFFFFu) sm.flag[7] = 2; // duplicate (keyframe, landmark) edge
+                                    w6[i] = (w6[i] & ~(0xFFFFu << sh)) | ((uint32_t)ps << sh);
+                                }
+                        };
+                        int kq[4], pq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { const int e = min(b0 + q, ne - 1); kq[q] = kfi[e]; pq[q] = kf_pos[e]; }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (b0 + q < b1) put(kq[q], pq[q]);
+                        for (int e = b0 + 4; e < b1; ++e) put(kfi[e], kf_pos[e]);
                     }
-                    for (int p = 0; p < npairs; ++p) {
-                        const int k1 = sm.pk1[p], k2 = sm.pk2[p];
-                        if (k1 == k2) continue; // the diagonal pass streams the keyframe's own record list
-                        const uint32_t wa = k1 < 4 ? w0 : (k1 < 8 ? w1 : w2), wb = k2 < 4 ? w0 : (k2 < 8 ? w1 : w2);
-                        const uint32_t o1 = (wa >> (8 * (k1 & 3))) & 0xFFu, o2 = (wb >> (8 * (k2 & 3))) & 0xFFu;
-                        const bool hit = o1 != 0xFFu && o2 != 0xFFu;
-                        const unsigned long long m = __ballot(hit);
-                        if (m == 0) continue; // uniform
-                        const int cur = sm.cnt[wave * kCntStride + p];
-                        if (pass && hit) hits[cur + __popcll(m & lt_mask)] = make_int2(kf_pos[eb0 + (int)o1] | (kf_pos[eb0 + (int)o2] << 16), l);
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane == 0) sm.cnt[wave * kCntStride + p] = (uint16_t)0 + cur + __popcll(m);
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                    int idx = 0;
+#pragma unroll
+                    for (int K1 = 0; K1 < kMaxKf - 1; ++K1)
+#pragma unroll
+                        for (int K2 = K1 + 1; K2 < kMaxKf; ++K2) {
+                            if (K2 < nk) { // uniform
+                                const uint32_t f1 = (w6[K1 >> 1] >> (16 * (K1 & 1))) & 0xFFFFu, f2 = (w6[K2 >> 1] >> (16 * (K2 & 1))) & 0xFFFFu;
+                                const bool hit = f1 != 0xFFFFu && f2 != 0xFFFFu;
+                                const unsigned long long m = __ballot(hit);
+                                if (pass && hit) hits[run[idx] + __popcll(m & lt_mask)] = make_int2((int)(f1 | (f2 << 16)), l);
+                                run[idx] += __popcll(m);
+                            }
+                            ++idx;
+                        }
+                }
+                if (!pass && lane == 0) {
+                    int idx = 0;
+#pragma unroll
+                    for (int K1 = 0; K1 < kMaxKf - 1; ++K1)
+#pragma unroll
+                        for (int K2 = K1 + 1; K2 < kMaxKf; ++K2) {
+                            if (K2 < nk) sm.cnt[wave * kCntStride + K1 * nk - K1 * (K1 - 1) / 2 + (K2 - K1)] = run[idx];
+                            ++idx;
+                        }
                 }
                 if (!pass) {
                     __syncthreads();
@@ -437,6 +465,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     __syncthreads();
                 }
             }
+            if (sm.flag[7]) { if (tid == 0) ka.status[w] = VSLAM_ERR_ARG; return; } // (uniform: read after the barriers of the list build)
             // ---- balance the Schur work: item = keyframe pair; rank by hit count, deal ranks to waves in snake order
             const int nitems = npairs;
             for (int i = tid; i < kLmWaves * kItemSlots; i += kLmBlock) sm.item[i] = 0xFF;
