@@ -212,7 +212,7 @@ typedef struct vslam_ba_batch {
     const int32_t* d_kf_idx;      /* total_edge */
     const int32_t* d_lm_idx;      /* total_edge, window-local */
     const float* d_uv;            /* total_edge x 2 */
-    double* d_chi2;               /* total_edge, out (last pass) */
+    double* d_chi2;               /* total_edge, out (last pass), caller's edge order; NULL = not wanted */
     vslam_lm_stats* d_stats;      /* n_windows (last pass) or NULL */
     int32_t total_lm, total_edge;
 } vslam_ba_batch;

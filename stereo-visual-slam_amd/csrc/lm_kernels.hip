@@ -78,6 +78,7 @@ struct LmKernelArgs {
     float* uvk;       // 2 x total_edge: observations in keyframe-major order
     int32_t* status;  // n_windows
     long long* dbg_cycles; // tuning aid (VSLAM_LM_PROFILE=1): 16 phase cycle counters per window, thread 0
+    int want_chi2;    // the caller passed a chi2 output array: scatter chi2 back to its edge order at the end
     int dbg_skip;     // tuning aid (VSLAM_LM_SKIP): bit0 Schur hits, bit1 Cholesky, bit2 pose blocks, bit3 landmark blocks, bit4 eval, bit5 back-subst, bit6 setup lists
 };
 
@@ -1057,7 +1058,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // ------------------------------------------------------------------ write-back (:272-287, :429-435)
     __syncthreads();
     if (update_poses) for (int i = tid; i < nk * 7; i += kLmBlock) a.T[(size_t)w * nk * 7 + i] = sm.T[i];
-    if (!IMPL) // chi2 back to the caller's edge order (edges of excluded landmarks: 0)
+    if (!IMPL && ka.want_chi2) // chi2 back to the caller's edge order (edges of excluded landmarks: 0)
         for (int e = tid; e < ne; e += kLmBlock) chi2[e] = act[lmi[e]] ? chi2k[kf_pos[e]] : 0.0;
     if (with_lm && update_lms)
         for (int l = tid; l < nl; l += kLmBlock)
@@ -1154,6 +1155,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     LmKernelArgs ka;
     memset(&ka, 0, sizeof(ka));
     ka.a = a;
+    ka.want_chi2 = a.chi2 != nullptr;
     { const char* e = getenv("VSLAM_LM_SKIP"); ka.dbg_skip = e ? atoi(e) : 0; }
     static long long* d_cyc = nullptr; static int cyc_n = 0;
     if (getenv("VSLAM_LM_PROFILE")) {

@@ -102,7 +102,8 @@ class KeyframePipeline:
             bb.d_lm_off = self.ba_lm_off.data_ptr(); bb.d_edge_off = self.ba_e_off.data_ptr(); bb.d_T_c_w = self.ba_T.data_ptr()
             bb.d_xyz = self.ba_xyz.data_ptr(); bb.d_reliable = None; bb.d_lm_inlier = self.ba_inl.data_ptr()
             bb.d_kf_idx = self.ba_kf.data_ptr(); bb.d_lm_idx = self.ba_lm.data_ptr(); bb.d_uv = self.ba_uv.data_ptr()
-            bb.d_chi2 = self.ba_chi2.data_ptr(); bb.d_stats = None; bb.total_lm = self.total_lm; bb.total_edge = self.total_edge
+            bb.d_chi2 = None; bb.d_stats = None  # per-edge chi2 is internal to optimize_map, not one of its outputs
+            bb.total_lm = self.total_lm; bb.total_edge = self.total_edge
             self.ba_batch = bb
         torch.cuda.synchronize(self.dev)
 
