@@ -8,57 +8,141 @@
 //   step (i)  : key = d << 16 | i   -> min over i  = smallest d, then smallest i   (first minimum)
 //   step (ii) : key = d << 16 | j   -> min over {j : i*(j) = i} = smallest d, then smallest j (strict '<').
 //
-// gfx950 mapping: one lane owns one train descriptor (8 dwords in VGPRs); query descriptors are staged through
-// LDS in 16-B slots and broadcast-read (all lanes read the same address: conflict-free); distance =
-// 8 x (v_xor_b32 + v_bcnt_u32_b32 accumulate).  Integer work only: HBM/LDS-issue bound, no MFMA.
+// gfx950 mapping.  The all-pairs Hamming table is the one dense contraction of the pipeline: with the descriptor bits
+// recoded as +-1 bytes, <a, b> = 256 - 2 hamming(a, b), so a 32 x 32 block of distances is eight
+// v_mfma_i32_32x32x32_i8 (exact integer arithmetic).  `match_expand_kernel` writes the +-1 form (256 B per row) once per
+// call; `match_train_nearest_kernel` keeps 64 train columns per wave resident in VGPRs as MFMA B operands, streams
+// 32-row query tiles through LDS (row stride 272 B: conflict-free ds_read_b128) and folds the column minima in the
+// accumulator layout (column = lane % 32): per value one v_lshl_add + one v_max on packed keys, with the +256 bias
+// supplied as the MFMA C operand.  The previous v_xor + v_bcnt formulation was bound by v_bcnt_u32_b32 issuing at quarter rate.
 #include "vslam_internal.h"
 
 namespace vslam {
 
-constexpr int kMatchBlock = 256;
-constexpr int kQTile = 128; // queries staged per LDS tile (4 KiB)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---- descriptors (32 B) -> 256 bytes of +-1 (bit k set -> -1, clear -> +1); one dword (32 output bytes) per thread
+__global__ __launch_bounds__(256) void match_expand_kernel(const uint8_t* __restrict__ d_q, size_t q_stride, const int32_t* __restrict__ d_nq,
+                                                          const uint8_t* __restrict__ d_t, size_t t_stride, const int32_t* __restrict__ d_nt,
+                                                          int max_rows, int8_t* __restrict__ d_q8, int8_t* __restrict__ d_t8) {
+    const int b = blockIdx.z, side = blockIdx.y;
+    const int n = min(side ? d_nt[b] : d_nq[b], max_rows);
+    const int t = blockIdx.x * 256 + threadIdx.x; // (row, dword)
+    if (t >= n * 8) return;
+    const uint32_t word = reinterpret_cast<const uint32_t*>((side ? d_t + (size_t)b * t_stride : d_q + (size_t)b * q_stride))[t];
+    uint32_t o[8];
+#pragma unroll
+    for (int nib = 0; nib < 8; ++nib) {
+        const uint32_t s = __umul24((word >> (4 * nib)) & 0xFu, 0x204081u) & 0x01010101u; // bit k of the nibble -> byte k
+        o[nib] = ((s << 8) - (s << 1)) | 0x01010101u;                                     // 0 -> 0x01 (+1), 1 -> 0xFF (-1)
+    }
+    uint4* dst = reinterpret_cast<uint4*>((side ? d_t8 : d_q8) + ((size_t)b * max_rows) * 256 + (size_t)t * 32);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+constexpr int kMatchBlock = 256;             // 4 waves
+constexpr int kColsPerWave = 64;             // two 32-column MFMA tiles held in registers
+constexpr int kColsPerBlock = (kMatchBlock / 64) * kColsPerWave;
+constexpr int kQRows = 32;                   // query rows per LDS tile
+constexpr int kQStride = 272;                // bytes per staged query row (256 + 16: conflict-free 16-B reads)
 
 __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
-    const uint8_t* __restrict__ d_q, size_t q_stride, const int32_t* __restrict__ d_nq, const uint8_t* __restrict__ d_t,
-    size_t t_stride, const int32_t* __restrict__ d_nt, int max_rows, int qsplit, uint32_t* __restrict__ d_train_best) {
+    const int8_t* __restrict__ d_q8, const int32_t* __restrict__ d_nq, const int8_t* __restrict__ d_t8, const int32_t* __restrict__ d_nt,
+    int max_rows, int qsplit, uint32_t* __restrict__ d_train_best, int dbg) {
     const int b = blockIdx.z;
     const int nq = min(d_nq[b], max_rows), nt = min(d_nt[b], max_rows);
-    const int j = blockIdx.x * kMatchBlock + threadIdx.x;
-    if (blockIdx.x * kMatchBlock >= nt || nq <= 0) return;
-    // query range of this split
-    const int per = (nq + qsplit - 1) / qsplit;
-    const int q0 = blockIdx.y * per, q1 = min(nq, q0 + per);
-    if (q0 >= q1) return;
-
-    __shared__ uint4 sq[kQTile * 2];
-    const uint4* tq = reinterpret_cast<const uint4*>(d_t + (size_t)b * t_stride);
-    uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0;
-    if (j < nt) { t0 = tq[2 * j]; t1 = tq[2 * j + 1]; }
-    const uint4* gq = reinterpret_cast<const uint4*>(d_q + (size_t)b * q_stride);
-
-    uint32_t best = 0xFFFFFFFFu;
-    for (int base = q0; base < q1; base += kQTile) {
-        const int cnt = min(kQTile, q1 - base);
-        __syncthreads();
-        for (int s = threadIdx.x; s < cnt * 2; s += kMatchBlock) sq[s] = gq[2 * base + s];
-        __syncthreads();
-        for (int i = 0; i < cnt; ++i) {
-            const uint4 a = sq[2 * i], c = sq[2 * i + 1];
-            uint32_t d = __popc(a.x ^ t0.x);
-            d += __popc(a.y ^ t0.y);
-            d += __popc(a.z ^ t0.z);
-            d += __popc(a.w ^ t0.w);
-            d += __popc(c.x ^ t1.x);
-            d += __popc(c.y ^ t1.y);
-            d += __popc(c.z ^ t1.z);
-            d += __popc(c.w ^ t1.w);
-            const uint32_t key = (d << 16) | (uint32_t)(base + i);
-            best = min(best, key);
-        }
+    const int c0 = blockIdx.x * kColsPerBlock;
+    if (c0 >= nt || nq <= 0) return;
+    // query range of this split, in whole tiles
+    const int ntiles = (nq + kQRows - 1) / kQRows, per = (ntiles + qsplit - 1) / qsplit;
+    const int tile0 = blockIdx.y * per, tile1 = min(ntiles, tile0 + per);
+    if (tile0 >= tile1) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    __shared__ alignas(16) int8_t sq[2][kQRows * kQStride];
+    const int8_t* Q8 = d_q8 + (size_t)b * max_rows * 256;
+    const int8_t* T8 = d_t8 + (size_t)b * max_rows * 256;
+    // B operands: this wave's 64 train columns, resident for the whole kernel
+    v4i breg[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = min(c0 + wave * kColsPerWave + 32 * t + r, nt - 1);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) breg[t][s] = *reinterpret_cast<const v4i*>(T8 + (size_t)j * 256 + s * 32 + h * 16);
     }
-    if (j < nt) {
-        if (qsplit == 1) d_train_best[(size_t)b * max_rows + j] = best;
-        else atomicMin(&d_train_best[(size_t)b * max_rows + j], best);
+    // staging: 512 16-byte chunks per tile, two per thread
+    const int ch0 = threadIdx.x, ch1 = threadIdx.x + kMatchBlock;
+    auto gload = [&](int tile, uint4& x0, uint4& x1) {
+        const int r0 = min(tile * kQRows + (ch0 >> 4), nq - 1), r1 = min(tile * kQRows + (ch1 >> 4), nq - 1);
+        x0 = *reinterpret_cast<const uint4*>(Q8 + (size_t)r0 * 256 + (ch0 & 15) * 16);
+        x1 = *reinterpret_cast<const uint4*>(Q8 + (size_t)r1 * 256 + (ch1 & 15) * 16);
+    };
+    auto sstore = [&](int buf, const uint4& x0, const uint4& x1) {
+        *reinterpret_cast<uint4*>(&sq[buf][(ch0 >> 4) * kQStride + (ch0 & 15) * 16]) = x0;
+        *reinterpret_cast<uint4*>(&sq[buf][(ch1 >> 4) * kQStride + (ch1 & 15) * 16]) = x1;
+    };
+    uint4 x0, x1;
+    gload(tile0, x0, x1);
+    sstore(0, x0, x1);
+    __syncthreads();
+    // running maximum per column tile of (dot + 256) << 16 | (0xFFFF - query row): largest dot = smallest distance, then
+    // smallest row.  Accumulator slot v of a tile whose first row is q0 holds row q0 + 4 h + 8 (v / 4) + v % 4.
+    uint32_t m0 = 0, m1 = 0;
+    v16i bias;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) bias[v] = 256;
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int buf = (tile - tile0) & 1;
+        if (tile + 1 < tile1 && !(dbg & 4)) gload(tile + 1, x0, x1);
+        v4i a[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) a[s] = (dbg & 1) ? breg[0][s] : *reinterpret_cast<const v4i*>(&sq[buf][r * kQStride + s * 32 + h * 16]);
+        v16i acc0 = bias, acc1 = bias;
+        if (!(dbg & 8)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], breg[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], breg[1][s], acc1, 0, 0, 0);
+        }
+        } else { acc0[0] += a[0][0] + a[7][3]; acc1[0] += a[3][1]; }
+        const int ib = tile * kQRows + 4 * h;
+        const uint32_t inv = 0xFFFFu - (uint32_t)ib;
+        if (dbg & 2) { m0 = max(m0, (uint32_t)acc0[0] + (uint32_t)acc0[15]); m1 = max(m1, (uint32_t)acc1[3]); }
+        else if (tile * kQRows + kQRows <= nq) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const uint32_t iv = inv - (uint32_t)(8 * (v / 4) + (v % 4));
+                m0 = max(m0, ((uint32_t)acc0[v] << 16) + iv);
+                m1 = max(m1, ((uint32_t)acc1[v] << 16) + iv);
+            }
+        } else { // last, partial tile: rows >= nq must not compete
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int off = 8 * (v / 4) + (v % 4);
+                const bool ok = ib + off < nq;
+                const uint32_t iv = inv - (uint32_t)off;
+                m0 = max(m0, ok ? ((uint32_t)acc0[v] << 16) + iv : 0u);
+                m1 = max(m1, ok ? ((uint32_t)acc1[v] << 16) + iv : 0u);
+            }
+        }
+        if (tile + 1 < tile1 && !(dbg & 4)) sstore(buf ^ 1, x0, x1);
+        if (!(dbg & 4)) __syncthreads();
+    }
+    m0 = max(m0, (uint32_t)__shfl_xor((int)m0, 32));
+    m1 = max(m1, (uint32_t)__shfl_xor((int)m1, 32));
+    if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t m = t ? m1 : m0;
+            const int j = c0 + wave * kColsPerWave + 32 * t + r;
+            if (j < nt && m != 0) {
+                const uint32_t d = (512u - (m >> 16)) >> 1, i = 0xFFFFu - (m & 0xFFFFu);
+                const uint32_t key = (d << 16) | i;
+                if (qsplit == 1) d_train_best[(size_t)b * max_rows + j] = key;
+                else atomicMin(&d_train_best[(size_t)b * max_rows + j], key);
+            }
+        }
     }
 }
 
@@ -136,18 +220,25 @@ __global__ __launch_bounds__(kFinBlock) void match_finalize_kernel(
 
 int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const uint8_t* d_t, size_t t_stride,
                  const int32_t* d_nt, const double* d_gap, int gate, double ratio, double gap_thr, int B, int max_rows,
-                 uint32_t* d_train_best, vslam_dmatch* d_out, int out_capacity, int32_t* d_nout, hipStream_t stream) {
+                 uint32_t* d_train_best, int8_t* d_q8, int8_t* d_t8, vslam_dmatch* d_out, int out_capacity, int32_t* d_nout, hipStream_t stream) {
     if (B <= 0) return VSLAM_OK;
     if (max_rows > kMaxRows || max_rows <= 0) { set_error("matcher: max_rows %d out of range (<= %d)", max_rows, kMaxRows); return VSLAM_ERR_ARG; }
+    {
+        ProfScope prof__(stream, "match_expand_kernel");
+        hipLaunchKernelGGL(match_expand_kernel, dim3((max_rows * 8 + 255) / 256, 2, B), dim3(256), 0, stream, d_q, q_stride, d_nq, d_t, t_stride,
+                           d_nt, max_rows, d_q8, d_t8);
+    }
     // fill the chip: ~>= 1024 workgroups.  Split the query range when the batch is small.
-    const int tblocks = (max_rows + kMatchBlock - 1) / kMatchBlock;
+    const int tblocks = (max_rows + kColsPerBlock - 1) / kColsPerBlock;
     int qsplit = 1;
-    while (qsplit < 16 && (long)tblocks * qsplit * B < 1024 && max_rows / (qsplit * 2) >= kQTile) qsplit *= 2;
+    while (qsplit < 16 && (long)tblocks * qsplit * B < 1024 && max_rows / (qsplit * 2) >= 4 * kQRows) qsplit *= 2;
+    // every in-range train row is written exactly once when the query range is not split
     if (qsplit > 1) VS_HIP(hipMemsetAsync(d_train_best, 0xFF, (size_t)B * max_rows * sizeof(uint32_t), stream));
     {
+        static const int dbg = getenv("VSLAM_MATCH_DBG") ? atoi(getenv("VSLAM_MATCH_DBG")) : 0;
         ProfScope prof__(stream, "match_train_nearest_kernel");
-        hipLaunchKernelGGL(match_train_nearest_kernel, dim3(tblocks, qsplit, B), dim3(kMatchBlock), 0, stream, d_q, q_stride, d_nq,
-                           d_t, t_stride, d_nt, max_rows, qsplit, d_train_best);
+        hipLaunchKernelGGL(match_train_nearest_kernel, dim3(tblocks, qsplit, B), dim3(kMatchBlock), 0, stream, d_q8, d_nq, d_t8, d_nt, max_rows,
+                           qsplit, d_train_best, dbg);
     }
     ProfScope prof__(stream, "match_finalize_kernel");
     hipLaunchKernelGGL(match_finalize_kernel, dim3(B), dim3(kFinBlock), 0, stream, d_nq, d_nt, d_gap, gate, ratio, gap_thr,
