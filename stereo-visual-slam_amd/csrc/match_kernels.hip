@@ -48,16 +48,43 @@ constexpr int kColsPerBlock = (kMatchBlock / 64) * kColsPerWave;
 constexpr int kQRows = 32;                   // query rows per LDS tile
 constexpr int kQStride = 272;                // bytes per staged query row (256 + 16: conflict-free 16-B reads)
 
+// epilogue of one 32 x 32 tile: fold the 16 accumulator slots of this lane into the running maximum of
+// dot << 16 | (0xFFFF - row) (signed compare: largest dot = smallest distance, then smallest row)
+__device__ inline void fold_tile(const v16i& acc0, const v16i& acc1, int ib, int nq, bool full, int& m0, int& m1) {
+    const int inv = 0xFFFF - ib;
+    if (full) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int iv = inv - (8 * (v / 4) + (v % 4));
+            m0 = max(m0, (acc0[v] << 16) + iv);
+            m1 = max(m1, (acc1[v] << 16) + iv);
+        }
+    } else { // last, partial tile: rows >= nq must not compete
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int off = 8 * (v / 4) + (v % 4);
+            if (ib + off < nq) {
+                m0 = max(m0, (acc0[v] << 16) + inv - off);
+                m1 = max(m1, (acc1[v] << 16) + inv - off);
+            }
+        }
+    }
+}
+
+// Work items are numbered column-block-major (w = (colblock * qsplit + split) * B + item): the items' live column blocks
+// come first in the grid and spread evenly over the XCDs / CUs, the blocks beyond an item's train rows (capacity padding)
+// sit at the end and exit at once.  (With the item as the slow index the live blocks of every item landed on the same few XCDs.)
 __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
     const int8_t* __restrict__ d_q8, const int32_t* __restrict__ d_nq, const int8_t* __restrict__ d_t8, const int32_t* __restrict__ d_nt,
-    int max_rows, int qsplit, uint32_t* __restrict__ d_train_best, int dbg) {
-    const int b = blockIdx.z;
+    int max_rows, int qsplit, int B, uint32_t* __restrict__ d_train_best) {
+    const int w = blockIdx.x;
+    const int b = w % B, split = (w / B) % qsplit, cb = w / (B * qsplit);
     const int nq = min(d_nq[b], max_rows), nt = min(d_nt[b], max_rows);
-    const int c0 = blockIdx.x * kColsPerBlock;
+    const int c0 = cb * kColsPerBlock;
     if (c0 >= nt || nq <= 0) return;
     // query range of this split, in whole tiles
     const int ntiles = (nq + kQRows - 1) / kQRows, per = (ntiles + qsplit - 1) / qsplit;
-    const int tile0 = blockIdx.y * per, tile1 = min(ntiles, tile0 + per);
+    const int tile0 = split * per, tile1 = min(ntiles, tile0 + per);
     if (tile0 >= tile1) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     __shared__ alignas(16) int8_t sq[2][kQRows * kQStride];
@@ -82,62 +109,49 @@ __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
         *reinterpret_cast<uint4*>(&sq[buf][(ch0 >> 4) * kQStride + (ch0 & 15) * 16]) = x0;
         *reinterpret_cast<uint4*>(&sq[buf][(ch1 >> 4) * kQStride + (ch1 & 15) * 16]) = x1;
     };
-    uint4 x0, x1;
-    gload(tile0, x0, x1);
-    sstore(0, x0, x1);
-    __syncthreads();
-    // running maximum per column tile of (dot + 256) << 16 | (0xFFFF - query row): largest dot = smallest distance, then
-    // smallest row.  Accumulator slot v of a tile whose first row is q0 holds row q0 + 4 h + 8 (v / 4) + v % 4.
-    uint32_t m0 = 0, m1 = 0;
-    v16i bias;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) bias[v] = 256;
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int buf = (tile - tile0) & 1;
-        if (tile + 1 < tile1 && !(dbg & 4)) gload(tile + 1, x0, x1);
+    auto mma_tile = [&](int buf, v16i& acc0, v16i& acc1) {
         v4i a[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) a[s] = (dbg & 1) ? breg[0][s] : *reinterpret_cast<const v4i*>(&sq[buf][r * kQStride + s * 32 + h * 16]);
-        v16i acc0 = bias, acc1 = bias;
-        if (!(dbg & 8)) {
+        for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const v4i*>(&sq[buf][r * kQStride + s * 32 + h * 16]);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc0[v] = 0; acc1[v] = 0; }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], breg[0][s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], breg[1][s], acc1, 0, 0, 0);
         }
-        } else { acc0[0] += a[0][0] + a[7][3]; acc1[0] += a[3][1]; }
-        const int ib = tile * kQRows + 4 * h;
-        const uint32_t inv = 0xFFFFu - (uint32_t)ib;
-        if (dbg & 2) { m0 = max(m0, (uint32_t)acc0[0] + (uint32_t)acc0[15]); m1 = max(m1, (uint32_t)acc1[3]); }
-        else if (tile * kQRows + kQRows <= nq) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const uint32_t iv = inv - (uint32_t)(8 * (v / 4) + (v % 4));
-                m0 = max(m0, ((uint32_t)acc0[v] << 16) + iv);
-                m1 = max(m1, ((uint32_t)acc1[v] << 16) + iv);
-            }
-        } else { // last, partial tile: rows >= nq must not compete
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int off = 8 * (v / 4) + (v % 4);
-                const bool ok = ib + off < nq;
-                const uint32_t iv = inv - (uint32_t)off;
-                m0 = max(m0, ok ? ((uint32_t)acc0[v] << 16) + iv : 0u);
-                m1 = max(m1, ok ? ((uint32_t)acc1[v] << 16) + iv : 0u);
-            }
-        }
-        if (tile + 1 < tile1 && !(dbg & 4)) sstore(buf ^ 1, x0, x1);
-        if (!(dbg & 4)) __syncthreads();
+    };
+    uint4 x0, x1;
+    gload(tile0, x0, x1);
+    sstore(0, x0, x1);
+    if (tile0 + 1 < tile1) gload(tile0 + 1, x0, x1);
+    __syncthreads();
+    int m0 = INT_MIN, m1 = INT_MIN;
+    // software pipeline: the MFMAs of tile t + 1 are issued before the (VALU) epilogue of tile t
+    v16i accA0, accA1, accB0, accB1;
+    mma_tile(0, accA0, accA1);
+    for (int tile = tile0; tile < tile1; tile += 2) {
+        // ---- stage tile + 1 into buffer 1, issue its MFMAs, then fold tile
+        if (tile + 1 < tile1) { sstore(1, x0, x1); if (tile + 2 < tile1) gload(tile + 2, x0, x1); }
+        __syncthreads();
+        if (tile + 1 < tile1) mma_tile(1, accB0, accB1);
+        fold_tile(accA0, accA1, tile * kQRows + 4 * h, nq, tile * kQRows + kQRows <= nq, m0, m1);
+        if (tile + 1 >= tile1) break;
+        // ---- stage tile + 2 into buffer 0, issue its MFMAs, then fold tile + 1
+        if (tile + 2 < tile1) { sstore(0, x0, x1); if (tile + 3 < tile1) gload(tile + 3, x0, x1); }
+        __syncthreads();
+        if (tile + 2 < tile1) mma_tile(0, accA0, accA1);
+        fold_tile(accB0, accB1, (tile + 1) * kQRows + 4 * h, nq, (tile + 1) * kQRows + kQRows <= nq, m0, m1);
     }
-    m0 = max(m0, (uint32_t)__shfl_xor((int)m0, 32));
-    m1 = max(m1, (uint32_t)__shfl_xor((int)m1, 32));
+    m0 = max(m0, __shfl_xor(m0, 32));
+    m1 = max(m1, __shfl_xor(m1, 32));
     if (h == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const uint32_t m = t ? m1 : m0;
+            const int m = t ? m1 : m0;
             const int j = c0 + wave * kColsPerWave + 32 * t + r;
-            if (j < nt && m != 0) {
-                const uint32_t d = (512u - (m >> 16)) >> 1, i = 0xFFFFu - (m & 0xFFFFu);
+            if (j < nt && m != INT_MIN) {
+                const uint32_t d = (uint32_t)(256 - (m >> 16)) >> 1, i = 0xFFFFu - ((uint32_t)m & 0xFFFFu);
                 const uint32_t key = (d << 16) | i;
                 if (qsplit == 1) d_train_best[(size_t)b * max_rows + j] = key;
                 else atomicMin(&d_train_best[(size_t)b * max_rows + j], key);
@@ -235,10 +249,9 @@ int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const
     // every in-range train row is written exactly once when the query range is not split
     if (qsplit > 1) VS_HIP(hipMemsetAsync(d_train_best, 0xFF, (size_t)B * max_rows * sizeof(uint32_t), stream));
     {
-        static const int dbg = getenv("VSLAM_MATCH_DBG") ? atoi(getenv("VSLAM_MATCH_DBG")) : 0;
         ProfScope prof__(stream, "match_train_nearest_kernel");
-        hipLaunchKernelGGL(match_train_nearest_kernel, dim3(tblocks, qsplit, B), dim3(kMatchBlock), 0, stream, d_q8, d_nq, d_t8, d_nt, max_rows,
-                           qsplit, d_train_best, dbg);
+        hipLaunchKernelGGL(match_train_nearest_kernel, dim3(tblocks * qsplit * B), dim3(kMatchBlock), 0, stream, d_q8, d_nq, d_t8, d_nt, max_rows,
+                           qsplit, B, d_train_best);
     }
     ProfScope prof__(stream, "match_finalize_kernel");
     hipLaunchKernelGGL(match_finalize_kernel, dim3(B), dim3(kFinBlock), 0, stream, d_nq, d_nt, d_gap, gate, ratio, gap_thr,
