@@ -587,7 +587,9 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
                                                               const int32_t* __restrict__ d_corner_cnt, int sel_cap,
                                                               vslam_keypoint* __restrict__ d_sel, int32_t* __restrict__ d_sel_cnt,
                                                               int32_t* __restrict__ d_status) {
-    const int l = blockIdx.x, b = blockIdx.y;
+    // level-major work numbering: with the level as the fast grid index every level-0 workgroup (the heaviest) lands on the
+    // same XCD (workgroups are dealt to the 8 XCDs round-robin)
+    const int b = blockIdx.x, l = blockIdx.y;
     const LevelView V = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
     const uint32_t* corners = d_corners + (size_t)b * corner_total + T.corner_off[l];
     const int n = min(d_corner_cnt[b * kNLevels + l], T.corner_cap[l]);
@@ -718,7 +720,7 @@ int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
         attr_set = true;
     }
     ProfScope prof__(stream, "orb_select_kernel");
-    hipLaunchKernelGGL(orb_select_kernel, dim3(kNLevels, B), dim3(kSelBlock), smem, stream, T, d_imgs, img_bytes, pitch, d_pyr,
+    hipLaunchKernelGGL(orb_select_kernel, dim3(B, kNLevels), dim3(kSelBlock), smem, stream, T, d_imgs, img_bytes, pitch, d_pyr,
                        (size_t)plan.pyr_bytes, plan.corner_total, d_corners, d_corner_cnt, plan.sel_cap, d_sel, d_sel_cnt, d_status);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
