@@ -40,6 +40,7 @@ constexpr int kMaxKf = VSLAM_MAX_KF;
 constexpr int kMaxNp = 6 * kMaxKf;
 constexpr int kMaxPairs = kMaxKf * (kMaxKf + 1) / 2;
 constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
+constexpr int kDinvLds = 2000;  // landmarks whose Dinv stays in LDS (48 B each: the 96 KB the static state leaves free)
 constexpr int kLin = 8;        // doubles per edge of linearisation scratch: two sets of {X, Y, 1/Z, w} (current state / trial state)
 constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
 constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
@@ -78,6 +79,7 @@ struct LmKernelArgs {
     float* uvk;       // 2 x total_edge: observations in keyframe-major order
     int32_t* status;  // n_windows
     long long* dbg_cycles; // tuning aid (VSLAM_LM_PROFILE=1): 16 phase cycle counters per window, thread 0
+    int dinv_lds;     // landmarks per window whose Dinv is kept in dynamic LDS (0 = none)
     int want_chi2;    // the caller passed a chi2 output array: scatter chi2 back to its edge order at the end
     int dbg_skip;     // tuning aid (VSLAM_LM_SKIP): bit0 Schur hits, bit1 Cholesky, bit2 pose blocks, bit3 landmark blocks, bit4 eval, bit5 back-subst, bit6 setup lists
 };
@@ -265,6 +267,18 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     double* Hll = a.Hll + 6 * (size_t)lm0;
     double* bl = a.bl + 3 * (size_t)lm0;
     double* Dinv = a.Dinv + 6 * (size_t)lm0;
+    // Dinv of the first kDinvLds landmarks lives in LDS (written once per trial, gathered ~8 times per landmark by the Schur
+    // passes and once by the back-substitution); the rest goes through global memory
+    extern __shared__ double sDinv[];
+    const int ncache = (!IMPL && mode == 0) ? min(nl, ka.dinv_lds) : 0;
+    auto storeD = [&](int l, const double (&Di)[6]) {
+        if (l < ncache) { double2* q = reinterpret_cast<double2*>(sDinv + 6 * l); q[0] = make_double2(Di[0], Di[1]); q[1] = make_double2(Di[2], Di[3]); q[2] = make_double2(Di[4], Di[5]); }
+        else { double2* q = reinterpret_cast<double2*>(Dinv + 6 * (size_t)l); q[0] = make_double2(Di[0], Di[1]); q[1] = make_double2(Di[2], Di[3]); q[2] = make_double2(Di[4], Di[5]); }
+    };
+    auto loadD = [&](int l, double2& Da, double2& Db, double2& Dc) {
+        if (l < ncache) { const double2* q = reinterpret_cast<const double2*>(sDinv + 6 * l); Da = q[0]; Db = q[1]; Dc = q[2]; }
+        else { const double2* q = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)l); Da = q[0]; Db = q[1]; Dc = q[2]; }
+    };
     double* db = a.db + 3 * (size_t)lm0;
     double* lin = a.lin + kLin * (size_t)e0;
     double* chi2 = a.chi2 + e0;
@@ -638,8 +652,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     if (it > 0) { // lambda of the first trial is already known: invert here and skip that trial's pass over Hll
                         double Di[6];
                         if (!inv3_sym(h[0] + lambda, h[1], h[2], h[3] + lambda, h[4], h[5] + lambda, Di)) sm.flag[1] = 1;
-                        double2* Dp = reinterpret_cast<double2*>(Dinv + 6 * (size_t)l);
-                        Dp[0] = make_double2(Di[0], Di[1]); Dp[1] = make_double2(Di[2], Di[3]); Dp[2] = make_double2(Di[4], Di[5]);
+                        storeD(l, Di);
                     }
                 }
             }
@@ -665,8 +678,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         if (!act[l]) continue;
                         double Di[6];
                         if (!inv3_sym(PC(Hll, 0, l) + lambda, PC(Hll, 1, l), PC(Hll, 2, l), PC(Hll, 3, l) + lambda, PC(Hll, 4, l), PC(Hll, 5, l) + lambda, Di)) bad = 1;
-                        double2* Dp = reinterpret_cast<double2*>(Dinv + 6 * (size_t)l);
-                        Dp[0] = make_double2(Di[0], Di[1]); Dp[1] = make_double2(Di[2], Di[3]); Dp[2] = make_double2(Di[4], Di[5]);
+                        storeD(l, Di);
                     }
                     if (bad) sm.flag[1] = 1;
                 }
@@ -691,14 +703,14 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         if (jbeg < jend) { // (an empty list has no valid record to prefetch)
                         int ln = kf_lm[min(j, jend - 1)], lnn = kf_lm[min(j + 64, jend - 1)];
                         double4 ra = recA[min(j, jend - 1)];
-                        const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)ln);
-                        double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
+                        double2 Da, Db, Dc;
+                        loadD(ln, Da, Db, Dc);
                         double g0 = PC(bl, 0, ln), g1 = PC(bl, 1, ln), g2 = PC(bl, 2, ln);
                         for (; j < jend; j += 64) {
                             const int lnnn = kf_lm[min(j + 128, jend - 1)];
                             const double4 ran = recA[min(j + 64, jend - 1)];
-                            const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)lnn);
-                            const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
+                            double2 Dan, Dbn, Dcn;
+                            loadD(lnn, Dan, Dbn, Dcn);
                             const double g0n = PC(bl, 0, lnn), g1n = PC(bl, 1, lnn), g2n = PC(bl, 2, lnn);
                             double A1[12], B1[6];
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
@@ -757,13 +769,13 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         int2 h = hits[min(j, jend - 1)];
                         int2 hn = hits[min(j + 64, jend - 1)];
                         double4 ra = recA[h.x & 0xFFFF], rb = recA[(unsigned)h.x >> 16];
-                        const double2* Dp0 = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)h.y);
-                        double2 Da = Dp0[0], Db = Dp0[1], Dc = Dp0[2];
+                        double2 Da, Db, Dc;
+                        loadD(h.y, Da, Db, Dc);
                         for (; j < jend; j += 64) {
                             const int2 hnn = hits[min(j + 128, jend - 1)];
                             const double4 ran = recA[hn.x & 0xFFFF], rbn = recA[(unsigned)hn.x >> 16];
-                            const double2* Dpn = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)hn.y);
-                            const double2 Dan = Dpn[0], Dbn = Dpn[1], Dcn = Dpn[2];
+                            double2 Dan, Dbn, Dcn;
+                            loadD(hn.y, Dan, Dbn, Dcn);
                             double A1[12], A2[12], B1[6], B2[6];
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
                             jac_point(A1, &sm.Rt[12 * k1], B1);
@@ -955,8 +967,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         b0[u] = lm_ptr[l]; b1[u] = lm_ptr[l + 1];
                         px[u] = PC(P, 0, l); py[u] = PC(P, 1, l); pz[u] = PC(P, 2, l);
                         g0[u] = PC(bl, 0, l); g1[u] = PC(bl, 1, l); g2[u] = PC(bl, 2, l);
-                        const double2* Dp = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)l);
-                        const double2 da = Dp[0], dbb = Dp[1], dc = Dp[2];
+                        double2 da, dbb, dc;
+                        loadD(l, da, dbb, dc);
                         Dq[u][0] = da.x; Dq[u][1] = da.y; Dq[u][2] = dbb.x; Dq[u][3] = dbb.y; Dq[u][4] = dc.x; Dq[u][5] = dc.y;
                     }
                     int kk[kLmU][kLmE]; float2 zz[kLmU][kLmE];
@@ -1156,6 +1168,13 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     memset(&ka, 0, sizeof(ka));
     ka.a = a;
     ka.want_chi2 = a.chi2 != nullptr;
+    ka.dinv_lds = kDinvLds;
+    const size_t dyn_lds = (size_t)kDinvLds * 6 * sizeof(double);
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) { // more than 64 KB of dynamic LDS needs the opt-in
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_window_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+        lds_attr_set = true;
+    }
     { const char* e = getenv("VSLAM_LM_SKIP"); ka.dbg_skip = e ? atoi(e) : 0; }
     static long long* d_cyc = nullptr; static int cyc_n = 0;
     if (getenv("VSLAM_LM_PROFILE")) {
@@ -1168,12 +1187,12 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1);
     if (schedule) {
         // run_vslam.cpp:58-71: optimize_map(5) x2 without write-back, optimize_map(10) writing poses, optimize_pose_only(10)
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 0, 5, 0, 0, 1);
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 0, 5, 0, 0, 1);
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 0, 10, 1, 0, 1);
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, 1, 10, 1, 0, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 10, 1, 0, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1);
     } else {
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), 0, stream, ka, mode, iters, update_poses, update_lms, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, mode, iters, update_poses, update_lms, 1);
     }
     VS_HIP(hipGetLastError());
     if (ka.dbg_cycles) {
