@@ -3,6 +3,11 @@
 // Host code stays on the CPU: it is O(N) association and policy; the kernels do the arithmetic.
 #include "vo_host.hpp"
 
+#include <zlib.h>
+
+#include <cstring>
+#include <iterator>
+
 #include <algorithm>
 #include <cstdio>
 #include <fstream>
@@ -48,10 +53,66 @@ int ImageSource::read_pgm(const std::string& path, Image& img) {
     return f.gcount() == (std::streamsize)img.data.size() ? 0 : -1;
 }
 
+// 8-bit grayscale, non-interlaced PNG (the KITTI odometry gray sequences): chunk walk, zlib inflate, scanline unfiltering.
+// Replaces cv::imread(path, CV_LOAD_IMAGE_GRAYSCALE) for that file type (visual_odometry.cpp:49-50).
+int ImageSource::read_png(const std::string& path, Image& img) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return -1;
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (file.size() < 8 + 25 || std::memcmp(file.data(), sig, 8) != 0) return -1;
+    auto be32 = [&](size_t o) { return (uint32_t)file[o] << 24 | (uint32_t)file[o + 1] << 16 | (uint32_t)file[o + 2] << 8 | (uint32_t)file[o + 3]; };
+    uint32_t w = 0, h = 0;
+    std::vector<uint8_t> idat;
+    for (size_t o = 8; o + 12 <= file.size();) {
+        const uint32_t len = be32(o);
+        if (o + 12 + (size_t)len > file.size()) return -1;
+        const char* type = reinterpret_cast<const char*>(&file[o + 4]);
+        const uint8_t* data = &file[o + 8];
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) return -1;
+            w = be32(o + 8); h = be32(o + 12);
+            // bit depth 8, colour type 0 (gray), compression 0, filter 0, no interlace
+            if (data[8] != 8 || data[9] != 0 || data[10] != 0 || data[11] != 0 || data[12] != 0) return -1;
+        } else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+        else if (!std::memcmp(type, "IEND", 4)) break;
+        o += 12 + (size_t)len;
+    }
+    if (w == 0 || h == 0 || w > 16384 || h > 16384 || idat.empty()) return -1;
+    std::vector<uint8_t> raw((size_t)h * (w + 1));
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return -1;
+    img.cols = (int)w; img.rows = (int)h; img.data.assign((size_t)w * h, 0);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* in = &raw[(size_t)y * (w + 1)];
+        uint8_t* out = &img.data[(size_t)y * w];
+        const uint8_t* up = y ? out - w : nullptr;
+        const int ft = in[0];
+        for (uint32_t x = 0; x < w; ++x) {
+            const int a = x ? out[x - 1] : 0, b = up ? up[x] : 0, c = (x && up) ? up[x - 1] : 0;
+            int pred = 0;
+            switch (ft) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                default: return -1;
+            }
+            out[x] = (uint8_t)(in[1 + x] + pred);
+        }
+    }
+    return 0;
+}
+
+// dataset_/image_0/%06d.png (KITTI layout, visual_odometry.cpp:44-50); .pgm is accepted as a dependency-free alternative
 int ImageSource::read(int id, Image& left, Image& right) const {
     char name[32];
-    std::snprintf(name, sizeof(name), "%06d.pgm", id);
-    if (read_pgm(dataset_ + "image_0/" + name, left) || read_pgm(dataset_ + "image_1/" + name, right)) {
+    std::snprintf(name, sizeof(name), "%06d", id);
+    const std::string l = dataset_ + "image_0/" + name, r = dataset_ + "image_1/" + name;
+    const bool ok = (read_png(l + ".png", left) == 0 && read_png(r + ".png", right) == 0) ||
+                    (read_pgm(l + ".pgm", left) == 0 && read_pgm(r + ".pgm", right) == 0);
+    if (!ok) {
         std::cout << "Could not open or find the image" << std::endl; // visual_odometry.cpp:53-57
         return -1;
     }

@@ -15,12 +15,13 @@ namespace vslam {
 enum TrackState { Init, Track, Lost };
 enum DepthSource { DepthStereoMatch = 0, DepthSGBM = 1 };
 
-// replaces cv::imread on `dataset + "image_0/%06d.png"` (visual_odometry.cpp:37-68): binary PGM (P5) files
+// replaces cv::imread on `dataset + "image_0/%06d.png"` (visual_odometry.cpp:37-68): 8-bit gray PNG (zlib), or binary PGM (P5)
 struct ImageSource {
     std::string dataset_;
     explicit ImageSource(std::string dataset) : dataset_(std::move(dataset)) {}
     int read(int id, Image& left, Image& right) const;
     static int read_pgm(const std::string& path, Image& img);
+    static int read_png(const std::string& path, Image& img);
 };
 
 class VO {

@@ -271,13 +271,47 @@ def write_pgm(path, img):
         f.write(np.ascontiguousarray(img, np.uint8).tobytes())
 
 
-def write_pgm_sequence(root, n_frames, seed=0, w=W_KITTI, h=H_KITTI):
-    """KITTI-like layout with binary PGMs: root/image_0/%06d.pgm (left), root/image_1/%06d.pgm (right).
-    returns the ground-truth T_c_w list"""
+def write_png(path, img, filters=True):
+    """8-bit grayscale PNG (the KITTI odometry file type).  With `filters`, scanlines cycle through the five PNG filter
+    types so that a reader has to implement all of them."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    rows = []
+    prev = np.zeros(w, np.int32)
+    for y in range(h):
+        cur = img[y].astype(np.int32)
+        ft = (y % 5) if filters else 0
+        a = np.concatenate([[0], cur[:-1]]); b = prev; c = np.concatenate([[0], prev[:-1]])
+        if ft == 0: pred = np.zeros(w, np.int32)
+        elif ft == 1: pred = a
+        elif ft == 2: pred = b
+        elif ft == 3: pred = (a + b) >> 1
+        else:
+            p = a + b - c; pa = np.abs(p - a); pb = np.abs(p - b); pc = np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+        rows.append(bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    z = zlib.compress(b"".join(rows), 6)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)))
+        for o in range(0, len(z), 32768):  # several IDAT chunks, like real encoders
+            f.write(chunk(b"IDAT", z[o:o + 32768]))
+        f.write(chunk(b"IEND", b""))
+
+
+def write_pgm_sequence(root, n_frames, seed=0, w=W_KITTI, h=H_KITTI, fmt="pgm"):
+    """KITTI-like layout: root/image_0/%06d.<fmt> (left), root/image_1/%06d.<fmt> (right), fmt = "pgm" (binary P5) or "png"
+    (8-bit gray, what KITTI ships).  Returns the ground-truth T_c_w list."""
     import os
     os.makedirs(os.path.join(root, "image_0"), exist_ok=True); os.makedirs(os.path.join(root, "image_1"), exist_ok=True)
     seq = stereo_sequence(n_frames, seed, w, h)
+    wr = write_png if fmt == "png" else write_pgm
     for i, (L, R, T, _) in enumerate(seq):
-        write_pgm(os.path.join(root, "image_0", "%06d.pgm" % i), L)
-        write_pgm(os.path.join(root, "image_1", "%06d.pgm" % i), R)
+        wr(os.path.join(root, "image_0", "%06d.%s" % (i, fmt)), L)
+        wr(os.path.join(root, "image_1", "%06d.%s" % (i, fmt)), R)
     return [s[2] for s in seq]

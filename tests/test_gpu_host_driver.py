@@ -49,7 +49,7 @@ def test_run_vslam_driver_with_sgbm_depth(synth):
     subprocess.check_call(["make", "-C", HOST, "-s", "-j8"])
     n = 24
     with tempfile.TemporaryDirectory() as d:
-        gt = synth.write_pgm_sequence(d + "/", n, seed=6)
+        gt = synth.write_pgm_sequence(d + "/", n, seed=6, fmt="png")  # KITTI's own file type: exercises the PNG reader
         path_len = np.linalg.norm(-synth.R_from_quat(gt[-1][:4]).T @ gt[-1][4:])
         traj = os.path.join(d, "traj_sgbm.txt")
         out = subprocess.run([os.path.join(HOST, "run_vslam"), d + "/", str(n), "1", "1500", traj, "0", "1"], capture_output=True, text=True, timeout=300)
