@@ -11,13 +11,21 @@
 //
 // gfx950 mapping: ONE WORKGROUP PER WINDOW runs the whole LM loop persistently (no host round trips; a batch of
 // windows fills the 256 CUs).  All sums are f64 with a FIXED order (no floating-point atomics):
-//   - per-landmark blocks (Hll, b_l, Dinv)      : one lane per landmark over its CSR edge range
-//   - per-pose blocks (Hpp, b_p, W*db)          : one wave per pose over a by-pose edge list, butterfly reduce
-//   - Schur blocks S[k1][k2]                    : one wave per keyframe pair over a precomputed hit list
-//                                                 (edge pairs sharing a landmark), butterfly reduce, single owner
-//   - reduced system                            : right-looking Cholesky in LDS by the whole workgroup
+//   - evaluation + linearisation                : one keyframe-major pass per state: (pose, third) waves stream the pose's edge
+//                                                 list, write the 32-B records {X, Y, 1/Z, w} and accumulate Hpp, b_p on the
+//                                                 fly; trial states are linearised speculatively into spare buffers, so an
+//                                                 accepted trial needs no re-evaluation
+//   - per-landmark blocks (Hll, b_l, Dinv), back-substitution : one lane per landmark; records are recomputed from the
+//                                                 landmark position and the observations (batched loads), not gathered;
+//                                                 Dinv of the first kDinvLds landmarks stays in LDS
+//   - Schur blocks S[k1][k2]                    : one wave per keyframe pair, dealt by work; off-diagonal pairs walk a
+//                                                 precomputed 8-B hit list, diagonal pairs stream the keyframe's own list and
+//                                                 also produce the reduced right-hand side; single owner per block
+//   - wave reductions                           : halving butterfly (N sums cost ~N shuffles and end one per lane)
+//   - reduced system                            : blocked Cholesky + blocked triangular solves in LDS
 // Landmarks and pixels are f32 at rest (quirk Q4); poses, accumulators and the LM state are f64.
-// No MFMA: the largest dense object is the 72x72 reduced system; the path is latency/f64-VALU bound.
+// No MFMA: the largest dense object is the 72x72 reduced system.  Bound: a mix of HBM-rate phases (evaluation, Schur
+// gathers) and f64 VALU at two waves per SIMD; see DESIGN.md section 5 for the phase split and counters.
 #include "vslam_internal.h"
 
 #include <stdlib.h>
