@@ -29,7 +29,7 @@ class OrbLayout(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orb.c", "match.c", "geom.c", "lm.c", "sgbm.c", "vo_oracle.h", "orb_pattern.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb.c", "match.c", "geom.c", "lm.c", "sgbm.c", "ransac.c", "vo_oracle.h", "orb_pattern.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -342,6 +342,26 @@ def chi2_classify(chi2, flag_lm, lm_inlier):
     ni = C.c_int(); no = C.c_int()
     th = lib().vo_chi2_classify(_p(chi2), len(chi2), _p(flag_lm), _p(lm_inlier), len(lm_inlier), C.byref(ni), C.byref(no))
     return float(th), lm_inlier, ni.value, no.value
+
+
+def ransac_subsets(count, max_iters=100, model_points=5):
+    out = np.zeros((max_iters, model_points), np.int32)
+    lib().vo_ransac_subsets(int(count), int(model_points), int(max_iters), _p(out))
+    return out
+
+
+def ransac_update_num_iters(p, ep, model_points, max_iters):
+    f = lib().vo_ransac_update_num_iters
+    f.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    return f(p, ep, model_points, max_iters)
+
+
+def pnp_ransac(xyz, uv, T0, K=K_KITTI, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    T = _d(T0, 7).copy(); inl = np.zeros(max(len(xyz), 1), np.uint8); it = C.c_int()
+    n = lib().vo_pnp_ransac(_p(xyz), _p(uv), len(xyz), _p(_d(K, 4)), _p(T), int(max_iters), C.c_double(reproj_err), C.c_double(confidence),
+                            int(lm_iters), _p(inl), C.byref(it))
+    return T, inl[:len(xyz)], n, it.value
 
 
 def pnp_motion_only(xyz, uv, T0, K=K_KITTI, iters=10, huber_delta=5.991, reproj_thr=4.0):

@@ -195,6 +195,13 @@ double vo_chi2_classify(const double* chi2, int n_edge, const int32_t* flag_lm, 
 int vo_pnp_motion_only(const float* xyz_w, const float* uv, int n, const double K[4], double T_c_w[7],
                        int iters, double huber_delta, double reproj_thr, uint8_t* inlier, vo_lm_stats* stats);
 
+/* RANSAC wrapper of VO::motion_estimation (cv::solvePnPRansac(..., 100, 4.0, 0.99), visual_odometry.cpp:277); see ransac.c
+ * for the restated control flow (RNG, subset draw, acceptance rule, adaptive iteration count) and the documented deviations. */
+int vo_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
+int vo_ransac_subsets(int count, int model_points, int max_iters, int32_t* subsets);
+int vo_pnp_ransac(const float* xyz_w, const float* uv, int n, const double K[4], double T_c_w[7], int max_iters, double reproj_err,
+                  double confidence, int lm_iters, uint8_t* inlier, int* iters_run);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
-    "vslam_profile_enable", "vslam_profile_read", "vslam_disparity_map", "vslam_disparity_map_dev",
+    "vslam_profile_enable", "vslam_profile_read", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac",
 ]
 
 
@@ -284,6 +284,16 @@ class VO:
                                                        int(match_cap), int(B), _p(d_uvQ), _p(d_uvT)), "vslam_gather_matched_uv_dev")
 
     # ------------------------------------------------------------ VO::motion_estimation (north_star motion-only stage)
+    def motion_estimation_ransac(self, xyz_w, uv, T_guess, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+        """RANSAC front of VO::motion_estimation (cv::solvePnPRansac(..., 100, 4.0, 0.99), visual_odometry.cpp:277).
+        Returns (T, inlier mask, n_inliers, iterations evaluated); n_inliers == 0 means no model was found."""
+        xyz = np.ascontiguousarray(xyz_w, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        T = np.ascontiguousarray(T_guess, np.float64).copy(); n = len(xyz)
+        inl = np.zeros(max(n, 1), np.uint8); ni = C.c_int(); it = C.c_int()
+        self._chk(self.lib.vslam_pnp_ransac(self.h, _p(xyz), _p(uv), n, _p(T), int(max_iters), C.c_double(reproj_err), C.c_double(confidence),
+                                            int(lm_iters), _p(inl), C.byref(ni), C.byref(it)), "vslam_pnp_ransac")
+        return T, inl[:n], ni.value, it.value
+
     def motion_estimation(self, xyz_w, uv, T_guess, iters=10):
         xyz = np.ascontiguousarray(xyz_w, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
         T = np.ascontiguousarray(T_guess, np.float64).copy(); n = len(xyz)

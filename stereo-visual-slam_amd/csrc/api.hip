@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cfloat>
+#include <cmath>
 #include <vector>
 
 #include "se3_device.h"
@@ -151,7 +153,7 @@ const char* vslam_version(void) { return "vslam_hip 0.1 (gfx950)"; }
 const char* vslam_kernel_names(void) {
     return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_blur_kernel orb_describe_kernel match_expand_kernel match_train_nearest_kernel "
            "match_finalize_kernel sgbm_prefilter_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel sgbm_lrcheck_kernel "
-           "sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel sgbm_ccl_apply_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel";
+           "sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel sgbm_ccl_apply_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel pnp_hypothesis_count_kernel";
 }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
@@ -548,6 +550,114 @@ int vslam_pnp_motion_only(vslam_ctx* ctx, const float* xyz_w, const float* uv, i
     if (stats) VS_HIP(hipMemcpyAsync(stats, d_st, sizeof(vslam_lm_stats), hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
     if (n_inliers) *n_inliers = ni;
+    return VSLAM_OK;
+}
+
+// RANSAC wrapper (see include/vslam_hip.h and oracle/ransac.c for the restated control flow)
+static unsigned cv_rng_next(uint64_t& state) {
+    state = (uint64_t)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);
+    return (unsigned)state;
+}
+static int ransac_update_num_iters(double p, double ep, int model_points, int max_iters) { // cv::RANSACUpdateNumIters
+    p = std::min(std::max(p, 0.), 1.); ep = std::min(std::max(ep, 0.), 1.);
+    double num = std::max(1. - p, DBL_MIN), denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num); denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+}
+
+int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters, double reproj_err,
+                     double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !xyz_w || !uv || n < 0 || !T_c_w || max_iters < 0 || max_iters > 4096 || lm_iters < 0 || !(reproj_err > 0)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if (n_inliers) *n_inliers = 0;
+    if (iters_run) *iters_run = 0;
+    if (inlier && n > 0) memset(inlier, 0, (size_t)n);
+    const int mp = 5, H = max_iters;
+    if (n < mp || H == 0) return VSLAM_OK;
+    VS_HIP(hipSetDevice(c->device));
+    // 1. the subset sequence (host: a few hundred RNG draws)
+    std::vector<float> hx((size_t)H * mp * 3), hu((size_t)H * mp * 2);
+    std::vector<double> hT((size_t)H * 7);
+    std::vector<int32_t> hn((size_t)H, mp);
+    uint64_t state = 0xFFFFFFFFFFFFFFFFULL;
+    for (int it = 0; it < H; ++it) {
+        int idx[5];
+        for (int i = 0; i < mp; ++i)
+            for (;;) {
+                const int v = (int)(cv_rng_next(state) % (unsigned)n);
+                int j = 0;
+                for (; j < i; ++j) if (idx[j] == v) break;
+                idx[i] = v;
+                if (j == i) break;
+            }
+        for (int i = 0; i < mp; ++i) {
+            memcpy(&hx[((size_t)it * mp + i) * 3], xyz_w + 3 * (size_t)idx[i], 12);
+            memcpy(&hu[((size_t)it * mp + i) * 2], uv + 2 * (size_t)idx[i], 8);
+        }
+        memcpy(&hT[(size_t)it * 7], T_c_w, 56);
+    }
+    int rc;
+    if ((rc = arena_reserve(c, al256(hx.size() * 4) + al256(hu.size() * 4) + al256(hT.size() * 8) + 2 * al256((size_t)H * 4) + 2 * al256(12 * (size_t)n) +
+                                   2 * al256(8 * (size_t)n) + 2 * al256(n) + 4096))) return rc;
+    Arena ar(c);
+    float* d_hx = arena_take<float>(ar, hx.size()); float* d_hu = arena_take<float>(ar, hu.size());
+    double* d_hT = arena_take<double>(ar, hT.size()); int32_t* d_hn = arena_take<int32_t>(ar, H); int32_t* d_cnt = arena_take<int32_t>(ar, H);
+    float* d_x = arena_take<float>(ar, 3 * (size_t)n); float* d_u = arena_take<float>(ar, 2 * (size_t)n);
+    float* d_ix = arena_take<float>(ar, 3 * (size_t)n); float* d_iu = arena_take<float>(ar, 2 * (size_t)n);
+    uint8_t* d_mask = arena_take<uint8_t>(ar, n); double* d_T = arena_take<double>(ar, 7); int32_t* d_n1 = arena_take<int32_t>(ar, 2);
+    VS_HIP(hipMemcpyAsync(d_hx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_hu, hu.data(), hu.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_hT, hT.data(), hT.size() * 8, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_hn, hn.data(), (size_t)H * 4, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_x, xyz_w, 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_u, uv, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    // 2. every hypothesis: least-squares LM on its 5 points (no robust kernel), then its inlier count over all points
+    PnpArgs p;
+    memset(&p, 0, sizeof(p));
+    p.xyz = d_hx; p.uv = d_hu; p.n = d_hn; p.capacity = mp; p.B = H; p.T = d_hT; p.iters = lm_iters;
+    fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err;
+    if ((rc = launch_pnp(p, c->stream))) return rc;
+    if ((rc = launch_pnp_hypothesis_count(d_x, d_u, n, d_hT, H, p.K, reproj_err, d_cnt, c->stream))) return rc;
+    std::vector<int32_t> cnt(H);
+    VS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    // 3. replay of the sequential loop over the counts (ptsetreg.cpp: strict improvement, adaptive iteration count)
+    int best = -1, max_good = 0, niters = H, it = 0;
+    for (it = 0; it < niters; ++it)
+        if (cnt[it] > std::max(max_good, mp - 1)) {
+            best = it; max_good = cnt[it];
+            niters = ransac_update_num_iters(confidence, (double)(n - max_good) / n, mp, niters);
+        }
+    if (iters_run) *iters_run = it;
+    if (best < 0) return VSLAM_OK;
+    // 4. mask of the best model, refinement on its inliers
+    std::vector<uint8_t> mask(n);
+    int32_t nn = n;
+    VS_HIP(hipMemcpyAsync(d_n1, &nn, 4, hipMemcpyHostToDevice, c->stream));
+    memset(&p, 0, sizeof(p));
+    p.xyz = d_x; p.uv = d_u; p.n = d_n1; p.capacity = n; p.B = 1; p.T = d_hT + 7 * (size_t)best; p.iters = 0;
+    fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err; p.inlier = d_mask; p.n_inliers = d_n1 + 1;
+    if ((rc = launch_pnp(p, c->stream))) return rc; // (0 LM iterations: only the inlier test at the hypothesis pose)
+    VS_HIP(hipMemcpyAsync(mask.data(), d_mask, n, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    std::vector<float> ix, iu;
+    for (int i = 0; i < n; ++i) if (mask[i]) { ix.insert(ix.end(), xyz_w + 3 * (size_t)i, xyz_w + 3 * (size_t)i + 3); iu.insert(iu.end(), uv + 2 * (size_t)i, uv + 2 * (size_t)i + 2); }
+    const int m = (int)(iu.size() / 2);
+    if (m != max_good) { set_error("RANSAC inlier recount mismatch (%d vs %d)", m, max_good); return VSLAM_ERR_HIP; }
+    VS_HIP(hipMemcpyAsync(d_ix, ix.data(), ix.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_iu, iu.data(), iu.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_T, d_hT + 7 * (size_t)best, 56, hipMemcpyDeviceToDevice, c->stream));
+    nn = m;
+    VS_HIP(hipMemcpyAsync(d_n1, &nn, 4, hipMemcpyHostToDevice, c->stream));
+    memset(&p, 0, sizeof(p));
+    p.xyz = d_ix; p.uv = d_iu; p.n = d_n1; p.capacity = m; p.B = 1; p.T = d_T; p.iters = lm_iters;
+    fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err;
+    if ((rc = launch_pnp(p, c->stream))) return rc;
+    VS_HIP(hipMemcpyAsync(T_c_w, d_T, 56, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    if (inlier) memcpy(inlier, mask.data(), n);
+    if (n_inliers) *n_inliers = max_good;
     return VSLAM_OK;
 }
 

@@ -189,6 +189,8 @@ struct PnpArgs {
     uint8_t* inlier; int32_t* n_inliers; vslam_lm_stats* stats;
 };
 int launch_pnp(const PnpArgs& a, hipStream_t stream);
+int launch_pnp_hypothesis_count(const float* d_xyz, const float* d_uv, int n, const double* d_T, int n_hyp, const double K[4], double reproj_thr,
+                                int32_t* d_counts, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- context
 struct Ctx {

@@ -11,7 +11,7 @@
 #include "vo_host.hpp"
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s <dataset_dir/> <n_frames> [if_write_pose] [anms_num] [traj_path] [q1] [depth: 0 = L/R match + DLT, 1 = SGBM]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s <dataset_dir/> <n_frames> [if_write_pose] [anms_num] [traj_path] [q1] [depth: 0 = L/R match + DLT, 1 = SGBM] [pnp: 0 = motion-only LM, 1 = RANSAC]\n", argv[0]); return 2; }
     const std::string dataset = argv[1];
     const int n_frames = std::atoi(argv[2]);
     const bool if_write_pose = argc > 3 ? std::atoi(argv[3]) != 0 : true;
@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
     vslam::Map my_map(if_write_pose, traj);
     vslam::VO my_VO(dataset, ctx, my_map);
     my_VO.depth_source_ = (argc > 7 && std::atoi(argv[7]) != 0) ? vslam::DepthSGBM : vslam::DepthStereoMatch;
+    my_VO.pnp_mode_ = (argc > 8 && std::atoi(argv[8]) != 0) ? vslam::PnpRansac : vslam::PnpMotionOnlyLM;
     int n_keyframes = 0, n_ok = 0, n_ba = 0;
     for (int ite = 0; ite < n_frames; ite++) { // run_vslam.cpp:40
         bool if_insert_keyframe = false;

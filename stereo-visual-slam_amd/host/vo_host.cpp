@@ -221,7 +221,10 @@ void VO::motion_estimation(Frame& frame) {
     std::vector<uint8_t> inlier(rows.size(), 0);
     if (rows.size() >= 4) {
         int n_in = 0;
-        check(vslam_pnp_motion_only(ctx_, pts3d.data(), pts2d.data(), (int)rows.size(), T.data(), pnp_iterations_, inlier.data(), &n_in, nullptr), "motion_estimation");
+        if (pnp_mode_ == PnpRansac) // the reference's call: solvePnPRansac(..., false, 100, 4.0, 0.99, inliers) (:277)
+            check(vslam_pnp_ransac(ctx_, pts3d.data(), pts2d.data(), (int)rows.size(), T.data(), 100, 4.0, 0.99, pnp_iterations_, inlier.data(), &n_in, nullptr), "motion_estimation (RANSAC)");
+        else
+            check(vslam_pnp_motion_only(ctx_, pts3d.data(), pts2d.data(), (int)rows.size(), T.data(), pnp_iterations_, inlier.data(), &n_in, nullptr), "motion_estimation");
         num_inliers_ = n_in;
     }
     T_c_w_ = T; // :290-292

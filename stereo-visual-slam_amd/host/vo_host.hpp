@@ -14,6 +14,7 @@ namespace vslam {
 
 enum TrackState { Init, Track, Lost };
 enum DepthSource { DepthStereoMatch = 0, DepthSGBM = 1 };
+enum PnpMode { PnpMotionOnlyLM = 0, PnpRansac = 1 }; // north_star robust LM, or the reference's RANSAC control flow + LS refinement
 
 // replaces cv::imread on `dataset + "image_0/%06d.png"` (visual_odometry.cpp:37-68): 8-bit gray PNG (zlib), or binary PGM (P5)
 struct ImageSource {
@@ -41,6 +42,7 @@ public:
     int curr_landmark_id_ = 0;
     int pnp_iterations_ = 10;
     DepthSource depth_source_ = DepthStereoMatch;
+    PnpMode pnp_mode_ = PnpMotionOnlyLM;
 
     VO(std::string dataset, vslam_ctx* ctx, Map& map) : my_map_(map), source_(std::move(dataset)), ctx_(ctx) {}
 

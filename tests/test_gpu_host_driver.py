@@ -45,14 +45,15 @@ def test_run_vslam_driver_recovers_trajectory(synth):
 
 
 def test_run_vslam_driver_with_sgbm_depth(synth):
-    """same loop with the reference's own depth source: VO::disparity_map (SGBM on the device) + Frame::find_3d"""
+    """same loop with the reference's own depth source (VO::disparity_map = SGBM on the device, + Frame::find_3d) and its
+    own pose stage (RANSAC control flow of solvePnPRansac + refinement)"""
     subprocess.check_call(["make", "-C", HOST, "-s", "-j8"])
     n = 24
     with tempfile.TemporaryDirectory() as d:
         gt = synth.write_pgm_sequence(d + "/", n, seed=6, fmt="png")  # KITTI's own file type: exercises the PNG reader
         path_len = np.linalg.norm(-synth.R_from_quat(gt[-1][:4]).T @ gt[-1][4:])
         traj = os.path.join(d, "traj_sgbm.txt")
-        out = subprocess.run([os.path.join(HOST, "run_vslam"), d + "/", str(n), "1", "1500", traj, "0", "1"], capture_output=True, text=True, timeout=300)
+        out = subprocess.run([os.path.join(HOST, "run_vslam"), d + "/", str(n), "1", "1500", traj, "0", "1", "1"], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "VO IS LOST" not in out.stdout
         rows = np.loadtxt(traj)

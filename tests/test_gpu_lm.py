@@ -94,3 +94,23 @@ def test_local_ba_rejects_bad_graph(vo, pkg, synth):
     dup_uv = np.concatenate([w["uv"], w["uv"][:1]])
     with pytest.raises(pkg.VslamError):
         vo.optimize_map(w["T0"], w["xyz"], dup_kf, dup_lm, dup_uv)
+
+
+# ---------------------------------------------------------------- RANSAC front of the motion-only stage
+@pytest.mark.parametrize("M,outl,seed", [(400, 0.35, 9), (120, 0.15, 3), (60, 0.0, 2), (900, 0.5, 7)])
+def test_pnp_ransac_parity(vo, oracle, synth, M, outl, seed):
+    """vslam_pnp_ransac vs oracle/ransac.c: same subset sequence, same accepted hypothesis, same number of iterations,
+    identical inlier mask, pose within 1e-4 (cv::solvePnPRansac control flow, visual_odometry.cpp:277)"""
+    p = synth.pnp_problem(M=M, seed=seed, outlier_frac=outl, sigma_px=0.4)
+    gT, ginl, gn, git = vo.motion_estimation_ransac(p["xyz"], p["uv"], p["T0"])
+    wT, winl, wn, wit = oracle.pnp_ransac(p["xyz"], p["uv"], p["T0"])
+    assert git == wit and gn == wn
+    assert np.array_equal(ginl, winl)
+    assert np.allclose(gT, wT, rtol=RTOL, atol=1e-7)
+    assert gn >= (1 - outl) * M * 0.8
+
+
+def test_pnp_ransac_too_few_points(vo, synth):
+    p = synth.pnp_problem(M=4, seed=1)
+    T, inl, n, it = vo.motion_estimation_ransac(p["xyz"], p["uv"], p["T0"])
+    assert n == 0 and it == 0 and np.array_equal(T, p["T0"])
