@@ -122,6 +122,13 @@ __device__ inline void load_tile_u8(uint8_t* lds, int lds_pitch, const uint8_t* 
 }
 
 // ------------------------------------------------------------------------------------------- host plan
+#ifndef VSLAM_FAST_TILE_H
+#define VSLAM_FAST_TILE_H 32
+#endif
+#ifndef VSLAM_FAST_TILE_W
+#define VSLAM_FAST_TILE_W 64
+#endif
+constexpr int kTileW = VSLAM_FAST_TILE_W, kTileH = VSLAM_FAST_TILE_H; // FAST output tile per workgroup
 static inline int cv_round_host(double v) { return (int)lrint(v); }
 
 int orb_plan_init(OrbPlan* plan, int w, int h, int nfeatures, int kp_capacity) {
@@ -143,8 +150,8 @@ int orb_plan_init(OrbPlan* plan, int w, int h, int nfeatures, int kp_capacity) {
         if (l > 0) pyr += ((L.w + 63) & ~63) * L.h;
         L.corner_cap = (L.w * L.h / 16 + 255) & ~255;
         L.corner_off = corners; corners += L.corner_cap;
-        L.tiles_x = L.w > 62 ? (L.w - 62 + 63) / 64 : 0;
-        L.tiles_y = L.h > 62 ? (L.h - 62 + 15) / 16 : 0;
+        L.tiles_x = L.w > 62 ? (L.w - 62 + kTileW - 1) / kTileW : 0;
+        L.tiles_y = L.h > 62 ? (L.h - 62 + kTileH - 1) / kTileH : 0;
         L.tile_off = tiles; tiles += L.tiles_x * L.tiles_y;
         L.tab_off = tab; tab += L.w;
     }
@@ -291,10 +298,10 @@ int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------- K2 FAST
-constexpr int kTileW = 64, kTileH = 16;
+// (kTileW, kTileH are defined next to the host plan, which counts the tiles)
 constexpr int kPixW = kTileW + 8, kPixH = kTileH + 8;  // 72 x 24 pixel tile (halo 4)
 constexpr int kScW = kTileW + 2, kScH = kTileH + 2;    // 66 x 18 score tile (halo 1)
-constexpr int kPixPitch = 76;                          // LDS row pitch (bytes)
+constexpr int kPixPitch = kPixW + 4;                    // LDS row pitch (bytes)
 
 __device__ inline bool ring9(uint32_t m) {
     const uint32_t x = m | (m << 16);
