@@ -918,8 +918,12 @@ int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, in
 // second pyramid, one launch for all levels.  64x16 output tiles: (70 x 22) raw pixels staged in LDS, separable
 // passes through an int32 LDS tile -- the arithmetic of cv::GaussianBlur's 8U path: taps cvRound(k*256) =
 // {18,34,49,55,49,34,18} per pass, (sum + 2^15) >> 16 after the column pass.
-constexpr int kBlurTileW = 64, kBlurTileH = 32;
+#ifndef VSLAM_BLUR_TILE_H
+#define VSLAM_BLUR_TILE_H 32
+#endif
+constexpr int kBlurTileW = 64, kBlurTileH = VSLAM_BLUR_TILE_H;
 constexpr int kBlurRawW = kBlurTileW + 8, kBlurRawH = kBlurTileH + 6, kBlurRawPitch = 76; // raw tile starts at x0 - 4 (dword loads)
+constexpr int kBlurTmpPitch = kBlurRawH + 4; // u16 per column of the transposed row-pass tile (even: dword-aligned pairs; +4: bank spread)
 
 struct BlurTable {
     int w[kNLevels], h[kNLevels], pitch[kNLevels], pyr_off[kNLevels], blur_off[kNLevels];
@@ -938,6 +942,11 @@ static void fill_blur_table(const OrbPlan& plan, BlurTable* T) {
     T->tile_off[kNLevels] = tiles;
 }
 
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) { // v_dot2_u32_u16: a.lo * b.lo + a.hi * b.hi + c
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
+}
+
 __global__ __launch_bounds__(256) void orb_blur_kernel(BlurTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes, int pitch0,
                                                       const uint8_t* __restrict__ d_pyr, size_t pyr_bytes, uint8_t* __restrict__ d_blur,
                                                       size_t blur_bytes) {
@@ -954,39 +963,42 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(BlurTable T, const uint8_
     const int ox = (tile % T.tiles_x[l]) * kBlurTileW, oy = (tile / T.tiles_x[l]) * kBlurTileH;
 
     __shared__ __attribute__((aligned(16))) uint8_t raw[kBlurRawH * kBlurRawPitch];
-    __shared__ int tmp[kBlurRawH * kBlurTileW];
+    // row-pass output, u16 (<= 257 * 255), stored COLUMN-major so that the column pass reads vertical neighbours as packed pairs
+    __shared__ __attribute__((aligned(16))) uint16_t tmpT[kBlurTileW * kBlurTmpPitch];
     load_tile_u8<true, 256>(raw, kBlurRawPitch, src, spitch, W, H, ox - 4, oy - 3, kBlurRawW, kBlurRawH);
     __syncthreads();
-    const int gk[7] = {18, 34, 49, 55, 49, 34, 18};
-    // row pass: one lane = 4 consecutive outputs of one row (10 taps read once)
+    // taps cvRound(k * 256) = {18, 34, 49, 55, 49, 34, 18}, packed for v_dot4_u32_u8 / v_dot2_u32_u16
+    constexpr uint32_t W0 = 18u | 34u << 8 | 49u << 16 | 55u << 24, W1 = 49u | 34u << 8 | 18u << 16;
+    // row pass: one lane = 4 consecutive outputs of one row from three aligned dwords (output column c reads raw columns c+1 .. c+7)
     for (int i = threadIdx.x; i < kBlurRawH * (kBlurTileW / 4); i += 256) {
-        const int r = i / (kBlurTileW / 4), c = (i - r * (kBlurTileW / 4)) * 4;
-        const uint8_t* p = &raw[r * kBlurRawPitch + c + 1]; // output column c reads raw columns c+1 .. c+7
-        int v[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) v[k] = p[k];
+        const int c = (i / kBlurRawH) * 4, r = i - (i / kBlurRawH) * kBlurRawH; // rows fastest: conflict-free raw reads (19-dword pitch) and tmpT writes
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(&raw[r * kBlurRawPitch + c]);
+        const uint32_t A = p[0], B = p[1], C = p[2];
+        uint32_t s[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            int s = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) s += gk[k] * v[o + k];
-            tmp[r * kBlurTileW + c + o] = s;
+            const uint32_t lo = o == 3 ? B : __builtin_amdgcn_alignbyte(B, A, o + 1), hi = o == 3 ? C : __builtin_amdgcn_alignbyte(C, B, o + 1);
+            s[o] = __builtin_amdgcn_udot4(hi, W1, __builtin_amdgcn_udot4(lo, W0, 0u, false), false);
         }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) tmpT[(c + o) * kBlurTmpPitch + r] = (uint16_t)s[o];
     }
     __syncthreads();
-    // column pass: one lane = 4 consecutive rows of one column
+    // column pass: one lane = 4 consecutive rows of one column; rows come as (even, odd) u16 pairs, odd outputs use shifted weights
+    constexpr uint32_t E0 = 18u | 34u << 16, E1 = 49u | 55u << 16, E2 = 49u | 34u << 16, E3 = 18u;          // taps start on the pair
+    constexpr uint32_t O0 = 18u << 16, O1 = 34u | 49u << 16, O2 = 55u | 49u << 16, O3 = 34u | 18u << 16;    // taps start on its high half
     for (int i = threadIdx.x; i < (kBlurTileH / 4) * kBlurTileW; i += 256) {
         const int c = i & (kBlurTileW - 1), r = (i / kBlurTileW) * 4;
-        int v[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) v[k] = tmp[(r + k) * kBlurTileW + c];
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(&tmpT[c * kBlurTmpPitch + r]); // rows r .. r+9 as 5 pairs
+        const uint32_t p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4];
+        uint32_t s[4];
+        s[0] = udot2(p3, E3, udot2(p2, E2, udot2(p1, E1, udot2(p0, E0, 0u))));
+        s[1] = udot2(p3, O3, udot2(p2, O2, udot2(p1, O1, udot2(p0, O0, 0u))));
+        s[2] = udot2(p4, E3, udot2(p3, E2, udot2(p2, E1, udot2(p1, E0, 0u))));
+        s[3] = udot2(p4, O3, udot2(p3, O2, udot2(p2, O1, udot2(p1, O0, 0u))));
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            int s = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) s += gk[k] * v[o + k];
-            int px = (s + (1 << 15)) >> 16;
-            px = min(max(px, 0), 255);
+            const int px = min((int)((s[o] + (1u << 15)) >> 16), 255);
             const int x = ox + c, y = oy + r + o;
             if (x < W && y < H) dst[(size_t)y * dpitch + x] = (uint8_t)px;
         }
