@@ -1020,6 +1020,7 @@ int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes
 // pyramid (L2-resident gathers inside a 37x37 window); rotation cos/sin come precomputed per keypoint (d_cs, written
 // by the ANMS kernel with one lane per keypoint, so the f64 sin/cos is not repeated by all 64 lanes of a wave).
 constexpr int kDescWaves = 4;
+constexpr int kDescR = 19, kDescRows = 2 * kDescR + 1, kDescPitch = 40; // |pattern| <= 13 -> rotated radius <= 18.4; rows of 39 (+1) bytes
 
 __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable T, LevelTable LT, const uint8_t* __restrict__ d_imgs,
                                                                       size_t img_bytes, int pitch0, const uint8_t* __restrict__ d_pyr,
@@ -1042,6 +1043,40 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
     const float inv_scale = __fdiv_rn(1.f, LT.scale[l]);
     const int cx = __float2int_rn(__fmul_rn(kp.x, inv_scale)), cy = __float2int_rn(__fmul_rn(kp.y, inv_scale));
     const float ca = cs.x, sa = cs.y;
+    // Fast path (every keypoint the detector emits: edgeThreshold 31 > the rotated pattern radius 19): the wave stages the
+    // 39 x 40 byte neighbourhood of the blurred level in LDS with coalesced unaligned-dword row loads and gathers the 512
+    // samples from there -- scattered byte loads from global memory are bound by the texture-address line rate.
+    __shared__ __attribute__((aligned(16))) uint8_t patch[kDescWaves][kDescRows * kDescPitch];
+    const bool inside = cx - kDescR >= 0 && cx + kDescR + 1 < W && cy - kDescR >= 0 && cy + kDescR < H; // uniform per wave
+    if (inside) {
+        uint8_t* pl = patch[wave];
+        const uint8_t* org = blur + (size_t)(cy - kDescR) * bpitch + (cx - kDescR);
+#pragma unroll
+        for (int it = 0; it < (kDescRows * (kDescPitch / 4) + 63) / 64; ++it) {
+            const int i = lane + 64 * it, row = i / (kDescPitch / 4), col = i - row * (kDescPitch / 4);
+            if (row < kDescRows) {
+                uint32_t v;
+                __builtin_memcpy(&v, org + (size_t)row * bpitch + 4 * col, 4);
+                *reinterpret_cast<uint32_t*>(pl + row * kDescPitch + 4 * col) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier(); // LDS traffic of one wave is ordered; this only pins the compiler
+        int nibf = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const signed char* q = &c_pattern[(4 * lane + k) * 4];
+            const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+            const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
+            const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
+            const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
+            const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
+            const int t0 = pl[(iy0 + kDescR) * kDescPitch + ix0 + kDescR], t1 = pl[(iy1 + kDescR) * kDescPitch + ix1 + kDescR];
+            nibf |= (t0 < t1) << k;
+        }
+        const int hif = __shfl_down(nibf, 1);
+        if ((lane & 1) == 0) d_desc[((size_t)b * kp_capacity + j) * 32 + (lane >> 1)] = (uint8_t)(nibf | (hif << 4));
+        return;
+    }
     auto sample = [&](int ix, int iy) -> int {
         const int x = cx + ix, y = cy + iy;
         if (x >= 0 && x < W && y >= 0 && y < H) return blur[(size_t)y * bpitch + x];
