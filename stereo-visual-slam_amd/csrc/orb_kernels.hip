@@ -761,9 +761,8 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
     const int b = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem);                  // kMaxRows u64
-    float* sx = reinterpret_cast<float*>(smem + (size_t)kMaxRows * 8);                       // kMaxRows
-    float* sy = sx + kMaxRows;
-    float* sr = sy + kMaxRows;
+    float2* sxy = reinterpret_cast<float2*>(smem + (size_t)kMaxRows * 8);                    // kMaxRows (x, y) pairs: one broadcast read per candidate
+    float* sr = reinterpret_cast<float*>(sxy + kMaxRows);
     double* srad = reinterpret_cast<double*>(smem + (size_t)kMaxRows * 8 + (size_t)kMaxRows * 12); // kMaxRows
     uint16_t* sidx = reinterpret_cast<uint16_t*>(smem + (size_t)kMaxRows * 28);              // kMaxRows : source index per rank
     uint16_t* sord = sidx + kMaxRows;                                                        // kMaxRows : output order
@@ -810,7 +809,7 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
         for (int r = threadIdx.x; r < N; r += kAnmsBlock) {
             const int g = (int)(skey[r] & 0xFFFFFFFFu);
             const vslam_keypoint* kp = src_ptr(g);
-            sidx[r] = (uint16_t)g; sx[r] = kp->x; sy[r] = kp->y; sr[r] = kp->response;
+            sidx[r] = (uint16_t)g; sxy[r] = make_float2(kp->x, kp->y); sr[r] = kp->response;
         }
         __syncthreads();
         // ---- suppression radius (visual_odometry.cpp:124-138)
@@ -819,12 +818,14 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
             // first j in [0, i) with !(sr[j] > thr); sr is non-increasing
             int lo = 0, hi = i;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (sr[mid] > thr) lo = mid + 1; else hi = mid; }
-            const float xi = sx[i], yi = sy[i];
+            const float xi = sxy[i].x, yi = sxy[i].y;
             double best = 1.7976931348623157e308;
             bool any = false;
             for (int j = 0; j < lo; ++j) {
-                const float dx = __fsub_rn(xi, sx[j]), dy = __fsub_rn(yi, sy[j]);
-                const double d2 = __dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy));
+                const float2 pj = sxy[j];
+                const float dx = __fsub_rn(xi, pj.x), dy = __fsub_rn(yi, pj.y);
+                // dx^2 and dy^2 are exact in f64 (24-bit factors), so the fused form rounds once, exactly like mul + mul + add
+                const double d2 = __fma_rn((double)dx, (double)dx, __dmul_rn((double)dy, (double)dy));
                 best = fmin(best, d2);
                 any = true;
             }
