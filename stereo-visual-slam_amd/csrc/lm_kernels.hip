@@ -81,7 +81,6 @@ struct LmKernelArgs {
     const int32_t* pnp_n;
     int capacity;
     uint8_t* act;     // total_lm
-    uint8_t* eo;      // total_lm x kMaxKf
     int32_t* kf_pos;  // total_edge
     double* chi2k;    // total_edge: chi2 per edge in keyframe-major order (scattered to the caller's order at the end)
     float* uvk;       // 2 x total_edge: observations in keyframe-major order
@@ -287,7 +286,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         if (l < ncache) { const double2* q = reinterpret_cast<const double2*>(sDinv + 6 * l); Da = q[0]; Db = q[1]; Dc = q[2]; }
         else { const double2* q = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)l); Da = q[0]; Db = q[1]; Dc = q[2]; }
     };
-    double* db = a.db + 3 * (size_t)lm0;
     double* lin = a.lin + kLin * (size_t)e0;
     double* chi2 = a.chi2 + e0;
     double* chi2k = IMPL ? chi2 : ka.chi2k + e0;                       // keyframe-major (identity for the single-pose problem)
@@ -299,7 +297,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     int32_t* pair_ptr = a.pair_ptr + (size_t)w * (kMaxPairs + 1);
     int2* hits = reinterpret_cast<int2*>(a.pair_hits) + (size_t)e0 * kHitsPerEdge; // off-diagonal pairs only: {pos1 | pos2 << 16, landmark}
     uint8_t* act = ka.act + lm0;
-    uint8_t* eo = ka.eo + (size_t)lm0 * kMaxKf;
     const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
     const double delta = a.huber_delta;
     const bool with_lm = (mode == 0);
@@ -317,9 +314,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     double4* recA = reinterpret_cast<double4*>(lin);                       // {X, Y, 1/Z, w}
     double4* recA_alt = reinterpret_cast<double4*>(lin + 4 * (size_t)ne);
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
-    auto EKF = [&](int e) -> int { return IMPL ? 0 : kfi[e]; };
-    auto ELM = [&](int e) -> int { return IMPL ? e : lmi[e]; };
-    auto POS = [&](int e) -> int { return IMPL ? e : kf_pos[e]; };
 
     // ------------------------------------------------------------------ setup
     if (tid < 8) sm.flag[tid] = 0;
@@ -1172,7 +1166,6 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     const size_t o_Hll = need; need += al(total_lm * 6 * 8);
     const size_t o_bl = need; need += al(total_lm * 3 * 8);
     const size_t o_Di = need; need += al(total_lm * 6 * 8);
-    const size_t o_db = need; need += al(total_lm * 3 * 8);
     const size_t o_lin = need; need += al(total_edge * kLin * 8);
     const size_t o_lmptr = need; need += al((total_lm + n_windows + 1) * 4);
     const size_t o_kfptr = need; need += al((size_t)n_windows * (kMaxKf + 1) * 4);
@@ -1180,7 +1173,6 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     const size_t o_pp = need; need += al((size_t)n_windows * (kMaxPairs + 1) * 4);
     const size_t o_hits = need; need += with_lm ? al(total_edge * kHitsPerEdge * 8) : 256;
     const size_t o_act = need; need += al(total_lm);
-    const size_t o_eo = need; need += with_lm ? al(total_lm * kMaxKf) : 256;
     const size_t o_kpos = need; need += al(total_edge * 4);
     const size_t o_st = need; need += al((size_t)n_windows * 4);
     const size_t o_chi = need; need += al(total_edge * 8);
@@ -1190,10 +1182,10 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     if (g_lm.bytes < need) { hipStreamSynchronize(stream); int rc = ensure(&g_lm.buf, &g_lm.bytes, need); if (rc) return rc; }
     uint8_t* base = (uint8_t*)g_lm.buf;
     ka.a.P = (double*)(base + o_P); ka.a.Ptrial = (double*)(base + o_Pt); ka.a.Hll = (double*)(base + o_Hll);
-    ka.a.bl = (double*)(base + o_bl); ka.a.Dinv = (double*)(base + o_Di); ka.a.db = (double*)(base + o_db);
+    ka.a.bl = (double*)(base + o_bl); ka.a.Dinv = (double*)(base + o_Di);
     ka.a.lin = (double*)(base + o_lin); ka.a.lm_ptr = (int32_t*)(base + o_lmptr); ka.a.kf_ptr = (int32_t*)(base + o_kfptr);
     ka.a.kf_edges = (int32_t*)(base + o_kfe); ka.a.pair_ptr = (int32_t*)(base + o_pp); ka.a.pair_hits = (int32_t*)(base + o_hits);
-    ka.act = base + o_act; ka.eo = base + o_eo; ka.kf_pos = (int32_t*)(base + o_kpos); ka.status = (int32_t*)(base + o_st);
+    ka.act = base + o_act; ka.kf_pos = (int32_t*)(base + o_kpos); ka.status = (int32_t*)(base + o_st);
     g_lm.status = ka.status; g_lm.status_n = n_windows;
     if (!ka.a.chi2) ka.a.chi2 = (double*)(base + o_chi);
     ka.chi2k = (double*)(base + o_chik); ka.uvk = (float*)(base + o_uvk);

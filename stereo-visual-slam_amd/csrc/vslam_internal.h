@@ -159,13 +159,12 @@ struct LmWindowArgs {
     double* Hll;    // total_lm x 6
     double* bl;     // total_lm x 3
     double* Dinv;   // total_lm x 6
-    double* db;     // total_lm x 3
     double* lin;    // total_edge x 6 : X Y Z w ex ey at the linearisation point
     int32_t* lm_ptr;   // total_lm + n_windows (CSR by landmark, window-local edge ids, built in-kernel)
     int32_t* kf_ptr;   // n_windows x (MAX_KF + 1)
     int32_t* kf_edges; // total_edge (edge ids grouped by keyframe, ascending inside a group)
     int32_t* pair_ptr; // n_windows x (NPAIR + 1)
-    int32_t* pair_hits;// hits: (e1, e2) packed as two int32  -> 2 x hit_capacity
+    int32_t* pair_hits;// Schur hit records of the off-diagonal keyframe pairs: {pos1 | pos2 << 16, landmark} (8 B each)
     int32_t hit_capacity_per_edge; // hits of a window <= n_edges_w * hit_capacity_per_edge
     double K[4];
     double huber_delta;
