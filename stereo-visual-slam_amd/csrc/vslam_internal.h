@@ -159,10 +159,10 @@ struct LmWindowArgs {
     double* Hll;    // total_lm x 6
     double* bl;     // total_lm x 3
     double* Dinv;   // total_lm x 6
-    double* lin;    // total_edge x 6 : X Y Z w ex ey at the linearisation point
+    double* lin;    // total_edge x 8 : two sets of {X, Y, 1/Z, w} records (current / trial state), keyframe-major
     int32_t* lm_ptr;   // total_lm + n_windows (CSR by landmark, window-local edge ids, built in-kernel)
     int32_t* kf_ptr;   // n_windows x (MAX_KF + 1)
-    int32_t* kf_edges; // total_edge (edge ids grouped by keyframe, ascending inside a group)
+    int32_t* kf_edges; // total_edge: landmark id of the edge stored at keyframe-major position j
     int32_t* pair_ptr; // n_windows x (NPAIR + 1)
     int32_t* pair_hits;// Schur hit records of the off-diagonal keyframe pairs: {pos1 | pos2 << 16, landmark} (8 B each)
     int32_t hit_capacity_per_edge; // hits of a window <= n_edges_w * hit_capacity_per_edge
