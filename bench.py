@@ -127,8 +127,9 @@ def main():
 
     def one_step():
         pipe.step()
-        if world > 1:  # throughput-mode pose gather (RCCL over xGMI), 56 B per keyframe
-            gather_poses(pipe.d_Tpnp, dist)
+        if world > 1:  # throughput-mode pose gather (RCCL over xGMI), 56 B per keyframe; ordered after the step on its stream
+            with torch.cuda.stream(pipe.stream):
+                gather_poses(pipe.d_Tpnp, dist)
 
     for _ in range(args.warmup):
         one_step()

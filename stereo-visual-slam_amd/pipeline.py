@@ -24,7 +24,9 @@ class KeyframePipeline:
         self.B = B
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
-        self.stream = torch.cuda.current_stream(self.dev)
+        # One explicit stream for the library AND for the few torch ops between its calls (copies of initial guesses, the pose
+        # gather): torch's default stream has handle 0, which the C-ABI reads as "create your own stream" -- the two would race.
+        self.stream = torch.cuda.Stream(self.dev)
         self.with_ba = with_ba
         p = default_params(max_batch=2 * B, anms_num=anms_num)
         self.vo = VO(params=p, device=device, stream=self.stream.cuda_stream)
@@ -135,15 +137,17 @@ class KeyframePipeline:
         vo.build_pnp_inputs_dev(self.d_f2f.data_ptr(), self.d_nf2f.data_ptr(), cap, self.d_lr.data_ptr(), self.d_nlr.data_ptr(), cap,
                                 self.d_xyz.data_ptr(), self.d_valid.data_ptr(), self.d_kps.data_ptr() + cap * 28, cap, n, self.d_kp2lr.data_ptr(),
                                 self.d_pxyz.data_ptr(), self.d_puv.data_ptr(), self.d_pn.data_ptr(), cap)
-        self.d_Tpnp.copy_(self.d_Tident)
+        with torch.cuda.stream(self.stream):
+            self.d_Tpnp.copy_(self.d_Tident)
         vo.motion_estimation_dev(self.d_pxyz.data_ptr(), self.d_puv.data_ptr(), self.d_pn.data_ptr(), cap, n, self.d_Tpnp.data_ptr(), 10,
                                  self.d_inl.data_ptr(), self.d_ninl.data_ptr())
 
     def stage_ba(self):
         if not self.with_ba:
             return
-        self.ba_T.copy_(self.ba_T0)
-        self.ba_inl.fill_(1)
+        with torch.cuda.stream(self.stream):
+            self.ba_T.copy_(self.ba_T0)
+            self.ba_inl.fill_(1)
         self.vo.ba_batch_dev(self.ba_batch, schedule=1)
 
     def step(self):
