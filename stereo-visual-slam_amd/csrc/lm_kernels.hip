@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
                     lin_record(R, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
                     part += rho;
-                    dstA[j] = make_double4(X, Y, Zi, wgt);
+                    if (with_lm) dstA[j] = make_double4(X, Y, Zi, wgt); // only the Schur passes read the records back
                     jac_pose(K, X, Y, Zi, A);
 #pragma unroll
                     for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
