@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (not part of pytest: minutes of runtime).  Sizes and seeds are drawn at random;
+any mismatch prints the reproducer and exits non-zero.  usage: python tools/fuzz_parity.py [--seconds 120] [--seed 0]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oracle as O
+import stereo_visual_slam_amd as pkg
+from stereo_visual_slam_amd import synth
+
+ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+O.build()
+rng = np.random.default_rng(a.seed)
+vo = pkg.VO(device=0, max_batch=2)
+t_end = time.time() + a.seconds
+n = dict(match=0, sgbm=0, orb=0, ba=0, pnp=0, ransac=0)
+
+
+def fail(what, **kw):
+    print("MISMATCH", what, kw); sys.exit(1)
+
+
+def kps_equal(x, y):
+    return len(x) == len(y) and all(np.array_equal(x[f], y[f]) for f in ("x", "y", "size", "angle", "response", "octave", "class_id"))
+
+
+while time.time() < t_end:
+    kind = rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac"])
+    seed = int(rng.integers(1 << 30))
+    if kind == "match":
+        nq, nt = int(rng.integers(1, 2200)), int(rng.integers(1, 2200))
+        if rng.random() < 0.2: nq = int(rng.integers(1, 70))
+        if rng.random() < 0.2: nt = int(rng.integers(1, 70))
+        q, t = synth.random_descriptors(nq, nt, seed=seed, tie_frac=float(rng.choice([0.0, 0.05, 0.5])))
+        gap = float(rng.integers(1, 4))
+        for gate in (False, True):
+            g = vo.feature_matching(q, t, gap, gate=gate)
+            w = O.feature_matching(q, t, gap) if gate else O.bf_match_xcheck(q, t)
+            if len(g) != len(w) or any(not np.array_equal(g[f], w[f]) for f in ("queryIdx", "trainIdx", "distance")):
+                fail("match", nq=nq, nt=nt, seed=seed, gate=gate)
+    elif kind == "sgbm":
+        w, h = int(rng.integers(100, 700)), int(rng.integers(10, 200))
+        L = synth.noise_image(seed % 1000, w + 40, h)
+        sh = int(rng.integers(0, 40))
+        Lc = np.ascontiguousarray(L[:, :w]); R = np.ascontiguousarray(L[:, sh:sh + w]).copy()
+        if rng.random() < 0.5:
+            R = np.clip(R.astype(int) + rng.integers(-15, 16, R.shape), 0, 255).astype(np.uint8)
+        gf, gi, graw = vo.disparity_map(Lc, R, return_i16=True)
+        wi, wraw = O.sgbm_compute(Lc, R, return_raw=True)
+        if not (np.array_equal(graw, wraw) and np.array_equal(gi, wi)):
+            fail("sgbm", w=w, h=h, seed=seed, shift=sh)
+    elif kind == "orb":
+        w, h = int(rng.integers(96, 900)), int(rng.integers(96, 500))
+        img = synth.noise_image(seed % 100000, w, h)
+        nf = int(rng.choice([300, 1000, 3000])); an = int(rng.choice([50, 100, 500]))
+        ctx = pkg.VO(device=0, max_batch=1, img_w=w, img_h=h, orb_nfeatures=nf, anms_num=an)
+        try:
+            if not kps_equal(ctx.orb_detect(img), O.orb_detect(img, nf)):
+                fail("orb_detect", w=w, h=h, seed=seed, nf=nf)
+            k, d = ctx.feature_detection(img); wk, wd = O.feature_detection(img, nf, an)
+            if not (kps_equal(k, wk) and np.array_equal(d, wd)):
+                fail("feature_detection", w=w, h=h, seed=seed, nf=nf, an=an)
+        finally:
+            ctx.close()
+    elif kind == "ba":
+        nk = int(rng.integers(1, 13)); nl = int(rng.choice([40, 300, 1500, 2600]))
+        win = synth.ba_window(n_kf=nk, n_lm=nl, seed=seed, max_obs=min(5, nk), min_obs=min(2, nk))
+        it = int(rng.integers(1, 11))
+        r = vo.optimize_map(win["T0"], win["xyz"], win["kf_idx"], win["lm_idx"], win["uv"], True, True, it)
+        T, x, chi2, st = O.local_ba(win["T0"], win["xyz"], win["kf_idx"], win["lm_idx"], win["uv"], iters=it, update_poses=True, update_lms=True)
+        if not (np.allclose(r["T"], T, rtol=1e-4, atol=1e-6) and np.allclose(r["xyz"], x, rtol=1e-4, atol=1e-4)):
+            fail("local_ba", nk=nk, nl=nl, seed=seed, iters=it)
+    elif kind == "pnp":
+        M = int(rng.integers(4, 1500))
+        p = synth.pnp_problem(M=M, seed=seed, outlier_frac=float(rng.choice([0.0, 0.15, 0.4])))
+        gT, gi, gn, _ = vo.motion_estimation(p["xyz"], p["uv"], p["T0"], iters=10)
+        wT, wi, wn, _ = O.pnp_motion_only(p["xyz"], p["uv"], p["T0"], iters=10)
+        if not (np.allclose(gT, wT, rtol=1e-4, atol=1e-6) and gn == wn):
+            fail("pnp", M=M, seed=seed)
+    else:
+        M = int(rng.integers(5, 1200))
+        p = synth.pnp_problem(M=M, seed=seed, outlier_frac=float(rng.choice([0.0, 0.2, 0.45])), sigma_px=0.4)
+        gT, gi, gn, git = vo.motion_estimation_ransac(p["xyz"], p["uv"], p["T0"])
+        wT, wi, wn, wit = O.pnp_ransac(p["xyz"], p["uv"], p["T0"])
+        if not (git == wit and gn == wn and np.array_equal(gi, wi) and np.allclose(gT, wT, rtol=1e-4, atol=1e-6)):
+            fail("ransac", M=M, seed=seed, got=(gn, git), want=(wn, wit))
+    n[kind] += 1
+print("fuzz ok:", n)
+vo.close()
