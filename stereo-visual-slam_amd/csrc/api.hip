@@ -199,6 +199,7 @@ void vslam_destroy(vslam_ctx* ctx) {
     hipStreamSynchronize(c->stream);
     orb_tables_free(&c->tab);
     if (c->d_sgbm) hipFree(c->d_sgbm);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
     void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs,
                     c->match.d_train_best, c->match.d_q8, c->match.d_t8, c->d_stage};
     for (void* q : ptrs) if (q) hipFree(q);
@@ -216,10 +217,28 @@ int vslam_sync(vslam_ctx* ctx) {
 size_t vslam_device_bytes(const vslam_ctx* ctx) { return ctx ? reinterpret_cast<const Ctx*>(ctx)->dev_bytes : 0; }
 
 // ---------------------------------------------------------------------------------------------- ORB, host buffers
-static int upload_image(Ctx* c, Arena& ar, const uint8_t* img, int w, int h, int stride, uint8_t** d_img, int* pitch) {
+// Host image -> device image with a 64-byte row pitch.  The rows are repacked on the host into a pinned staging buffer and
+// sent as ONE linear copy: hipMemcpy2DAsync from pageable memory degenerates into a copy per row (measured 2.8 ms for a
+// 1241x376 image against 0.03 ms for the same bytes as one block).  Several images of one call use consecutive slots.
+static int upload_image(Ctx* c, Arena& ar, const uint8_t* img, int w, int h, int stride, uint8_t** d_img, int* pitch, int slot = 0) {
     *pitch = (w + 63) & ~63;
-    *d_img = arena_take<uint8_t>(ar, (size_t)*pitch * h);
-    VS_HIP(hipMemcpy2DAsync(*d_img, *pitch, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    const size_t bytes = (size_t)*pitch * h;
+    *d_img = arena_take<uint8_t>(ar, bytes);
+    const size_t need = bytes * (size_t)(slot + 1);
+    if (c->pinned_bytes < need) {
+        VS_HIP(hipStreamSynchronize(c->stream));
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr; c->pinned_bytes = 0;
+        const size_t want = std::max(need, 2 * bytes);
+        VS_HIP(hipHostMalloc((void**)&c->h_pinned, want, hipHostMallocDefault));
+        c->pinned_bytes = want;
+    }
+    uint8_t* stage = c->h_pinned + bytes * (size_t)slot;
+    for (int y = 0; y < h; ++y) {
+        memcpy(stage + (size_t)y * *pitch, img + (size_t)y * stride, (size_t)w);
+        memset(stage + (size_t)y * *pitch + w, 0, (size_t)(*pitch - w)); // deterministic padding
+    }
+    VS_HIP(hipMemcpyAsync(*d_img, stage, bytes, hipMemcpyHostToDevice, c->stream));
     return VSLAM_OK;
 }
 
@@ -406,7 +425,7 @@ int vslam_disparity_map(vslam_ctx* ctx, const uint8_t* left, const uint8_t* righ
     Arena ar(c);
     uint8_t *d_l, *d_r; int pl, pr;
     if ((rc = upload_image(c, ar, left, w, h, stride, &d_l, &pl))) return rc;
-    if ((rc = upload_image(c, ar, right, w, h, stride, &d_r, &pr))) return rc;
+    if ((rc = upload_image(c, ar, right, w, h, stride, &d_r, &pr, 1))) return rc;
     float* d_f = arena_take<float>(ar, npix);
     int16_t* d_i = arena_take<int16_t>(ar, npix);
     int16_t* d_raw = arena_take<int16_t>(ar, npix);
