@@ -735,6 +735,7 @@ int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
 
 // ------------------------------------------------------------------------------------------- K5 ANMS
 constexpr int kAnmsBlock = 1024;
+constexpr int kAnmsBrute = 160; // at most this many stronger keypoints: scanning them beats walking the grid
 
 __device__ inline int block_rank_1024(bool flag, int* s_wave_tot, int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -770,6 +771,7 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
     int* s_wave_tot = reinterpret_cast<int*>(smem + (size_t)kMaxRows * 32 + 16);             // kAnmsBlock / 64
     int* s_off = s_wave_tot + kAnmsBlock / 64;                                               // kNLevels + 1
 
+    OPH_INIT();
     // ---- gather (lists in order): flat index g -> (list, i)
     if (threadIdx.x == 0) {
         int acc = 0;
@@ -812,7 +814,49 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
             sidx[r] = (uint16_t)g; sxy[r] = make_float2(kp->x, kp->y); sr[r] = kp->response;
         }
         __syncthreads();
-        // ---- suppression radius (visual_odometry.cpp:124-138)
+        OPH(24);
+        // ---- suppression radius (visual_odometry.cpp:124-138): distance to the nearest keypoint whose response exceeds
+        // 1.11 x mine, i.e. to the nearest of the ranks [0, lo).  The reference scans all of them (O(N^2)); here the keypoints
+        // are binned into a uniform grid (cell lists sorted by rank) and a query walks outward ring by ring until the best
+        // distance found is below the distance to the unvisited cells.  Only candidates that cannot be the minimum are
+        // skipped and every distance is evaluated exactly as before, so the radii are bit-identical.
+        const int csz = max(32, (int)ceilf(sqrtf((float)img_w * (float)img_h * (1.f / 900.f))));
+        const int gx = min(max((img_w + csz - 1) / csz, 1), 1023), gy = max(min((img_h + csz - 1) / csz, 1023 / gx), 1), ncell = gx * gy;
+        int* ccnt = reinterpret_cast<int*>(skey);                 // the sort buffer is free until the radius sort
+        int* coff = ccnt + 1024;
+        uint16_t* tmpl = reinterpret_cast<uint16_t*>(coff + 1024); // ranks per cell, arrival order
+        uint16_t* clist = tmpl + kMaxRows;                          // ranks per cell, ascending
+        uint16_t* cof = clist + kMaxRows;                           // cell of every rank
+        auto cell_of = [&](float x, float y) -> int {
+            const int cx = min(max((int)(x / (float)csz), 0), gx - 1), cy = min(max((int)(y / (float)csz), 0), gy - 1);
+            return cy * gx + cx;
+        };
+        for (int c = threadIdx.x; c <= ncell; c += kAnmsBlock) ccnt[c] = 0;
+        __syncthreads();
+        for (int r = threadIdx.x; r < N; r += kAnmsBlock) { const int c = cell_of(sxy[r].x, sxy[r].y); cof[r] = (uint16_t)c; atomicAdd(&ccnt[c], 1); }
+        __syncthreads();
+        if (threadIdx.x < 64) { // exclusive prefix over the cells by one wave (16 cells per lane)
+            const int per = (ncell + 63) / 64, c0 = threadIdx.x * per, c1 = min(c0 + per, ncell);
+            int mine = 0;
+            for (int c = c0; c < c1; ++c) mine += ccnt[c];
+            int incl = mine;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += t; }
+            int run = incl - mine;
+            for (int c = c0; c < c1; ++c) { const int n = ccnt[c]; coff[c] = run; run += n; }
+            if (threadIdx.x == 63) coff[ncell] = incl;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < ncell; c += kAnmsBlock) ccnt[c] = 0;
+        __syncthreads();
+        for (int r = threadIdx.x; r < N; r += kAnmsBlock) { const int c = cof[r]; tmpl[coff[c] + atomicAdd(&ccnt[c], 1)] = (uint16_t)r; }
+        __syncthreads();
+        for (int r = threadIdx.x; r < N; r += kAnmsBlock) { // rank-sorted position inside the cell (arrival order is not deterministic)
+            const int c = cof[r], o0 = coff[c], o1 = coff[c + 1];
+            int pos = 0;
+            for (int t = o0; t < o1; ++t) pos += tmpl[t] < r;
+            clist[o0 + pos] = (uint16_t)r;
+        }
+        __syncthreads();
         for (int i = threadIdx.x; i < N; i += kAnmsBlock) {
             const float thr = __fmul_rn(sr[i], 1.11f);
             // first j in [0, i) with !(sr[j] > thr); sr is non-increasing
@@ -820,24 +864,51 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (sr[mid] > thr) lo = mid + 1; else hi = mid; }
             const float xi = sxy[i].x, yi = sxy[i].y;
             double best = 1.7976931348623157e308;
-            bool any = false;
-            for (int j = 0; j < lo; ++j) {
+            auto visit = [&](int j) {
                 const float2 pj = sxy[j];
                 const float dx = __fsub_rn(xi, pj.x), dy = __fsub_rn(yi, pj.y);
                 // dx^2 and dy^2 are exact in f64 (24-bit factors), so the fused form rounds once, exactly like mul + mul + add
-                const double d2 = __fma_rn((double)dx, (double)dx, __dmul_rn((double)dy, (double)dy));
-                best = fmin(best, d2);
-                any = true;
+                best = fmin(best, __fma_rn((double)dx, (double)dx, __dmul_rn((double)dy, (double)dy)));
+            };
+            if (lo <= kAnmsBrute) {
+                for (int j = 0; j < lo; ++j) visit(j);
+            } else {
+                const int ci = cof[i], cxi = ci % gx, cyi = ci / gx;
+                const int kmax = max(max(cxi, gx - 1 - cxi), max(cyi, gy - 1 - cyi));
+                for (int k = 0; k <= kmax; ++k) {
+                    if (k > 0) { // every unvisited keypoint lies outside the square of rings < k
+                        const double bx = fmin((double)xi - (double)((cxi - k + 1) * csz), (double)((cxi + k) * csz) - (double)xi);
+                        const double by = fmin((double)yi - (double)((cyi - k + 1) * csz), (double)((cyi + k) * csz) - (double)yi);
+                        const double bnd = fmin(bx, by) * (1.0 - 1e-6); // (margin: the reference's dx, dy are f32-rounded differences)
+                        if (bnd > 0 && best <= bnd * bnd) break;
+                    }
+                    const int y0 = cyi - k, y1 = cyi + k, x0 = cxi - k, x1 = cxi + k;
+                    for (int cy = max(y0, 0); cy <= min(y1, gy - 1); ++cy) {
+                        const bool edge_row = cy == y0 || cy == y1;
+                        const int step = (edge_row || k == 0) ? 1 : 2 * k; // interior rows of the ring: only the two end cells
+                        for (int cx = x0; cx <= x1; cx += step) {
+                            if (cx < 0 || cx >= gx) continue;
+                            const int c = cy * gx + cx;
+                            for (int t = coff[c], t1 = coff[c + 1]; t < t1; ++t) {
+                                const int j = clist[t];
+                                if (j >= lo) break; // the list ascends in rank
+                                visit(j);
+                            }
+                        }
+                    }
+                }
             }
-            srad[i] = any ? sqrt(best) : 1.7976931348623157e308;
+            srad[i] = lo > 0 ? sqrt(best) : 1.7976931348623157e308;
         }
         __syncthreads();
+        OPH(25);
         // ---- the num-th largest radius (:141-146): sort the radii descending
         for (int g = threadIdx.x; g < np2; g += kAnmsBlock) skey[g] = g < N ? ~(unsigned long long)__double_as_longlong(srad[g]) : ~0ull;
         __syncthreads();
         bitonic_sort_lds(skey, np2);
         if (threadIdx.x == 0) s_final = ~skey[anms_num - 1];
         __syncthreads();
+        OPH(26);
         const double final_radius = __longlong_as_double((long long)s_final);
         // ---- keep rad >= final radius, in response order (:147-153)
         int written = 0;
@@ -879,6 +950,7 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
         if (cnt > kp_capacity) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStOutOverflow); cnt = kp_capacity; }
         for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) emit(r, src_ptr(sord[k32[r] & 0xFFFFu]));
         if (threadIdx.x == 0) d_count[b] = cnt;
+        OPH(27);
     } else {
         int cnt = M;
         if (cnt > kp_capacity) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStOutOverflow); cnt = kp_capacity; }

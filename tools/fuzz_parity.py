@@ -8,7 +8,7 @@ import oracle as O
 import stereo_visual_slam_amd as pkg
 from stereo_visual_slam_amd import synth
 
-ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0)
+ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--only", default="")
 a = ap.parse_args()
 O.build()
 rng = np.random.default_rng(a.seed)
@@ -26,7 +26,7 @@ def kps_equal(x, y):
 
 
 while time.time() < t_end:
-    kind = rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac"])
+    kind = a.only or rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac"])
     seed = int(rng.integers(1 << 30))
     if kind == "match":
         nq, nt = int(rng.integers(1, 2200)), int(rng.integers(1, 2200))
@@ -51,9 +51,9 @@ while time.time() < t_end:
         if not (np.array_equal(graw, wraw) and np.array_equal(gi, wi)):
             fail("sgbm", w=w, h=h, seed=seed, shift=sh)
     elif kind == "orb":
-        w, h = int(rng.integers(96, 900)), int(rng.integers(96, 500))
+        w, h = int(rng.integers(96, 1400)), int(rng.integers(96, 700))
         img = synth.noise_image(seed % 100000, w, h)
-        nf = int(rng.choice([300, 1000, 3000])); an = int(rng.choice([50, 100, 500]))
+        nf = int(rng.choice([300, 1000, 3000])); an = int(rng.choice([50, 100, 500, 1500]))
         ctx = pkg.VO(device=0, max_batch=1, img_w=w, img_h=h, orb_nfeatures=nf, anms_num=an)
         try:
             if not kps_equal(ctx.orb_detect(img), O.orb_detect(img, nf)):
