@@ -50,6 +50,20 @@ def algorithmic_bytes(kernel, pipe, anms_num):
     return 0, "n/a"
 
 
+def other_rooflines(prof, pipe, args):
+    """the one MFMA kernel of the path (the matcher's Hamming table) against the dense int8 peak; informative only"""
+    out = []
+    k = prof.get("match_train_nearest_kernel")
+    if k and k[0] > 0:
+        n = float(args.anms)
+        items = pipe.B + max(pipe.B - 1, 0)                      # L/R call + frame-to-frame call per step
+        macs = items * n * n * 256.0 * args.steps               # +-1 byte products per step
+        tops = 2.0 * macs / (k[0] / 1e3) / 1e12
+        out.append({"kernel": "match_train_nearest_kernel", "bound": "mfma", "achieved": round(tops, 1), "peak": 5000.0, "unit": "TOP/s (int8)",
+                    "frac": round(tops / 5000.0, 4), "note": "v_mfma_i32_32x32x32_i8; 4250 TOP/s sustained in tools/scratch/mfma_rate.hip"})
+    return out
+
+
 def cpu_baseline(pipe, anms_num, n_keyframes=3):
     """the CPU oracle (single thread) on a bounded sample of the same workload: `n_keyframes` stereo keyframes + windows"""
     import oracle as O
@@ -183,6 +197,7 @@ def main():
                          "algorithmic_bytes_per_launch_set": int(alg), "formula": formula,
                          "avg_ms_per_launch_set": round(1e3 * per_bracket_s, 4), "kernel_launches_per_set": dom_launches // max(dom_calls, 1)},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kern},
+            "other_rooflines": other_rooflines(prof, pipe, args),
             "stats": {"keypoints_per_image": float(out["cnt"].mean()), "lr_matches": float(out["nlr"].mean()),
                       "f2f_matches": float(out["nf2f"][:max(B - 1, 1)].mean()), "pnp_points": float(out["pn"][:max(B - 1, 1)].mean()),
                       "pnp_inliers": float(out["ninl"][:max(B - 1, 1)].mean())},
