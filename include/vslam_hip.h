@@ -150,6 +150,12 @@ int vslam_find_3d_disparity(vslam_ctx* ctx, const vslam_keypoint* kps, int n, co
 int vslam_triangulate(vslam_ctx* ctx, const float* uvL, const float* uvR, int n, const double T_c_w[7],
                       float* xyz_w, uint8_t* valid, uint8_t* reliable, int* n_valid);
 
+/* Batched, device-resident form of the above: item b = d_n[b] keypoints at d_kps + b*kp_capacity, disparity map
+ * d_disparity + b*h*w (tightly packed f32, e.g. the output of vslam_disparity_map_dev), pose d_T_c_w + 7*b. */
+int vslam_find_3d_disparity_dev(vslam_ctx* ctx, const vslam_keypoint* d_kps, const int32_t* d_n, int kp_capacity, int B,
+                                const float* d_disparity, int w, int h, const double* d_T_c_w, float* d_xyz_w,
+                                uint8_t* d_valid, uint8_t* d_reliable);
+
 /* Batched, device-resident: item b has d_n[b] pairs at offset b*capacity; pose d_T_c_w + 7*b. */
 int vslam_triangulate_dev(vslam_ctx* ctx, const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B,
                           const double* d_T_c_w, float* d_xyz_w, uint8_t* d_valid, uint8_t* d_reliable);

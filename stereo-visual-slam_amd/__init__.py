@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
-    "vslam_profile_enable", "vslam_profile_read", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac",
+    "vslam_profile_enable", "vslam_profile_read", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_find_3d_disparity_dev",
 ]
 
 
@@ -267,6 +267,10 @@ class VO:
         self._chk(self.lib.vslam_find_3d_disparity(self.h, _p(kps), n, _p(disparity), disparity.shape[1], disparity.shape[0],
                                                    disparity.shape[1], _p(T), _p(xyz), _p(valid), _p(rel), None), "vslam_find_3d_disparity")
         return xyz[:n], valid[:n], rel[:n]
+
+    def find_3d_disparity_dev(self, d_kps, d_n, kp_capacity, B, d_disp, w, h, d_T, d_xyz, d_valid, d_rel):
+        self._chk(self.lib.vslam_find_3d_disparity_dev(self.h, _p(d_kps), _p(d_n), int(kp_capacity), int(B), _p(d_disp), int(w), int(h), _p(d_T),
+                                                       _p(d_xyz), _p(d_valid), _p(d_rel)), "vslam_find_3d_disparity_dev")
 
     def triangulate(self, uvL, uvR, T_c_w):
         uvL = np.ascontiguousarray(uvL, np.float32).reshape(-1, 2); uvR = np.ascontiguousarray(uvR, np.float32).reshape(-1, 2)

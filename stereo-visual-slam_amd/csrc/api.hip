@@ -466,6 +466,13 @@ int vslam_find_3d_disparity(vslam_ctx* ctx, const vslam_keypoint* kps, int n, co
     return VSLAM_OK;
 }
 
+int vslam_find_3d_disparity_dev(vslam_ctx* ctx, const vslam_keypoint* d_kps, const int32_t* d_n, int kp_capacity, int B, const float* d_disparity,
+                                int w, int h, const double* d_T_c_w, float* d_xyz_w, uint8_t* d_valid, uint8_t* d_reliable) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_kps || !d_n || !d_disparity || !d_T_c_w || !d_xyz_w || !d_valid || !d_reliable || kp_capacity <= 0 || w <= 0 || h <= 0 || B < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    return launch_find3d_disparity_batch(d_kps, d_n, kp_capacity, B, d_disparity, w, h, d_T_c_w, cam_of(c), d_xyz_w, d_valid, d_reliable, c->stream);
+}
+
 int vslam_triangulate_dev(vslam_ctx* ctx, const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B,
                           const double* d_T_c_w, float* d_xyz_w, uint8_t* d_valid, uint8_t* d_reliable) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);

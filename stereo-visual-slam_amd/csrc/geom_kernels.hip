@@ -50,6 +50,25 @@ __global__ __launch_bounds__(256) void find3d_disparity_kernel(const vslam_keypo
     gate_store(p, Rinv, tinv, cam, i, xyz, valid, rel);
 }
 
+// batched form: item b has d_n[b] keypoints at kps + b * kp_capacity and its own disparity map and pose
+__global__ __launch_bounds__(256) void find3d_disparity_batch_kernel(const vslam_keypoint* __restrict__ kps, const int32_t* __restrict__ d_n,
+                                                                    int kp_capacity, const float* __restrict__ disp, int w, int h,
+                                                                    const double* __restrict__ d_T, CamParams cam, float* __restrict__ xyz,
+                                                                    uint8_t* __restrict__ valid, uint8_t* __restrict__ rel) {
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(d_n[b], kp_capacity)) return;
+    const size_t i = (size_t)b * kp_capacity + k;
+    double Rinv[9], tinv[3];
+    inverse_pose(d_T + 7 * b, Rinv, tinv);
+    const float u = kps[i].x, v = kps[i].y;
+    const int r = (int)v, c = (int)u; // quirk Q3: truncation
+    if (r < 0 || r >= h || c < 0 || c >= w) { valid[i] = 0; rel[i] = 0; xyz[3 * i] = xyz[3 * i + 1] = xyz[3 * i + 2] = 0.f; return; }
+    const double x = ((double)u - cam.cx) / cam.fx, y = ((double)v - cam.cy) / cam.fy;
+    const double depth = cam.fx * cam.b / (double)disp[((size_t)b * h + r) * w + c];
+    const double p[3] = {x * depth, y * depth, depth};
+    gate_store(p, Rinv, tinv, cam, i, xyz, valid, rel);
+}
+
 __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restrict__ uvL, const float* __restrict__ uvR,
                                                          const int32_t* __restrict__ d_n, int capacity, const double* __restrict__ d_T,
                                                          CamParams cam, float* __restrict__ xyz, uint8_t* __restrict__ valid,
@@ -161,6 +180,16 @@ int launch_find3d_disparity(const vslam_keypoint* d_kps, int n, const float* d_d
     if (n <= 0) return VSLAM_OK;
     hipLaunchKernelGGL(find3d_disparity_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_kps, n, d_disp, w, h, dstride, d_T, cam,
                        d_xyz, d_valid, d_rel);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+int launch_find3d_disparity_batch(const vslam_keypoint* d_kps, const int32_t* d_n, int kp_capacity, int B, const float* d_disp, int w, int h,
+                                  const double* d_T, CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream) {
+    if (B <= 0) return VSLAM_OK;
+    ProfScope prof__(stream, "find3d_disparity_kernel");
+    hipLaunchKernelGGL(find3d_disparity_batch_kernel, dim3((kp_capacity + 255) / 256, B), dim3(256), 0, stream, d_kps, d_n, kp_capacity, d_disp, w, h,
+                       d_T, cam, d_xyz, d_valid, d_rel);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }

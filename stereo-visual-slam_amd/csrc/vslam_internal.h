@@ -129,6 +129,8 @@ int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const
 struct CamParams { double fx, fy, cx, cy, b, dmin, dmax, drel; };
 int launch_find3d_disparity(const vslam_keypoint* d_kps, int n, const float* d_disp, int w, int h, int dstride,
                             const double* d_T, CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream);
+int launch_find3d_disparity_batch(const vslam_keypoint* d_kps, const int32_t* d_n, int kp_capacity, int B, const float* d_disp, int w, int h,
+                                  const double* d_T, CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream);
 int launch_triangulate(const float* d_uvL, const float* d_uvR, const int32_t* d_n, int capacity, int B, const double* d_T,
                        CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream);
 // f2f matches + per-keypoint 3-D points of the query frame -> compact (xyz, uv) PnP inputs (ordered, valid only)

@@ -20,7 +20,11 @@ from . import synth
 
 class KeyframePipeline:
     def __init__(self, B, device=0, anms_num=1500, n_lm=3000, n_kf=10, unique_scenes=4, unique_windows=4, seed=0, verbose=False,
-                 with_ba=True):
+                 with_ba=True, depth="match"):
+        """depth = "match": north_star stage (right-image ORB, L/R match, DLT); "sgbm": the reference's own depth path
+        (VO::disparity_map + Frame::find_3d on the left keypoints; the right image is only consumed by SGBM)"""
+        assert depth in ("match", "sgbm")
+        self.depth = depth
         self.B = B
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -68,6 +72,11 @@ class KeyframePipeline:
         self.d_xyz = torch.zeros((B, self.cap, 3), dtype=torch.float32, device=d)
         self.d_valid = torch.zeros((B, self.cap), dtype=torch.uint8, device=d)
         self.d_rel = torch.zeros((B, self.cap), dtype=torch.uint8, device=d)
+        if depth == "sgbm":
+            self.d_disp = torch.zeros((B, self.h, self.w), dtype=torch.float32, device=d)
+            ident_lr = np.zeros((B, self.cap), DMATCH_DTYPE)
+            ident_lr["queryIdx"] = np.arange(self.cap)[None, :]; ident_lr["trainIdx"] = np.arange(self.cap)[None, :]
+            self.d_lr = torch.from_numpy(ident_lr.view(np.uint8).reshape(B, self.cap, 16)).to(d)  # keypoint i <-> landmark slot i
         # ---- PnP
         self.d_kp2lr = torch.zeros((B, self.cap), dtype=torch.int32, device=d)
         self.d_pxyz = torch.zeros((B, self.cap, 3), dtype=torch.float32, device=d)
@@ -111,12 +120,22 @@ class KeyframePipeline:
 
     # ------------------------------------------------------------------ stages
     def stage_orb(self):
-        self.vo.feature_detection_dev(self.d_imgs.data_ptr(), self.img_bytes, self.pitch, 2 * self.B, self.d_kps.data_ptr(),
+        n_img = self.B if self.depth == "sgbm" else 2 * self.B  # the reference never detects on the right image
+        self.vo.feature_detection_dev(self.d_imgs.data_ptr(), self.img_bytes, self.pitch, n_img, self.d_kps.data_ptr(),
                                       self.d_desc.data_ptr(), self.d_cnt.data_ptr())
 
     def stage_stereo_match(self):
         B, cap = self.B, self.cap
         vo = self.vo
+        if self.depth == "sgbm":
+            # VO::disparity_map + Frame::find_3d / gates of set_ref_3d_position on every left keypoint (visual_odometry.cpp:159-217)
+            vo.disparity_map_dev(self.d_imgs.data_ptr(), self.d_imgs.data_ptr() + B * self.img_bytes, self.img_bytes, self.pitch, self.w, self.h, B,
+                                 self.d_disp.data_ptr())
+            vo.find_3d_disparity_dev(self.d_kps.data_ptr(), self.d_cnt.data_ptr(), cap, B, self.d_disp.data_ptr(), self.w, self.h,
+                                     self.d_Tident.data_ptr(), self.d_xyz.data_ptr(), self.d_valid.data_ptr(), self.d_rel.data_ptr())
+            with torch.cuda.stream(self.stream):
+                self.d_nlr.copy_(self.d_cnt[:B])
+            return
         # L/R: query = left descriptors of keyframe b, train = right descriptors of keyframe b
         vo.feature_matching_dev(self.d_desc.data_ptr(), cap * 32, self.d_cnt.data_ptr(), self.d_desc.data_ptr() + B * cap * 32, cap * 32,
                                 self.d_cnt.data_ptr() + 4 * B, self.d_gap.data_ptr(), 1, B, cap, self.d_lr.data_ptr(), cap, self.d_nlr.data_ptr())

@@ -67,3 +67,41 @@ def test_pipeline_matches_oracle_composite(oracle, synth):
             assert (out["ba_inl"][lm_off[b]:lm_off[b + 1]] == inl).mean() > 0.995
     finally:
         pipe.close()
+
+
+def test_pipeline_sgbm_depth_matches_oracle_composite(oracle, synth):
+    """throughput pipeline with the reference's own depth path: batched SGBM + Frame::find_3d on the left keypoints, then the
+    frame-to-frame stage on those landmarks (visual_odometry.cpp:159-217, :253-314)"""
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    B, anms = 3, 500
+    pipe = KeyframePipeline(B, anms_num=anms, unique_scenes=1, seed=4, with_ba=False, depth="sgbm")
+    try:
+        pipe.step()
+        out = pipe.download()
+        w = pipe.w
+        disp = pipe.d_disp.cpu().numpy()
+        prev = None
+        for b in range(B):
+            L = pipe.h_imgs[b][:, :w]; R = pipe.h_imgs[B + b][:, :w]
+            kL, dL = oracle.feature_detection(L, 3000, anms)
+            assert out["cnt"][b] == len(kL) and (out["desc"][b][:len(kL)] == dL).all()
+            wd = oracle.disparity_map(L, R)
+            assert np.array_equal(disp[b], wd)
+            xyz, valid, rel = oracle.find_3d_disparity(kL, wd, IDENT)
+            n = len(kL)
+            assert out["nlr"][b] == n
+            assert (out["valid"][b][:n] == valid).all() and (out["rel"][b][:n] == rel).all()
+            ok = valid.astype(bool)
+            assert np.allclose(out["xyz"][b][:n][ok], xyz[ok], rtol=1e-4, atol=1e-5) and ok.sum() > 50
+            if prev is not None:
+                i = b - 1
+                pk, pd, pxyz, pvalid = prev
+                f = oracle.feature_matching(pd, dL, 1.0)
+                assert out["nf2f"][i] == len(f)
+                okm = pvalid[f["queryIdx"]] != 0
+                assert out["pn"][i] == okm.sum()
+                p3 = pxyz[f["queryIdx"][okm]]; p2 = np.stack([kL["x"][f["trainIdx"][okm]], kL["y"][f["trainIdx"][okm]]], 1)
+                assert np.allclose(out["pxyz"][i][:okm.sum()], p3, rtol=1e-4, atol=1e-5) and np.array_equal(out["puv"][i][:okm.sum()], p2)
+            prev = (kL, dL, xyz, valid)
+    finally:
+        pipe.close()
