@@ -200,6 +200,7 @@ void vslam_destroy(vslam_ctx* ctx) {
     orb_tables_free(&c->tab);
     if (c->d_sgbm) hipFree(c->d_sgbm);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->lm.buf) hipFree(c->lm.buf);
     void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs,
                     c->match.d_train_best, c->match.d_q8, c->match.d_t8, c->d_stage};
     for (void* q : ptrs) if (q) hipFree(q);
@@ -540,7 +541,7 @@ int vslam_pnp_motion_only_dev(vslam_ctx* ctx, const float* d_xyz_w, const float*
     p.xyz = d_xyz_w; p.uv = d_uv; p.n = d_n; p.capacity = capacity; p.B = B; p.T = d_T_c_w; p.iters = iters;
     fill_K(c, p.K); p.huber_delta = c->p.huber_delta; p.reproj_thr = c->p.pnp_reproj_thr;
     p.inlier = d_inlier; p.n_inliers = d_n_inliers; p.stats = nullptr;
-    return launch_pnp(p, c->stream);
+    return launch_pnp(p, &c->lm, c->stream);
 }
 
 int vslam_pnp_motion_only(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int iters, uint8_t* inlier,
@@ -568,7 +569,7 @@ int vslam_pnp_motion_only(vslam_ctx* ctx, const float* xyz_w, const float* uv, i
     p.xyz = d_x; p.uv = d_u; p.n = d_n; p.capacity = n; p.B = 1; p.T = d_T; p.iters = iters;
     fill_K(c, p.K); p.huber_delta = c->p.huber_delta; p.reproj_thr = c->p.pnp_reproj_thr;
     p.inlier = d_in; p.n_inliers = d_n + 1; p.stats = d_st;
-    if ((rc = launch_pnp(p, c->stream))) return rc;
+    if ((rc = launch_pnp(p, &c->lm, c->stream))) return rc;
     int32_t ni = 0;
     VS_HIP(hipMemcpyAsync(T_c_w, d_T, 56, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipMemcpyAsync(&ni, d_n + 1, 4, hipMemcpyDeviceToHost, c->stream));
@@ -643,7 +644,7 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
     memset(&p, 0, sizeof(p));
     p.xyz = d_hx; p.uv = d_hu; p.n = d_hn; p.capacity = mp; p.B = H; p.T = d_hT; p.iters = lm_iters;
     fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err;
-    if ((rc = launch_pnp(p, c->stream))) return rc;
+    if ((rc = launch_pnp(p, &c->lm, c->stream))) return rc;
     if ((rc = launch_pnp_hypothesis_count(d_x, d_u, n, d_hT, H, p.K, reproj_err, d_cnt, c->stream))) return rc;
     std::vector<int32_t> cnt(H);
     VS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
@@ -664,7 +665,7 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
     memset(&p, 0, sizeof(p));
     p.xyz = d_x; p.uv = d_u; p.n = d_n1; p.capacity = n; p.B = 1; p.T = d_hT + 7 * (size_t)best; p.iters = 0;
     fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err; p.inlier = d_mask; p.n_inliers = d_n1 + 1;
-    if ((rc = launch_pnp(p, c->stream))) return rc; // (0 LM iterations: only the inlier test at the hypothesis pose)
+    if ((rc = launch_pnp(p, &c->lm, c->stream))) return rc; // (0 LM iterations: only the inlier test at the hypothesis pose)
     VS_HIP(hipMemcpyAsync(mask.data(), d_mask, n, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
     std::vector<float> ix, iu;
@@ -679,7 +680,7 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
     memset(&p, 0, sizeof(p));
     p.xyz = d_ix; p.uv = d_iu; p.n = d_n1; p.capacity = m; p.B = 1; p.T = d_T; p.iters = lm_iters;
     fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err;
-    if ((rc = launch_pnp(p, c->stream))) return rc;
+    if ((rc = launch_pnp(p, &c->lm, c->stream))) return rc;
     VS_HIP(hipMemcpyAsync(T_c_w, d_T, 56, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
     if (inlier) memcpy(inlier, mask.data(), n);
@@ -736,9 +737,9 @@ static int window_host(vslam_ctx* ctx, int mode, int n_kf, double* T_c_w, int n_
     a.n_windows = 1; a.n_kf = n_kf; a.lm_off = d_off; a.edge_off = d_off + 2; a.T = d_T; a.xyz = d_xyz; a.reliable = nullptr;
     a.lm_inlier = d_inl; a.kf_idx = d_kf; a.lm_idx = d_lm; a.uv = d_uv; a.chi2 = d_chi; a.stats = d_st; a.chi2_thr = d_thr;
     fill_K(c, a.K); a.huber_delta = c->p.huber_delta; a.total_lm = n_lm; a.total_edge = n_edge;
-    if ((rc = launch_lm_windows(a, 0, mode, iters, update_poses, update_lms, c->stream))) return rc;
+    if ((rc = launch_lm_windows(a, 0, mode, iters, update_poses, update_lms, &c->lm, c->stream))) return rc;
     int32_t status = 0;
-    if ((rc = lm_fetch_status(1, &status, c->stream))) return rc;
+    if ((rc = lm_fetch_status(&c->lm, 1, &status, c->stream))) return rc;
     if (status != VSLAM_OK) { set_error("window optimisation rejected the graph (duplicate (keyframe, landmark) edge or bad index)"); return status; }
     std::vector<double> chi(n_edge), chi_sorted(n_edge);
     VS_HIP(hipMemcpy(chi_sorted.data(), d_chi, 8 * (size_t)n_edge, hipMemcpyDeviceToHost));
@@ -788,13 +789,13 @@ int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* b, int schedule, in
     a.reliable = b->d_reliable; a.lm_inlier = b->d_lm_inlier; a.kf_idx = b->d_kf_idx; a.lm_idx = b->d_lm_idx; a.uv = b->d_uv;
     a.chi2 = b->d_chi2; a.stats = b->d_stats; a.chi2_thr = nullptr;
     fill_K(c, a.K); a.huber_delta = c->p.huber_delta; a.total_lm = b->total_lm; a.total_edge = b->total_edge;
-    return launch_lm_windows(a, schedule, mode, iters, update_poses, update_lms, c->stream);
+    return launch_lm_windows(a, schedule, mode, iters, update_poses, update_lms, &c->lm, c->stream);
 }
 
 int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !h_status || n_windows <= 0) return VSLAM_ERR_ARG;
-    return lm_fetch_status(n_windows, h_status, c->stream);
+    return lm_fetch_status(&c->lm, n_windows, h_status, c->stream);
 }
 
 // ---------------------------------------------------------------------------------------------- profiling + glue

@@ -1142,13 +1142,7 @@ int launch_pnp_hypothesis_count(const float* d_xyz, const float* d_uv, int n, co
     return VSLAM_OK;
 }
 
-// scratch owned by the launch wrappers (grown on demand, per process)
-struct LmScratch {
-    void* buf = nullptr; size_t bytes = 0;
-    int32_t* status = nullptr; int status_n = 0;
-};
-static LmScratch g_lm;
-
+// (LmScratch, owned by the context and grown on demand, is declared in vslam_internal.h)
 static int ensure(void** p, size_t* have, size_t need) {
     if (*have >= need) return VSLAM_OK;
     if (*p) hipFree(*p);
@@ -1158,7 +1152,7 @@ static int ensure(void** p, size_t* have, size_t need) {
     return VSLAM_OK;
 }
 
-static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_windows, bool with_lm, hipStream_t stream) {
+static int carve(LmScratch& g_lm, LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_windows, bool with_lm, hipStream_t stream) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t need = 0;
     const size_t o_P = need; need += al(total_lm * 3 * 8);
@@ -1192,7 +1186,8 @@ static int carve(LmKernelArgs& ka, size_t total_lm, size_t total_edge, int n_win
     return VSLAM_OK;
 }
 
-int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms, hipStream_t stream) {
+int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms, LmScratch* scratch,
+                      hipStream_t stream) {
     const size_t total_lm = a.total_lm, total_edge = a.total_edge;
     if (a.n_windows <= 0) return VSLAM_OK;
     if (a.n_kf <= 0 || a.n_kf > kMaxKf) { set_error("n_kf %d out of range (1..%d)", a.n_kf, kMaxKf); return VSLAM_ERR_ARG; }
@@ -1214,7 +1209,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipMemsetAsync(d_cyc, 0, sizeof(long long) * 16 * a.n_windows, stream);
         ka.dbg_cycles = d_cyc;
     }
-    int rc = carve(ka, total_lm, total_edge, a.n_windows, true, stream);
+    int rc = carve(*scratch, ka, total_lm, total_edge, a.n_windows, true, stream);
     if (rc) return rc;
     ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1);
     if (schedule) {
@@ -1239,7 +1234,8 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     return VSLAM_OK;
 }
 
-int lm_fetch_status(int n_windows, int32_t* h_status, hipStream_t stream) {
+int lm_fetch_status(const LmScratch* scratch, int n_windows, int32_t* h_status, hipStream_t stream) {
+    const LmScratch& g_lm = *scratch;
     if (!g_lm.buf || !h_status) return VSLAM_ERR_ARG;
     // the status words of the most recent launch live at a fixed offset that carve() recorded
     VS_HIP(hipMemcpyAsync(h_status, g_lm.status, sizeof(int32_t) * n_windows, hipMemcpyDeviceToHost, stream));
@@ -1247,7 +1243,7 @@ int lm_fetch_status(int n_windows, int32_t* h_status, hipStream_t stream) {
     return VSLAM_OK;
 }
 
-int launch_pnp(const PnpArgs& p, hipStream_t stream) {
+int launch_pnp(const PnpArgs& p, LmScratch* scratch, hipStream_t stream) {
     if (p.B <= 0) return VSLAM_OK;
     LmKernelArgs ka;
     memset(&ka, 0, sizeof(ka));
@@ -1257,7 +1253,7 @@ int launch_pnp(const PnpArgs& p, hipStream_t stream) {
     ka.a.huber_delta = p.huber_delta;
     ka.pnp_n = p.n; ka.capacity = p.capacity;
     const size_t tot = (size_t)p.B * p.capacity;
-    int rc = carve(ka, tot, tot, p.B, false, stream);
+    int rc = carve(*scratch, ka, tot, tot, p.B, false, stream);
     if (rc) return rc;
     ProfScope prof__(stream, "lm_window_kernel<pnp>", 2);
     hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0);

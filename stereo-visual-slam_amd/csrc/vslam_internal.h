@@ -179,17 +179,22 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
                 int16_t* d_disp_i16, int16_t* d_disp_raw, uint8_t** scratch, size_t* scratch_bytes, size_t* dev_bytes, hipStream_t stream);
 size_t sgbm_scratch_bytes(int w, int h, int B);
 
-int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms,
+// device scratch of the LM kernels: owned by the context (two contexts / streams must not share it), grown on demand
+struct LmScratch {
+    void* buf = nullptr; size_t bytes = 0;
+    int32_t* status = nullptr; int status_n = 0;
+};
+int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms, LmScratch* scratch,
                       hipStream_t stream);
 size_t lm_hits_per_edge();
-int lm_fetch_status(int n_windows, int32_t* h_status, hipStream_t stream);
+int lm_fetch_status(const LmScratch* scratch, int n_windows, int32_t* h_status, hipStream_t stream);
 
 struct PnpArgs {
     const float* xyz; const float* uv; const int32_t* n; int capacity; int B;
     double* T; int iters; double K[4]; double huber_delta; double reproj_thr;
     uint8_t* inlier; int32_t* n_inliers; vslam_lm_stats* stats;
 };
-int launch_pnp(const PnpArgs& a, hipStream_t stream);
+int launch_pnp(const PnpArgs& a, LmScratch* scratch, hipStream_t stream);
 int launch_pnp_hypothesis_count(const float* d_xyz, const float* d_uv, int n, const double* d_T, int n_hyp, const double K[4], double reproj_thr,
                                 int32_t* d_counts, hipStream_t stream);
 
@@ -209,6 +214,7 @@ struct Ctx {
     uint8_t* h_pinned; size_t pinned_bytes;
     // SGBM working set (cost volumes; grown on demand by vslam_disparity_map*)
     uint8_t* d_sgbm; size_t sgbm_bytes;
+    LmScratch lm;
 };
 
 } // namespace vslam
