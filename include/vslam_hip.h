@@ -129,7 +129,9 @@ int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stri
 /* Replaces VO::disparity_map (visual_odometry.cpp:159-174): cv::StereoSGBM::create(0, 96, 9, 8*9*9, 32*9*9, 1, 63, 10,
  * 100, 32)->compute(left, right) followed by convertTo(CV_32F, 1/16).  left/right: h x w u8 (row stride in bytes);
  * disparity: h x w f32, tightly packed (invalid pixels = -1.0, like the reference).  Optional outputs (may be NULL):
- * disp_i16 = the CV_16S fixed-point map after median + speckle filtering, disp_raw_i16 = before them. */
+ * disp_i16 = the CV_16S fixed-point map after median + speckle filtering, disp_raw_i16 = before them.
+ * Sizes: 100 < w <= 4096, h > 9 (VSLAM_ERR_ARG otherwise; OpenCV 3.2's own output is undefined for w - 96 <= 4, where its
+ * horizontal box sum reads past the pixel-cost row). */
 int vslam_disparity_map(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                         float* disparity, int16_t* disp_i16, int16_t* disp_raw_i16);
 

@@ -93,6 +93,9 @@ int vo_sgbm_compute(const uint8_t* left, const uint8_t* right, int w, int h, int
     if (D % 16 != 0 || w <= 0 || h <= 0) return -1;
     for (size_t i = 0; i < (size_t)w * h; ++i) disp[i] = (int16_t)INVALID;
     if (width1 <= 0) return 0;
+    /* OpenCV 3.2's horizontal-sum initialisation reads pixel-cost columns 0..SW2 without clamping; with width1 <= SW2 that
+     * is a read past its pixDiff buffer (undefined output).  Such widths are rejected here and by the HIP path. */
+    if (width1 <= SW2) return -2;
     const size_t rowsz = (size_t)width1 * D;
 
     /* hsum ring of 2*SH2+2 rows, C (one row, updated in place), S, Lr (2 rows x 4 directions), minLr */

@@ -445,7 +445,8 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     SgbmDims dm;
     dm.w = w; dm.h = h; dm.D = 96; dm.minX1 = 96; dm.width1 = w - 96; dm.P1 = 8 * 9 * 9; dm.P2 = 32 * 9 * 9; dm.SW2 = 4; dm.SH2 = 4; dm.uniq = 10;
     dm.disp12 = 1; dm.ftzero = 63; dm.pitch = pitch; dm.img_bytes = img_bytes; // visual_odometry.cpp:163-164
-    if (dm.width1 <= 0 || h <= 2 * dm.SH2 + 1 || w > 4096) { set_error("image size unsupported (need 96 < w <= 4096, h > 9)"); return VSLAM_ERR_ARG; }
+    // width1 <= SW2 is undefined in OpenCV 3.2 (unclamped read of pixel-cost columns 0..SW2), so it is an argument error here.
+    if (dm.width1 <= dm.SW2 || h <= 2 * dm.SH2 + 1 || w > 4096) { set_error("image size unsupported (need 100 < w <= 4096, h > 9)"); return VSLAM_ERR_ARG; }
     const size_t vol = (size_t)h * dm.width1 * dm.D, npix = (size_t)w * h;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t need = 0;

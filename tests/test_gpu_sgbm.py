@@ -80,4 +80,6 @@ def test_sgbm_rejects_bad_arguments(vo, pkg):
     with pytest.raises(pkg.VslamError):
         vo.disparity_map(np.zeros((40, 90), np.uint8), np.zeros((40, 90), np.uint8))   # w <= 96 disparities
     with pytest.raises(pkg.VslamError):
+        vo.disparity_map(np.zeros((40, 100), np.uint8), np.zeros((40, 100), np.uint8))  # width1 <= SW2: undefined in OpenCV
+    with pytest.raises(pkg.VslamError):
         vo.disparity_map(np.zeros((8, 200), np.uint8), np.zeros((8, 200), np.uint8))   # h <= block size

@@ -90,3 +90,16 @@ def test_disparity_range_and_subpixel_bounds(oracle, synth):
     v = d16[d16 != -16]
     assert v.min() >= 0 and v.max() <= 95 * 16
     assert (np.abs(d16[4:-4, 100:-4].astype(int) - 37 * 16) <= 1).mean() > 0.99
+
+
+def test_too_narrow_for_the_box_filter_is_rejected(oracle):
+    """width1 = w - 96 <= SW2 = 4: OpenCV 3.2 reads pixel-cost columns 0..SW2 unclamped (stereosgbm.cpp hsumAdd init), i.e.
+    past the row; the oracle and the HIP path both refuse instead of restating undefined output."""
+    import ctypes
+    for w in (97, 100):
+        z = np.zeros((20, w), np.uint8); d = np.zeros((20, w), np.int16)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = oracle.lib().vo_sgbm_compute(p(z), p(z), w, 20, w, 96, 9, 648, 2592, 1, 63, 10, 100, 32, p(d), None)
+        assert rc == -2
+    assert (oracle.sgbm_compute(np.zeros((20, 96), np.uint8), np.zeros((20, 96), np.uint8)) == -16).all()   # width1 = 0: all invalid
+    oracle.sgbm_compute(np.zeros((20, 101), np.uint8), np.zeros((20, 101), np.uint8))                       # smallest legal

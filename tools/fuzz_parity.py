@@ -40,7 +40,7 @@ while time.time() < t_end:
             if len(g) != len(w) or any(not np.array_equal(g[f], w[f]) for f in ("queryIdx", "trainIdx", "distance")):
                 fail("match", nq=nq, nt=nt, seed=seed, gate=gate)
     elif kind == "sgbm":
-        w, h = int(rng.integers(100, 700)), int(rng.integers(10, 200))
+        w, h = int(rng.integers(101, 700)), int(rng.integers(10, 200))
         L = synth.noise_image(seed % 1000, w + 40, h)
         sh = int(rng.integers(0, 40))
         Lc = np.ascontiguousarray(L[:, :w]); R = np.ascontiguousarray(L[:, sh:sh + w]).copy()
