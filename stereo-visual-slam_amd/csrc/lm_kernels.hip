@@ -60,6 +60,7 @@ struct LmShared {
     double S[kMaxNp * kMaxNp];
     double Hpp[kMaxKf * 36], HppT[kMaxKf * 36]; // pose blocks at the current state / at the state of the latest trial
     double bp[kMaxNp], bpT[kMaxNp], bs[kMaxNp], xp[kMaxNp];
+    double rdiag[kMaxNp];                       // 1 / L_ii of the reduced system's Cholesky factor (the solves multiply)
     double Rt[kMaxKf * 12], RtTrial[kMaxKf * 12];
     double T[kMaxKf * 7], TTrial[kMaxKf * 7];
     double red[kLmWaves * 2];
@@ -69,9 +70,10 @@ struct LmShared {
     uint8_t item[kLmWaves * kItemSlots];   // Schur work items (pair << 1 | row half) dealt to waves, 0xFF = none
     uint8_t pk1[kCntStride], pk2[kCntStride];
     int kfp[kMaxKf + 4];                   // kf_ptr (keyframe-major range starts), for the per-edge keyframe lookup
+    int rowp[kMaxKf + 4];                  // first 64-edge row of every keyframe's list (rows never straddle keyframes)
     int flag[8];
 };
-static_assert(kMaxKf * kPoseParts >= kLmWaves, "part[] must hold one slot per wave for single-pose problems");
+static_assert(kMaxKf * kPoseParts >= kMaxKf + kLmWaves - 1, "part[] must hold one slot per (keyframe, wave) segment");
 static_assert(kLmWaves <= 16, "cnt rows");
 static_assert(kMaxPairs <= kLmWaves * kItemSlots, "item[] too small");
 
@@ -153,6 +155,29 @@ __device__ inline double block_max(double v, double* red) {
     return s;
 }
 
+// 1/x and 1/sqrt(x) to ~1 ulp without the IEEE division / sqrt sequences (v_div_scale, v_div_fmas, v_div_fixup and the sqrt
+// rescaling): hardware seed + two Newton steps.  The LM outputs are tolerance-checked (1e-4), not bit-exact; 0, inf and NaN
+// inputs still give non-finite results, which is all the failure checks below rely on.
+__device__ inline double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ inline double rsqrt_nr(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(r * 0.5, fma(-x * r, r, 1.0), r);
+    r = fma(r * 0.5, fma(-x * r, r, 1.0), r);
+    return r;
+}
+
+// A wave-uniform double moved into scalar registers: values read from LDS land in VGPRs even when every lane reads the same
+// address; pinning the loop-invariant rotation of the current keyframe in SGPRs frees 2 VGPRs per value in the hot loops.
+__device__ inline double uniform_f64(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 __device__ inline void expand_pose(const double* T, double* Rt) {
     se3::rotmat(T, Rt);
     Rt[9] = T[4]; Rt[10] = T[5]; Rt[11] = T[6];
@@ -161,7 +186,7 @@ __device__ inline void expand_pose(const double* T, double* Rt) {
 __device__ inline void huber(double e, double delta, double& rho, double& w) {
     const double dsqr = delta * delta;
     if (e <= dsqr) { rho = e; w = 1.0; }
-    else { const double s = sqrt(e); rho = 2 * s * delta - dsqr; w = delta / s; }
+    else { const double r = rsqrt_nr(e), s = e * r; rho = 2 * s * delta - dsqr; w = delta * r; }
 }
 
 // 2x6 pose Jacobian of the reprojection error from (X, Y, 1/Z).  EdgeProjection uses 1/(Z+1e-18) (optimization.cpp:66),
@@ -172,22 +197,46 @@ __device__ inline void jac_pose(const double* K, double X, double Y, double Zi, 
     A[0] = -fx * Zi; A[1] = 0; A[2] = fx * X * Zi2; A[3] = fx * X * Y * Zi2; A[4] = -fx - fx * X * X * Zi2; A[5] = fx * Y * Zi;
     A[6] = 0; A[7] = -fy * Zi; A[8] = fy * Y * Zi2; A[9] = fy + fy * Y * Y * Zi2; A[10] = -fy * X * Y * Zi2; A[11] = -fy * X * Zi;
 }
+// The pose Jacobian has two structural zeros, A[1] = A[6] = 0.  Without fast-math the compiler must keep 0 * x (NaN / signed-zero
+// semantics), so the hot loops spell the sparsity out: the helpers below are called with loop indices that are constants after
+// unrolling, and the branches fold away.  (Dropping an exact 0 * finite term does not change any sum.)
+// A[i] * x + A[6 + i] * y
+__device__ inline double a_dot2(const double* A, int i, double x, double y) {
+    if (i == 0) return A[0] * x;
+    if (i == 1) return A[7] * y;
+    return A[i] * x + A[6 + i] * y;
+}
+// acc + A[i] * x + A[6 + i] * y
+__device__ inline double a_fma2(const double* A, int i, double x, double y, double acc) {
+    if (i == 0) return fma(A[0], x, acc);
+    if (i == 1) return fma(A[7], y, acc);
+    return fma(x, A[i], fma(y, A[6 + i], acc));
+}
+// acc + U[r] * V[c] + U[6 + r] * V[6 + c] for two arrays with the pose Jacobian's zero pattern
+__device__ inline double a_fma_pair(const double* U, int r, const double* V, int c, double acc) {
+    if (r != 0 && c != 0) acc = fma(U[6 + r], V[6 + c], acc);
+    if (r != 1 && c != 1) acc = fma(U[r], V[c], acc);
+    return acc;
+}
 // 2x3 landmark Jacobian = A[:, 0:3] * R
 __device__ inline void jac_point(const double A[12], const double* R, double B[6]) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) B[r * 3 + c] = A[r * 6] * R[c] + A[r * 6 + 1] * R[3 + c] + A[r * 6 + 2] * R[6 + c];
+    for (int c = 0; c < 3; ++c) {
+        B[c] = A[0] * R[c] + A[2] * R[6 + c];
+        B[3 + c] = A[7] * R[3 + c] + A[8] * R[6 + c];
+    }
 }
 
+template <bool FAST = false>
 __device__ inline void project_err(const double* Rt, const double* K, double px, double py, double pz, float u, float v, double& X,
-                                   double& Y, double& Z, double& ex, double& ey) {
+                                   double& Y, double& Z, double& ex, double& ey, double* rz_out = nullptr) {
     X = Rt[0] * px + Rt[1] * py + Rt[2] * pz + Rt[9];
     Y = Rt[3] * px + Rt[4] * py + Rt[5] * pz + Rt[10];
     Z = Rt[6] * px + Rt[7] * py + Rt[8] * pz + Rt[11];
-    const double rz = 1.0 / Z; // one reciprocal instead of two divisions (K*(T*p) / z, optimization.cpp:46-49); tolerance-checked
+    const double rz = FAST ? rcp_nr(Z) : 1.0 / Z; // one reciprocal instead of two divisions (K*(T*p) / z, optimization.cpp:46-49); tolerance-checked
     ex = (double)u - (K[0] * X * rz + K[2]);
     ey = (double)v - (K[1] * Y * rz + K[3]);
+    if (rz_out) *rz_out = rz;
 }
 
 // linearisation record of one observation at (pose Rt, point p): camera-frame X, Y, the reciprocal depth the Jacobians use,
@@ -195,18 +244,20 @@ __device__ inline void project_err(const double* Rt, const double* K, double px,
 // phases) and by the landmark-wise phases, which recompute it from the landmark position instead of gathering it.
 __device__ inline void lin_record(const double* Rt, const double* K, double px, double py, double pz, float2 z, double delta, bool with_lm,
                                   double& X, double& Y, double& Zi, double& wgt, double& ex, double& ey, double& chi, double& rho) {
-    double Z;
-    project_err(Rt, K, px, py, pz, z.x, z.y, X, Y, Z, ex, ey);
+    double Z, rz;
+    project_err<true>(Rt, K, px, py, pz, z.x, z.y, X, Y, Z, ex, ey, &rz);
     chi = ex * ex + ey * ey;
     huber(chi, delta, rho, wgt);
-    Zi = with_lm ? 1.0 / (Z + 1e-18) : 1.0 / Z; // optimization.cpp:66 vs :96-100
+    // optimization.cpp:66 uses 1/(Z + 1e-18), :96-100 1/Z.  Z + 1e-18 rounds to Z for every Z > 0.01: same reciprocal.
+    Zi = rz;
+    if (with_lm) { const double Zc = Z + 1e-18; if (Zc != Z) Zi = rcp_nr(Zc); }
 }
 
 __device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double Di[6]) {
     // symmetric [[a b c],[b d e],[c e f]] -> unique entries of the inverse (00 01 02 11 12 22)
     const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
     const double det = a * c00 + b * c01 + c * c02;
-    const double id = 1.0 / det;
+    const double id = rcp_nr(det);
     Di[0] = c00 * id; Di[1] = c01 * id; Di[2] = c02 * id;
     Di[3] = (a * f - c * c) * id; Di[4] = (b * c - a * e) * id; Di[5] = (a * d - b * b) * id;
     return isfinite(id);
@@ -220,21 +271,22 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
 #pragma unroll
     for (int i = 0; i < 6; ++i) L[7 * i] += lambda;
     bool ok = true;
+    double rd[6]; // reciprocal diagonal of L
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = L[j * 6 + j];
 #pragma unroll
         for (int k = 0; k < 6; ++k) if (k < j) d -= L[j * 6 + k] * L[j * 6 + k];
         if (!(d > 0.0) || !isfinite(d)) ok = false;
-        d = sqrt(d);
-        L[j * 6 + j] = d;
+        rd[j] = rsqrt_nr(d);
+        L[j * 6 + j] = d * rd[j];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             if (i > j) {
                 double s = L[i * 6 + j];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) if (k < j) s -= L[i * 6 + k] * L[j * 6 + k];
-                L[i * 6 + j] = s / d;
+                L[i * 6 + j] = s * rd[j];
             }
     }
     double y[6];
@@ -243,14 +295,14 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < 6; ++k) if (k < i) s -= L[i * 6 + k] * y[k];
-        y[i] = s / L[i * 6 + i];
+        y[i] = s * rd[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
 #pragma unroll
         for (int k = 0; k < 6; ++k) if (k > i) s -= L[k * 6 + i] * x[k];
-        x[i] = s / L[i * 6 + i];
+        x[i] = s * rd[i];
     }
     return ok;
 }
@@ -260,7 +312,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                                             int classify) {
     const LmWindowArgs& a = ka.a;
     __shared__ LmShared sm;
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // tell the compiler it is wave-uniform: wave-indexed control flow goes scalar
     const int nk = a.n_kf, np = 6 * nk;
     int lm0, nl, e0, ne;
     if (IMPL) { nl = min(max(ka.pnp_n[w], 0), ka.capacity); lm0 = w * ka.capacity; e0 = lm0; ne = nl; }
@@ -301,7 +354,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const double delta = a.huber_delta;
     const bool with_lm = (mode == 0);
     const int npairs = nk * (nk + 1) / 2;
-    const int nparts = nk == 1 ? kLmWaves : kPoseParts; // a pose's edge list is split over `nparts` waves
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int slot27 = wave_slot<27>(lane), slot36 = wave_slot<36>(lane); // which butterfly sum this lane ends up holding
     long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + 16 * (size_t)w : nullptr;
@@ -497,6 +549,13 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             }
         }
     }
+    if (IMPL && tid == 0) { sm.kfp[0] = 0; sm.kfp[1] = ne; }
+    __syncthreads();
+    if (tid == 0) { // the evaluation pass walks the keyframe-major lists in rows of 64 edges
+        int r = 0;
+        for (int kk = 0; kk < nk; ++kk) { sm.rowp[kk] = r; r += (sm.kfp[kk + 1] - sm.kfp[kk] + 63) >> 6; }
+        sm.rowp[nk] = r;
+    }
     __syncthreads();
 
     PH(0);
@@ -513,58 +572,112 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const float2* uv2 = reinterpret_cast<const float2*>(uv);
     constexpr int kEvalU = 4;
     constexpr int kLmU = 2, kLmE = 4; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
-    // Evaluation + linearisation at (Rt, Pcur) in one keyframe-major pass.  item = (pose, part): a wave streams its share of
-    // the pose's edge list (landmark ids and observations two steps ahead, landmark positions one step ahead), writes the
-    // records {X, Y, 1/Z, w} for the Schur phase and accumulates the pose blocks (H_pp upper triangle, b_p) on the fly, so the
-    // errors never have to be stored.  Returns the robust chi2.  Trial states go through the same pass into the spare
-    // buffers: an accepted trial is already linearised.
-    const int ntot = IMPL ? ne : sm.kfp[nk]; // active edges
+    // Evaluation + linearisation at (Rt, Pcur) in one keyframe-major pass.  The keyframe-major edge lists are cut into rows
+    // of 64 edges (a row never straddles two keyframes); every wave owns a contiguous range of rows and streams it through
+    // a register queue (landmark ids and observations four rows ahead, landmark positions two rows ahead: the lists come from
+    // HBM / Infinity Cache at ~1 us per dependent access, a row is ~0.5 us of arithmetic).  It writes the records
+    // {X, Y, 1/Z, w} for the Schur phase and accumulates the pose blocks (H_pp upper triangle, b_p) on the fly, so the errors
+    // never have to be stored; when the keyframe changes the 27 sums are folded (butterfly) into slot (keyframe + wave) --
+    // unique, because the waves' row ranges are ordered like the keyframes.  Returns the robust chi2.  Trial states go
+    // through the same pass into the spare buffers: an accepted trial is already linearised.
+    const int ntot = sm.kfp[nk]; // active edges
     auto LMJ = [&](int j) -> int { return IMPL ? j : kf_lm[j]; };
+    struct RowIt { int k, j, jend; };
+    auto row_next = [&](RowIt& r) {
+        r.j += 64;
+        while (r.j >= r.jend && r.k + 1 < nk) { ++r.k; r.j = sm.kfp[r.k]; r.jend = sm.kfp[r.k + 1]; }
+    };
+    const int nrows = sm.rowp[nk], rows_per_wave = (nrows + kLmWaves - 1) / kLmWaves;
     auto eval = [&](const double* Rt, const double* Pcur, double4* dstA, double* Hdst, double* bdst) -> double {
         double part = 0;
-        for (int item = wave; item < nk * nparts; item += kLmWaves) {
-            const int k = item / nparts, pt = item - k * nparts;
+        const long long t_ev = cyc ? clock64() : 0;
+        const int ra = min(wave * rows_per_wave, nrows), rb = min(ra + rows_per_wave, nrows);
+        if (ra < rb) {
+            RowIt cur;
+            {
+                int k = 0;
+                while (k + 1 < nk && sm.rowp[k + 1] <= ra) ++k;
+                cur.k = k; cur.j = sm.kfp[k] + 64 * (ra - sm.rowp[k]); cur.jend = sm.kfp[k + 1];
+            }
+            RowIt ahead = cur;
+            int lq[4];
+            float2 zq[4];
+            double pq[2][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = min(ahead.j + lane, ahead.jend - 1);
+                lq[q] = LMJ(jj); zq[q] = uvk2[jj];
+                row_next(ahead);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pq[q][c] = PC(Pcur, c, lq[q]);
             double acc[27];
 #pragma unroll
             for (int i = 0; i < 27; ++i) acc[i] = 0;
-            const int b0 = IMPL ? 0 : sm.kfp[k], b1 = IMPL ? ne : sm.kfp[k + 1];
-            const int s0 = b0 + (int)((long long)(b1 - b0) * pt / nparts), s1 = b0 + (int)((long long)(b1 - b0) * (pt + 1) / nparts);
-            if (s0 < s1) {
-                const double* R = &Rt[12 * k];
-                const int jl = s1 - 1;
-                int j = s0 + lane;
-                int l1 = LMJ(min(j, jl)), l2 = LMJ(min(j + 64, jl));
-                float2 z1 = uvk2[min(j, jl)], z2 = uvk2[min(j + 64, jl)];
-                double px = PC(Pcur, 0, l1), py = PC(Pcur, 1, l1), pz = PC(Pcur, 2, l1);
-                for (; j < s1; j += 64) {
-                    const int l3 = LMJ(min(j + 128, jl));
-                    const float2 z3 = uvk2[min(j + 128, jl)];
-                    const double pxn = PC(Pcur, 0, l2), pyn = PC(Pcur, 1, l2), pzn = PC(Pcur, 2, l2);
-                    double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
-                    lin_record(R, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
-                    part += rho;
-                    if (with_lm) dstA[j] = make_double4(X, Y, Zi, wgt); // only the Schur passes read the records back
-                    jac_pose(K, X, Y, Zi, A);
+            int kacc = cur.k;
+            double Rk[12]; // pose of the current keyframe, wave-uniform
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
-                    int idx = 0;
+            for (int i = 0; i < 12; ++i) Rk[i] = uniform_f64(Rt[12 * kacc + i]);
+            auto flush = [&](int k) {
+                wave_reduce_scatter<27>(acc, lane);
+                if (slot27 >= 0) sm.part[(k + wave) * 27 + slot27] = acc[0];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
+                for (int i = 0; i < 27; ++i) acc[i] = 0;
+            };
+            for (int row = ra; row < rb; row += 4) {
 #pragma unroll
-                        for (int cc = r; cc < 6; ++cc) { acc[idx] = fma(wA[r], A[cc], fma(wA[6 + r], A[6 + cc], acc[idx])); ++idx; }
+                for (int q = 0; q < 4; ++q) {
+                    if (row + q >= rb) break; // uniform
+                    if (cur.k != kacc) {
+                        flush(kacc);
+                        kacc = cur.k;
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) acc[21 + r] = fma(-wA[r], ex, fma(-wA[6 + r], ey, acc[21 + r]));
-                    px = pxn; py = pyn; pz = pzn; l2 = l3; z1 = z2; z2 = z3;
+                        for (int i = 0; i < 12; ++i) Rk[i] = uniform_f64(Rt[12 * kacc + i]);
+                    }
+                    const float2 z1 = zq[q];
+                    const double px = pq[q & 1][0], py = pq[q & 1][1], pz = pq[q & 1][2];
+                    { // refill the queues: ids of row + 4, positions of row + 2
+                        const int jj = min(ahead.j + lane, ahead.jend - 1);
+                        lq[q] = LMJ(jj); zq[q] = uvk2[jj];
+                        row_next(ahead);
+                        const int l2 = lq[(q + 2) & 3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) pq[q & 1][c] = PC(Pcur, c, l2);
+                    }
+                    const int j = cur.j + lane;
+                    if (j < cur.jend) {
+                        double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
+                        lin_record(Rk, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
+                        part += rho;
+                        if (with_lm && !(ka.dbg_skip & 128)) dstA[j] = make_double4(X, Y, Zi, wgt); // only the Schur passes read the records back
+                        jac_pose(K, X, Y, Zi, A);
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
+                        int idx = 0;
+#pragma unroll
+                        for (int r = 0; r < 6; ++r)
+#pragma unroll
+                            for (int cc = r; cc < 6; ++cc) { acc[idx] = a_fma_pair(wA, r, A, cc, acc[idx]); ++idx; }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) acc[21 + r] = a_fma2(wA, r, -ex, -ey, acc[21 + r]);
+                    }
+                    row_next(cur);
                 }
             }
-            wave_reduce_scatter<27>(acc, lane);
-            if (slot27 >= 0) sm.part[item * 27 + slot27] = acc[0];
+            flush(kacc);
         }
+        if (cyc && tid == 0) cyc[15] += clock64() - t_ev;
         const double total = block_sum(part, sm.red); // (its barriers also publish sm.part)
-        for (int t = tid; t < nk * 27; t += kLmBlock) { // parts summed in a fixed order
+        for (int t = tid; t < nk * 27; t += kLmBlock) { // the segments of a keyframe summed in wave order
             const int k = t / 27, i = t - k * 27;
+            const int r0 = sm.rowp[k], r1 = sm.rowp[k + 1];
             double v = 0;
-            for (int pp = 0; pp < nparts; ++pp) v += sm.part[(k * nparts + pp) * 27 + i];
+            for (int ww = 0; ww < kLmWaves; ++ww) {
+                const int wa = min(ww * rows_per_wave, nrows), wb = min(wa + rows_per_wave, nrows);
+                if (max(wa, r0) < min(wb, r1)) v += sm.part[(k + ww) * 27 + i];
+            }
             if (i < 21) {
                 int r = 0, rem = i;
                 while (rem >= 6 - r) { rem -= 6 - r; ++r; }
@@ -693,6 +806,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     const int p = sm.item[wave * kItemSlots + slot];
                     if (p == 0xFF) continue; // uniform per wave
                     const int k1 = sm.pk1[p], k2 = sm.pk2[p];
+                    double R1[9], R2[9]; // rotations of the pair, wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { R1[i] = uniform_f64(sm.Rt[12 * k1 + i]); R2[i] = uniform_f64(sm.Rt[12 * k2 + i]); }
                     double acc[36];
 #pragma unroll
                     for (int i = 0; i < 36; ++i) acc[i] = 0;
@@ -716,7 +832,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             const double g0n = PC(bl, 0, lnn), g1n = PC(bl, 1, lnn), g2n = PC(bl, 2, lnn);
                             double A1[12], B1[6];
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
-                            jac_point(A1, &sm.Rt[12 * k1], B1);
+                            jac_point(A1, R1, B1);
                             double BD[6];
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
@@ -727,7 +843,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             {
                                 const double m0 = ra.w * (BD[0] * g0 + BD[1] * g1 + BD[2] * g2), m1 = ra.w * (BD[3] * g0 + BD[4] * g1 + BD[5] * g2);
 #pragma unroll
-                                for (int r = 0; r < 6; ++r) accb[r] += A1[r] * m0 + A1[6 + r] * m1;
+                                for (int r = 0; r < 6; ++r) accb[r] = a_fma2(A1, r, m0, m1, accb[r]);
                             }
                             const double ww = ra.w * ra.w;
                             const double M00 = ww * (BD[0] * B1[0] + BD[1] * B1[1] + BD[2] * B1[2]);
@@ -735,9 +851,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             const double M11 = ww * (BD[3] * B1[3] + BD[4] * B1[4] + BD[5] * B1[5]);
 #pragma unroll
                             for (int r = 0; r < 6; ++r) {
-                                const double m0 = A1[r] * M00 + A1[6 + r] * M01, m1 = A1[r] * M01 + A1[6 + r] * M11;
+                                const double m0 = a_dot2(A1, r, M00, M01), m1 = a_dot2(A1, r, M01, M11);
 #pragma unroll
-                                for (int c = r; c < 6; ++c) acc[6 * r + c] = fma(m0, A1[c], fma(m1, A1[6 + c], acc[6 * r + c]));
+                                for (int c = r; c < 6; ++c) acc[6 * r + c] = a_fma2(A1, c, m0, m1, acc[6 * r + c]);
                             }
                             ra = ran; Da = Dan; Db = Dbn; Dc = Dcn; lnn = lnnn; g0 = g0n; g1 = g1n; g2 = g2n;
                         }
@@ -780,9 +896,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             loadD(hn.y, Dan, Dbn, Dcn);
                             double A1[12], A2[12], B1[6], B2[6];
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
-                            jac_point(A1, &sm.Rt[12 * k1], B1);
+                            jac_point(A1, R1, B1);
                             jac_pose(K, rb.x, rb.y, rb.z, A2);
-                            jac_point(A2, &sm.Rt[12 * k2], B2);
+                            jac_point(A2, R2, B2);
                             double BD[6];
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
@@ -798,9 +914,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 for (int c = 0; c < 2; ++c) M[2 * r + c] = ww * (BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]);
 #pragma unroll
                             for (int r = 0; r < 6; ++r) {
-                                const double m0 = A1[r] * M[0] + A1[6 + r] * M[2], m1 = A1[r] * M[1] + A1[6 + r] * M[3];
+                                const double m0 = a_dot2(A1, r, M[0], M[2]), m1 = a_dot2(A1, r, M[1], M[3]);
 #pragma unroll
-                                for (int c = 0; c < 6; ++c) acc[6 * r + c] = fma(m0, A2[c], fma(m1, A2[6 + c], acc[6 * r + c]));
+                                for (int c = 0; c < 6; ++c) acc[6 * r + c] = a_fma2(A2, c, m0, m1, acc[6 * r + c]);
                             }
                             ra = ran; rb = rbn; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
                         }
@@ -843,9 +959,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                             for (int kk = 0; kk < j; ++kk) d -= D[j * (j + 1) / 2 + kk] * D[j * (j + 1) / 2 + kk];
                             if (!(d > 0.0) || !isfinite(d)) good = false;
-                            d = sqrt(d);
-                            D[j * (j + 1) / 2 + j] = d;
-                            rd[j] = 1.0 / d; // one division per column; everything below multiplies
+                            rd[j] = rsqrt_nr(d); // the dependent chain of the factorisation: no IEEE sqrt / division on it
+                            D[j * (j + 1) / 2 + j] = d * rd[j];
 #pragma unroll
                             for (int i = j + 1; i < 6; ++i) {
                                 double v = D[i * (i + 1) / 2 + j];
@@ -873,6 +988,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         if (tid == 0) {
 #pragma unroll
                             for (int i = 0; i < 21; ++i) sm.xp[i] = D[i]; // parked in xp (free until the solves)
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) sm.rdiag[6 * J + i] = rd[i];
                         }
                     }
                     __syncthreads();
@@ -901,7 +1018,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             for (int c = 0; c < 6; ++c) {
 #pragma unroll
                                 for (int kk = 0; kk < c; ++kk) y[c] -= sm.S[(6 * J + c) * np + 6 * J + kk] * y[kk];
-                                y[c] /= sm.S[(6 * J + c) * np + 6 * J + c];
+                                y[c] *= sm.rdiag[6 * J + c];
                             }
                             __builtin_amdgcn_wave_barrier(); // every lane has read xp[6J..] before it is overwritten
                             if (lane < 6) sm.xp[6 * J + lane] = lane == 0 ? y[0] : lane == 1 ? y[1] : lane == 2 ? y[2] : lane == 3 ? y[3] : lane == 4 ? y[4] : y[5];
@@ -921,7 +1038,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             for (int c = 5; c >= 0; --c) {
 #pragma unroll
                                 for (int kk = c + 1; kk < 6; ++kk) x[c] -= sm.S[(6 * J + kk) * np + 6 * J + c] * x[kk];
-                                x[c] /= sm.S[(6 * J + c) * np + 6 * J + c];
+                                x[c] *= sm.rdiag[6 * J + c];
                             }
                             __builtin_amdgcn_wave_barrier();
                             if (lane < 6) sm.xp[6 * J + lane] = lane == 0 ? x[0] : lane == 1 ? x[1] : lane == 2 ? x[2] : lane == 3 ? x[3] : lane == 4 ? x[4] : x[5];
@@ -992,7 +1109,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             // W^T xp = w B^T (A xp_k)
                             double a0 = 0, a1 = 0;
 #pragma unroll
-                            for (int r = 0; r < 6; ++r) { a0 += A[r] * sm.xp[6 * k + r]; a1 += A[6 + r] * sm.xp[6 * k + r]; }
+                            for (int r = 0; r < 6; ++r) { // A[1] = A[6] = 0
+                                const double xr = sm.xp[6 * k + r];
+                                if (r != 1) a0 = fma(A[r], xr, a0);
+                                if (r != 0) a1 = fma(A[6 + r], xr, a1);
+                            }
                             a0 *= wg; a1 *= wg;
                             c0 -= B[0] * a0 + B[3] * a1; c1 -= B[1] * a0 + B[4] * a1; c2 -= B[2] * a0 + B[5] * a1;
                         };
@@ -1226,10 +1347,10 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipStreamSynchronize(stream);
         std::vector<long long> h(16 * (size_t)a.n_windows);
         hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        static const char* names[15] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)"};
+        static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(eval: row loop, wave 0)"};
         double tot = 0;
-        for (int i = 0; i < 15; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
-        fprintf(stderr, "  [lm profile] total %.0f ticks (clock64 = 100 MHz s_memtime units)\n", tot);
+        for (int i = 0; i < 16; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
+        fprintf(stderr, "  [lm profile] total %.0f ticks (clock64 = 100 MHz s_memtime units; really shader-clock cycles)\n", tot);
     }
     return VSLAM_OK;
 }
