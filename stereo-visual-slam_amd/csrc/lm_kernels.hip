@@ -56,7 +56,7 @@ constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work 
 
 size_t lm_hits_per_edge() { return kHitsPerEdge; }
 
-struct LmShared {
+struct alignas(16) LmShared {
     double S[kMaxNp * kMaxNp];
     double Hpp[kMaxKf * 36], HppT[kMaxKf * 36]; // pose blocks at the current state / at the state of the latest trial
     double bp[kMaxNp], bpT[kMaxNp], bs[kMaxNp], xp[kMaxNp];
@@ -75,6 +75,7 @@ struct LmShared {
 };
 static_assert(kMaxKf * kPoseParts >= kMaxKf + kLmWaves - 1, "part[] must hold one slot per (keyframe, wave) segment");
 static_assert(kLmWaves <= 16, "cnt rows");
+static_assert(kMaxNp <= 128, "the backward substitution keeps two unknowns per lane of a wave");
 static_assert(kMaxPairs <= kLmWaves * kItemSlots, "item[] too small");
 
 struct LmKernelArgs {
@@ -175,6 +176,11 @@ __device__ inline double rsqrt_nr(double x) {
 // address; pinning the loop-invariant rotation of the current keyframe in SGPRs frees 2 VGPRs per value in the hot loops.
 __device__ inline double uniform_f64(double v) {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double readlane_f64(double v, int l) { // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
 
@@ -561,7 +567,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     PH(0);
     // ------------------------------------------------------------------ LM iterations
     double lambda = 0, ni = 2, currentChi = 0;
-    bool have_lin = false;
     int it = 0, total_trials = 0;
     vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
 
@@ -626,49 +631,48 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                 for (int i = 0; i < 27; ++i) acc[i] = 0;
             };
-            for (int row = ra; row < rb; row += 4) {
+            // (not unrolled: one copy of the row body and of the butterfly keeps the loop inside the instruction cache; the
+            // queues are rotated with register moves instead of static indices)
+#pragma unroll 1
+            for (int row = ra;; ++row) {
+                const bool done = row >= rb;
+                if (done || cur.k != kacc) {
+                    flush(kacc);
+                    if (done) break;
+                    kacc = cur.k;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (row + q >= rb) break; // uniform
-                    if (cur.k != kacc) {
-                        flush(kacc);
-                        kacc = cur.k;
-#pragma unroll
-                        for (int i = 0; i < 12; ++i) Rk[i] = uniform_f64(Rt[12 * kacc + i]);
-                    }
-                    const float2 z1 = zq[q];
-                    const double px = pq[q & 1][0], py = pq[q & 1][1], pz = pq[q & 1][2];
-                    { // refill the queues: ids of row + 4, positions of row + 2
-                        const int jj = min(ahead.j + lane, ahead.jend - 1);
-                        lq[q] = LMJ(jj); zq[q] = uvk2[jj];
-                        row_next(ahead);
-                        const int l2 = lq[(q + 2) & 3];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) pq[q & 1][c] = PC(Pcur, c, l2);
-                    }
-                    const int j = cur.j + lane;
-                    if (j < cur.jend) {
-                        double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
-                        lin_record(Rk, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
-                        part += rho;
-                        if (with_lm && !(ka.dbg_skip & 128)) dstA[j] = make_double4(X, Y, Zi, wgt); // only the Schur passes read the records back
-                        jac_pose(K, X, Y, Zi, A);
-#pragma unroll
-                        for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
-                        int idx = 0;
-#pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int cc = r; cc < 6; ++cc) { acc[idx] = a_fma_pair(wA, r, A, cc, acc[idx]); ++idx; }
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) acc[21 + r] = a_fma2(wA, r, -ex, -ey, acc[21 + r]);
-                    }
-                    row_next(cur);
+                    for (int i = 0; i < 12; ++i) Rk[i] = uniform_f64(Rt[12 * kacc + i]);
                 }
+                const float2 z1 = zq[0];
+                const double px = pq[0][0], py = pq[0][1], pz = pq[0][2];
+                { // rotate the queues and refill their tails: ids of row + 4, positions of row + 2
+                    const int jj = min(ahead.j + lane, ahead.jend - 1);
+                    lq[0] = lq[1]; lq[1] = lq[2]; lq[2] = lq[3]; lq[3] = LMJ(jj);
+                    zq[0] = zq[1]; zq[1] = zq[2]; zq[2] = zq[3]; zq[3] = uvk2[jj];
+                    row_next(ahead);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { pq[0][c] = pq[1][c]; pq[1][c] = PC(Pcur, c, lq[1]); }
+                }
+                const int j = cur.j + lane;
+                if (j < cur.jend) {
+                    double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
+                    lin_record(Rk, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
+                    part += rho;
+                    if (with_lm) dstA[j] = make_double4(X, Y, Zi, wgt); // only the Schur passes read the records back
+                    jac_pose(K, X, Y, Zi, A);
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
+                    int idx = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int cc = r; cc < 6; ++cc) { acc[idx] = a_fma_pair(wA, r, A, cc, acc[idx]); ++idx; }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc[21 + r] = a_fma2(wA, r, -ex, -ey, acc[21 + r]);
+                }
+                row_next(cur);
             }
-            flush(kacc);
         }
-        if (cyc && tid == 0) cyc[15] += clock64() - t_ev;
         const double total = block_sum(part, sm.red); // (its barriers also publish sm.part)
         for (int t = tid; t < nk * 27; t += kLmBlock) { // the segments of a keyframe summed in wave order
             const int k = t / 27, i = t - k * 27;
@@ -718,14 +722,17 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     };
     bool last_trial_is_current = true; // g2o leaves the edge errors of the LAST EVALUATED trial behind (accepted or not)
 
-    for (it = 0; it < iters; ++it) {
-        if (!have_lin) currentChi = eval(sm.Rt, P, recA, sm.Hpp, sm.bp); // (an accepted trial already evaluated and linearised this state)
-        have_lin = false;
+    // The evaluation pass is the largest piece of code in the loop and the loop body has to stay inside the 64 KB instruction
+    // cache two CUs share, so there is ONE call site: the initial state is evaluated by a pseudo-iteration (it = -1, "boot")
+    // that skips the solve and runs the trial evaluation on the current buffers.  Every later iteration starts from an
+    // accepted trial, which is already evaluated and linearised.
+    for (it = iters > 0 ? -1 : 0; it < iters; ++it) {
+        const bool boot = it < 0;
         PH(1);
         if (it == 0 && st && tid == 0) st->chi2_init = currentChi;
         // ---- buildSystem: landmark blocks
         double maxdiag = 0;
-        if (with_lm) {
+        if (with_lm && !boot) {
             for (int l0 = tid; l0 < nl; l0 += kLmU * kLmBlock) {
                 int b0[kLmU], b1[kLmU];
                 double px[kLmU], py[kLmU], pz[kLmU];
@@ -785,6 +792,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         bool again = true;
         while (again) {
             bool ok2 = true;
+            double scale = 1.0;
+            if (!boot) {
             if (with_lm) {
                 // Dinv = (Hll + lambda I)^-1 per landmark (the first trial of iterations > 0 got it from the landmark-block pass)
                 if (it == 0 || qmax > 0) {
@@ -935,17 +944,43 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int J = 0; J < nk && ok2; ++J) {
                     // (1) block column J -= L[.,0..J) L[J,0..J)^T   -- one lane per element of the (nk-J) x 1 block column
                     const int nel = (nk - J) * 36;
+                    const long long t_c1 = cyc ? clock64() : 0;
                     for (int t = tid; t < nel; t += kLmBlock) {
                         const int I = J + t / 36, r = (t % 36) / 6, c = t % 6;
                         double v = sm.S[(6 * I + r) * np + 6 * J + c];
-                        for (int kk = 0; kk < 6 * J; ++kk) v -= sm.S[(6 * I + r) * np + kk] * sm.S[(6 * J + c) * np + kk];
+                        // six products per step, operands fetched as 16-B pairs before the first FMA (the compiler does not
+                        // pipeline the scalar loop: one LDS round trip per product otherwise)
+                        const double2* ra2 = reinterpret_cast<const double2*>(&sm.S[(6 * I + r) * np]);
+                        const double2* rb2 = reinterpret_cast<const double2*>(&sm.S[(6 * J + c) * np]);
+                        for (int K = 0; K < J; ++K) {
+                            const double2 a0 = ra2[3 * K], a1 = ra2[3 * K + 1], a2 = ra2[3 * K + 2];
+                            const double2 b0 = rb2[3 * K], b1 = rb2[3 * K + 1], b2 = rb2[3 * K + 2];
+                            v -= a0.x * b0.x; v -= a0.y * b0.y; v -= a1.x * b1.x; v -= a1.y * b1.y; v -= a2.x * b2.x; v -= a2.y * b2.y;
+                        }
                         sm.S[(6 * I + r) * np + 6 * J + c] = v;
                     }
+                    // the right-hand side rides along as one more row of the matrix: L y = bs is solved by the factorisation
+                    // itself (in place in bs), so only the backward substitution is left afterwards
+                    if (tid >= kLmBlock - 6) {
+                        const int c = tid - (kLmBlock - 6);
+                        double v = sm.bs[6 * J + c];
+                        const double2* ra2 = reinterpret_cast<const double2*>(&sm.bs[0]);
+                        const double2* rb2 = reinterpret_cast<const double2*>(&sm.S[(6 * J + c) * np]);
+                        for (int K = 0; K < J; ++K) {
+                            const double2 a0 = ra2[3 * K], a1 = ra2[3 * K + 1], a2 = ra2[3 * K + 2];
+                            const double2 b0 = rb2[3 * K], b1 = rb2[3 * K + 1], b2 = rb2[3 * K + 2];
+                            v -= a0.x * b0.x; v -= a0.y * b0.y; v -= a1.x * b1.x; v -= a1.y * b1.y; v -= a2.x * b2.x; v -= a2.y * b2.y;
+                        }
+                        sm.bs[6 * J + c] = v;
+                    }
+                    if (cyc && tid == 0) cyc[15] += clock64() - t_c1;
                     __syncthreads();
-                    // (2) every lane that owns a row below (and lane 0, which stores L_JJ) factors the 6x6 diagonal block in
-                    //     registers (redundantly: cheaper than a serial thread + barrier), then solves its row against it
+                    // (2) every lane that owns a row below (lane 0, which stores L_JJ, and the last lane, which owns the
+                    //     right-hand-side row) factors the 6x6 diagonal block in registers (redundantly: cheaper than a serial
+                    //     thread + barrier), then solves its row against it
                     const int nrows = (nk - J - 1) * 6;
-                    if (tid < nrows || tid == 0) {
+                    const bool rhs_row = tid == kLmBlock - 1;
+                    if (tid < nrows || tid == 0 || rhs_row) {
                         double D[21]; // lower triangle, row-major: (i,j) -> i*(i+1)/2 + j
 #pragma unroll
                         for (int i = 0; i < 6; ++i)
@@ -970,20 +1005,20 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             }
                         }
                         double x[6];
-                        const int row = 6 * (J + 1) + tid;
-                        if (tid < nrows) {
+                        double* rowv = rhs_row ? &sm.bs[6 * J] : &sm.S[(6 * (J + 1) + tid) * np + 6 * J];
+                        if (tid < nrows || rhs_row) {
 #pragma unroll
                             for (int c = 0; c < 6; ++c) {
-                                double v = sm.S[row * np + 6 * J + c];
+                                double v = rowv[c];
 #pragma unroll
                                 for (int kk = 0; kk < c; ++kk) v -= x[kk] * D[c * (c + 1) / 2 + kk];
                                 x[c] = v * rd[c];
                             }
                         }
                         if (tid == 0 && !good) sm.flag[1] = 1;
-                        if (tid < nrows)
+                        if (tid < nrows || rhs_row)
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) sm.S[row * np + 6 * J + c] = x[c];
+                            for (int c = 0; c < 6; ++c) rowv[c] = x[c];
                         // L_JJ is written only after the barrier below: other waves may still be reading the unfactored block
                         if (tid == 0) {
 #pragma unroll
@@ -1005,51 +1040,47 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 __syncthreads();
                 if (tid == 0) sm.flag[1] = 0;
                 if (ok2) {
-                    // forward / backward substitution by wave 0, blocked by pose: the 6x6 triangle is solved by every lane
-                    // redundantly in registers (no intra-block synchronisation), the rows outside the block are updated in parallel
+                    // backward substitution L^T x = y by wave 0 with the unknowns in registers: lane i owns u_i = x_i-in-progress
+                    // scaled by 1/L_ii (and u_{i+64}: np <= 128), so a step is readlane(u, r) -> one FMA with the pre-scaled row
+                    // of L (zero on and above the diagonal: finished unknowns stay put, no select).  The rows a block needs are
+                    // fetched and scaled while the previous block resolves.
                     if (wave == 0) {
-                        for (int i = lane; i < np; i += 64) sm.xp[i] = sm.bs[i];
-                        __builtin_amdgcn_wave_barrier();
-                        for (int J = 0; J < nk; ++J) { // L y = bs
-                            double y[6];
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) y[c] = sm.xp[6 * J + c];
+                        const double rd0 = lane < np ? sm.rdiag[lane] : 0.0, rd1 = lane + 64 < np ? sm.rdiag[lane + 64] : 0.0;
+                        double u0 = lane < np ? sm.bs[lane] * rd0 : 0.0, u1 = lane + 64 < np ? sm.bs[lane + 64] * rd1 : 0.0;
+                        double Ln0[6], Ln1[6];
+                        auto fetch_rows = [&](int J) {
 #pragma unroll
                             for (int c = 0; c < 6; ++c) {
-#pragma unroll
-                                for (int kk = 0; kk < c; ++kk) y[c] -= sm.S[(6 * J + c) * np + 6 * J + kk] * y[kk];
-                                y[c] *= sm.rdiag[6 * J + c];
+                                const int r = 6 * J + c;
+                                Ln0[c] = lane < r ? -sm.S[r * np + lane] * rd0 : 0.0;
+                                Ln1[c] = (r > 64 && lane + 64 < r) ? -sm.S[r * np + lane + 64] * rd1 : 0.0;
                             }
-                            __builtin_amdgcn_wave_barrier(); // every lane has read xp[6J..] before it is overwritten
-                            if (lane < 6) sm.xp[6 * J + lane] = lane == 0 ? y[0] : lane == 1 ? y[1] : lane == 2 ? y[2] : lane == 3 ? y[3] : lane == 4 ? y[4] : y[5];
-                            for (int i = 6 * (J + 1) + lane; i < np; i += 64) {
-                                double v = sm.xp[i];
+                        };
+                        fetch_rows(nk - 1);
+                        int J = nk - 1;
+                        for (; 6 * J + 5 >= 64; --J) { // unknowns 64.. live in u1 (only windows of more than 10 keyframes)
+                            double L0[6], L1[6];
 #pragma unroll
-                                for (int c = 0; c < 6; ++c) v -= sm.S[i * np + 6 * J + c] * y[c];
-                                sm.xp[i] = v;
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        for (int J = nk - 1; J >= 0; --J) { // L^T x = y
-                            double x[6];
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) x[c] = sm.xp[6 * J + c];
+                            for (int c = 0; c < 6; ++c) { L0[c] = Ln0[c]; L1[c] = Ln1[c]; }
+                            fetch_rows(J - 1);
 #pragma unroll
                             for (int c = 5; c >= 0; --c) {
-#pragma unroll
-                                for (int kk = c + 1; kk < 6; ++kk) x[c] -= sm.S[(6 * J + kk) * np + 6 * J + c] * x[kk];
-                                x[c] *= sm.rdiag[6 * J + c];
+                                const int r = 6 * J + c; // wave-uniform
+                                const double xr = r >= 64 ? readlane_f64(u1, r - 64) : readlane_f64(u0, r);
+                                u1 = fma(L1[c], xr, u1);
+                                u0 = fma(L0[c], xr, u0);
                             }
-                            __builtin_amdgcn_wave_barrier();
-                            if (lane < 6) sm.xp[6 * J + lane] = lane == 0 ? x[0] : lane == 1 ? x[1] : lane == 2 ? x[2] : lane == 3 ? x[3] : lane == 4 ? x[4] : x[5];
-                            for (int i = lane; i < 6 * J; i += 64) {
-                                double v = sm.xp[i];
-#pragma unroll
-                                for (int c = 0; c < 6; ++c) v -= sm.S[(6 * J + c) * np + i] * x[c];
-                                sm.xp[i] = v;
-                            }
-                            __builtin_amdgcn_wave_barrier();
                         }
+                        for (; J >= 0; --J) {
+                            double L0[6];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) L0[c] = Ln0[c];
+                            if (J > 0) fetch_rows(J - 1);
+#pragma unroll
+                            for (int c = 5; c >= 0; --c) u0 = fma(L0[c], readlane_f64(u0, 6 * J + c), u0);
+                        }
+                        if (lane < np) sm.xp[lane] = u0;
+                        if (lane + 64 < np) sm.xp[lane + 64] = u1;
                     }
                 } else {
                     for (int i = tid; i < np; i += kLmBlock) sm.xp[i] = 0;
@@ -1135,9 +1166,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 se3::mul(E, &sm.T[7 * tid], &sm.TTrial[7 * tid]);
                 expand_pose(&sm.TTrial[7 * tid], &sm.RtTrial[12 * tid]);
             }
-            const double scale = block_sum(scale_part, sm.red) + 1e-3;
+            scale = block_sum(scale_part, sm.red) + 1e-3;
+            } // !boot
             PH(9);
-            double tempChi = eval(sm.RtTrial, with_lm ? Pt : P, recA_alt, sm.HppT, sm.bpT);
+            double tempChi = eval(boot ? sm.Rt : sm.RtTrial, (boot || !with_lm) ? P : Pt, boot ? recA : recA_alt, boot ? sm.Hpp : sm.HppT, boot ? sm.bp : sm.bpT);
+            if (boot) { currentChi = tempChi; break; }
             last_trial_is_current = false;
             PH(10);
             if (!ok2) tempChi = 1.7976931348623157e308;
@@ -1153,7 +1186,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = sm.TTrial[i];
                 for (int i = tid; i < nk * 12; i += kLmBlock) sm.Rt[i] = sm.RtTrial[i];
                 if (with_lm) { double* t = P; P = Pt; Pt = t; }
-                { double4* ta = recA; recA = recA_alt; recA_alt = ta; have_lin = true; last_trial_is_current = true; }
+                { double4* ta = recA; recA = recA_alt; recA_alt = ta; last_trial_is_current = true; }
                 for (int i = tid; i < nk * 36; i += kLmBlock) sm.Hpp[i] = sm.HppT[i];
                 for (int i = tid; i < np; i += kLmBlock) sm.bp[i] = sm.bpT[i];
                 __syncthreads();
@@ -1164,6 +1197,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             ++qmax;
             again = (rho_gain < 0) && qmax < 10;
         }
+        if (boot) continue;
         total_trials += qmax;
         if (st && tid == 0 && it < VSLAM_LM_MAX_ITERS) { st->chi2_iter[it] = currentChi; st->lambda_iter[it] = lambda; st->trials_iter[it] = qmax; }
         if (qmax == 10 || rho_gain == 0) { ++it; break; }
