@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // then the arithmetic -- the per-thread summation order is unchanged.
     const float2* uv2 = reinterpret_cast<const float2*>(uv);
     constexpr int kEvalU = 4;
-    constexpr int kLmU = 2, kLmE = 4; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
+    constexpr int kLmU = 3, kLmE = 4; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
     // Evaluation + linearisation at (Rt, Pcur) in one keyframe-major pass.  The keyframe-major edge lists are cut into rows
     // of 64 edges (a row never straddles two keyframes); every wave owns a contiguous range of rows and streams it through
     // a register queue (landmark ids and observations four rows ahead, landmark positions two rows ahead: the lists come from
