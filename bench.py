@@ -64,7 +64,7 @@ def other_rooflines(prof, pipe, args):
     return out
 
 
-def cpu_baseline(pipe, anms_num, n_keyframes=3):
+def cpu_baseline(pipe, anms_num, n_keyframes=64):  # ~14 s of single-thread CPU work
     """the CPU oracle (single thread) on a bounded sample of the same workload: `n_keyframes` stereo keyframes + windows"""
     import oracle as O
     from stereo_visual_slam_amd import synth
