@@ -315,7 +315,7 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
 
 template <bool IMPL>
 __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel(LmKernelArgs ka, int mode, int iters, int update_poses, int update_lms,
-                                                            int classify) {
+                                                            int classify, int reuse_csr) {
     const LmWindowArgs& a = ka.a;
     __shared__ LmShared sm;
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
 
     // ------------------------------------------------------------------ setup
+    if (reuse_csr && ka.status[w] != VSLAM_OK) return; // a later launch of the schedule: the first one rejected this window's indices
     if (tid < 8) sm.flag[tid] = 0;
     for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = a.T[(size_t)w * nk * 7 + i];
     for (int i = tid; i < kLmWaves * kCntStride; i += kLmBlock) sm.cnt[i] = 0;
@@ -384,16 +385,40 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     }
     __syncthreads();
     if (tid < nk) expand_pose(&sm.T[7 * tid], &sm.Rt[12 * tid]);
-    for (int l = tid; l < nl; l += kLmBlock) {
-        PC(P, 0, l) = (double)xyz[3 * l]; PC(P, 1, l) = (double)xyz[3 * l + 1]; PC(P, 2, l) = (double)xyz[3 * l + 2];
+    // (the setup loops read cold data: every loop issues the loads of several iterations before it consumes the first --
+    // the compiler keeps a strided loop's iterations serial, one memory round trip each)
+    for (int l0 = tid; l0 < nl; l0 += 3 * kLmBlock) {
+        float v[3][3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int l = min(l0 + u * kLmBlock, nl - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[u][c] = xyz[3 * l + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int l = l0 + u * kLmBlock;
+            if (l < nl) { PC(P, 0, l) = (double)v[u][0]; PC(P, 1, l) = (double)v[u][1]; PC(P, 2, l) = (double)v[u][2]; }
+        }
     }
-    if (!IMPL) {
+    if (!IMPL && !reuse_csr) {
         // CSR by landmark from the sorted lm_idx; bad indices / unsorted input -> error flag
-        for (int e = tid; e < ne; e += kLmBlock) {
-            const int l = lmi[e], lp = e > 0 ? lmi[e - 1] : -1, k = kfi[e];
-            if (l < lp || l < 0 || l >= nl || k < 0 || k >= nk) { sm.flag[7] = 1; continue; }
-            for (int x = lp + 1; x <= l; ++x) lm_ptr[x] = e;
-            if (e == ne - 1) for (int x = l + 1; x <= nl; ++x) lm_ptr[x] = ne;
+        for (int eb = tid; eb < ne; eb += 4 * kLmBlock) {
+            int lv[4], lpv[4], kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(eb + u * kLmBlock, ne - 1);
+                lv[u] = lmi[e]; lpv[u] = e > 0 ? lmi[e - 1] : -1; kv[u] = kfi[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + u * kLmBlock;
+                if (e >= ne) break;
+                const int l = lv[u], lp = lpv[u], k = kv[u];
+                if (l < lp || l < 0 || l >= nl || k < 0 || k >= nk) { sm.flag[7] = 1; continue; }
+                for (int x = lp + 1; x <= l; ++x) lm_ptr[x] = e;
+                if (e == ne - 1) for (int x = l + 1; x <= nl; ++x) lm_ptr[x] = ne;
+            }
         }
         if (ne == 0) for (int x = tid; x <= nl; x += kLmBlock) lm_ptr[x] = 0;
     }
@@ -404,13 +429,19 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         if (tid == 0) ka.status[w] = VSLAM_ERR_ARG;
         return;
     }
-    for (int l = tid; l < nl; l += kLmBlock) {
-        bool on = true;
-        if (!IMPL) {
-            on = lm_ptr[l + 1] > lm_ptr[l] && a.lm_inlier[lm0 + l] != 0;
-            if (with_lm && a.reliable) on = on && a.reliable[lm0 + l] != 0;
+    for (int l0 = tid; l0 < nl; l0 += 3 * kLmBlock) {
+        bool on[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int l = min(l0 + u * kLmBlock, nl - 1);
+            on[u] = true;
+            if (!IMPL) {
+                on[u] = lm_ptr[l + 1] > lm_ptr[l] && a.lm_inlier[lm0 + l] != 0;
+                if (with_lm && a.reliable) on[u] = on[u] && a.reliable[lm0 + l] != 0;
+            }
         }
-        act[l] = on;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) if (l0 + u * kLmBlock < nl) act[l0 + u * kLmBlock] = on[u];
     }
     __syncthreads();
     if (!IMPL) {
@@ -545,11 +576,14 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             const int nitems = npairs;
             for (int i = tid; i < kLmWaves * kItemSlots; i += kLmBlock) sm.item[i] = 0xFF;
             __syncthreads();
+            // (work per item staged in LDS first: ranking straight from kf_ptr costs a global round trip per comparison)
+            int* s_work = sm.cnt; // free after the list build
+            if (tid < nitems) { const int a1 = sm.pk1[tid]; s_work[tid] = a1 == sm.pk2[tid] ? sm.kfp[a1 + 1] - sm.kfp[a1] : (int)sm.ptot[tid]; }
+            __syncthreads();
             if (tid < nitems) {
-                auto work = [&](int q) -> int { const int a1 = sm.pk1[q]; return a1 == sm.pk2[q] ? kf_ptr[a1 + 1] - kf_ptr[a1] : (int)sm.ptot[q]; };
-                const int mine = work(tid);
+                const int mine = s_work[tid];
                 int rank = 0;
-                for (int j = 0; j < nitems; ++j) { const int c = work(j); rank += (c > mine) || (c == mine && j < tid); }
+                for (int j = 0; j < nitems; ++j) { const int c = s_work[j]; rank += (c > mine) || (c == mine && j < tid); }
                 const int row = rank / kLmWaves, col = rank % kLmWaves;
                 sm.item[((row & 1) ? kLmWaves - 1 - col : col) * kItemSlots + row] = (uint8_t)tid;
             }
@@ -1369,12 +1403,12 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1);
     if (schedule) {
         // run_vslam.cpp:58-71: optimize_map(5) x2 without write-back, optimize_map(10) writing poses, optimize_pose_only(10)
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1);
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1);
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 10, 1, 0, 1);
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 1); // (the landmark CSR of the first launch is still valid)
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 10, 1, 0, 1, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1);
     } else {
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, mode, iters, update_poses, update_lms, 1);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, mode, iters, update_poses, update_lms, 1, 0);
     }
     VS_HIP(hipGetLastError());
     if (ka.dbg_cycles) {
@@ -1411,7 +1445,7 @@ int launch_pnp(const PnpArgs& p, LmScratch* scratch, hipStream_t stream) {
     int rc = carve(*scratch, ka, tot, tot, p.B, false, stream);
     if (rc) return rc;
     ProfScope prof__(stream, "lm_window_kernel<pnp>", 2);
-    hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0);
+    hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0, 0);
     hipLaunchKernelGGL(pnp_inlier_kernel, dim3(p.B), dim3(256), 0, stream, p.xyz, p.uv, p.n, p.capacity, p.T, p.K[0], p.K[1], p.K[2], p.K[3],
                        p.reproj_thr * p.reproj_thr, p.inlier, p.n_inliers);
     VS_HIP(hipGetLastError());
