@@ -515,6 +515,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             ++idx;
                         }
                 }
+                const long long t_h = cyc ? clock64() : 0;
                 for (int base = l_lo; base < l_hi; base += 64) {
                     const int l = base + lane;
                     uint32_t w6[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -536,21 +537,28 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         for (int q = 0; q < 4; ++q) if (b0 + q < b1) put(kq[q], pq[q]);
                         for (int e = b0 + 4; e < b1; ++e) put(kfi[e], kf_pos[e]);
                     }
+                    // which lanes' landmarks are seen by keyframe K: one ballot per keyframe, then a pair's hit mask is the AND of
+                    // two scalar masks (creation-ordered landmarks: most pairs of a row are empty and cost three scalar ops)
+                    unsigned long long pres[kMaxKf];
+#pragma unroll
+                    for (int K = 0; K < kMaxKf; ++K) pres[K] = K < nk ? __ballot(((w6[K >> 1] >> (16 * (K & 1))) & 0xFFFFu) != 0xFFFFu) : 0ull;
                     int idx = 0;
 #pragma unroll
                     for (int K1 = 0; K1 < kMaxKf - 1; ++K1)
 #pragma unroll
                         for (int K2 = K1 + 1; K2 < kMaxKf; ++K2) {
-                            if (K2 < nk) { // uniform
-                                const uint32_t f1 = (w6[K1 >> 1] >> (16 * (K1 & 1))) & 0xFFFFu, f2 = (w6[K2 >> 1] >> (16 * (K2 & 1))) & 0xFFFFu;
-                                const bool hit = f1 != 0xFFFFu && f2 != 0xFFFFu;
-                                const unsigned long long m = __ballot(hit);
-                                if (pass && hit) hits[run[idx] + __popcll(m & lt_mask)] = make_int2((int)(f1 | (f2 << 16)), l);
+                            const unsigned long long m = pres[K1] & pres[K2];
+                            if (m) { // uniform
+                                if (pass && ((m >> lane) & 1ull)) {
+                                    const uint32_t f1 = (w6[K1 >> 1] >> (16 * (K1 & 1))) & 0xFFFFu, f2 = (w6[K2 >> 1] >> (16 * (K2 & 1))) & 0xFFFFu;
+                                    hits[run[idx] + __popcll(m & lt_mask)] = make_int2((int)(f1 | (f2 << 16)), l);
+                                }
                                 run[idx] += __popcll(m);
                             }
                             ++idx;
                         }
                 }
+                if (cyc && tid == 0) cyc[15] += clock64() - t_h;
                 if (!pass && lane == 0) {
                     int idx = 0;
 #pragma unroll
@@ -978,7 +986,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int J = 0; J < nk && ok2; ++J) {
                     // (1) block column J -= L[.,0..J) L[J,0..J)^T   -- one lane per element of the (nk-J) x 1 block column
                     const int nel = (nk - J) * 36;
-                    const long long t_c1 = cyc ? clock64() : 0;
                     for (int t = tid; t < nel; t += kLmBlock) {
                         const int I = J + t / 36, r = (t % 36) / 6, c = t % 6;
                         double v = sm.S[(6 * I + r) * np + 6 * J + c];
@@ -1007,7 +1014,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         }
                         sm.bs[6 * J + c] = v;
                     }
-                    if (cyc && tid == 0) cyc[15] += clock64() - t_c1;
                     __syncthreads();
                     // (2) every lane that owns a row below (lane 0, which stores L_JJ, and the last lane, which owns the
                     //     right-hand-side row) factors the 6x6 diagonal block in registers (redundantly: cheaper than a serial
@@ -1415,7 +1421,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipStreamSynchronize(stream);
         std::vector<long long> h(16 * (size_t)a.n_windows);
         hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(eval: row loop, wave 0)"};
+        static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(probe)"};
         double tot = 0;
         for (int i = 0; i < 16; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
         fprintf(stderr, "  [lm profile] total %.0f ticks (clock64 = 100 MHz s_memtime units; really shader-clock cycles)\n", tot);
