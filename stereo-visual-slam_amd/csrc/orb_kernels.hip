@@ -449,11 +449,70 @@ int launch_orb_fast(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes
 }
 
 // ------------------------------------------------------------------------------------------- sorting helper
-// in-LDS bitonic sort (ascending) of n (power of two) keys by the whole workgroup
+// In-LDS bitonic sort (ascending) of n (power of two) keys by the whole workgroup.  A compare-exchange stage with stride j only
+// couples keys inside aligned blocks of 2j, so every wave owns a chunk of 64 E consecutive keys (E per lane, blocked) and runs
+// all stages with j < 64 E on registers: strides below E inside the lane, strides E..32 E as lane exchanges (ds_bpermute, no
+// barrier).  Only the strides >= 64 E of the last log2(n / 64 E) merge levels go through LDS with a workgroup barrier: 10 of the
+// 78 stages of a 4096-key sort on 1024 lanes (a 16-wave barrier costs ~400 cycles, a plain stage also one exposed LDS round trip).
 template <typename K>
-__device__ inline void bitonic_sort_lds(K* a, int n) {
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+__device__ inline K shfl_xor_key(K v, int d) {
+    if constexpr (sizeof(K) == 8) {
+        const int lo = __shfl_xor((int)(uint32_t)v, d), hi = __shfl_xor((int)(uint32_t)(v >> 32), d);
+        return ((K)(uint32_t)hi << 32) | (K)(uint32_t)lo;
+    } else {
+        return (K)__shfl_xor((int)v, d);
+    }
+}
+// stages j = jtop, jtop / 2, ..., 1 of merge level k on a wave's chunk; v[r] is the key with global index g0 + r
+template <typename K, int E>
+__device__ inline void bitonic_chunk_stages(K (&v)[E], int g0, int k, int jtop) {
+    const int lane = threadIdx.x & 63;
+    for (int j = jtop; j >= E; j >>= 1) {
+        const int d = j / E;
+        const bool lower = (lane & d) == 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const K o = shfl_xor_key(v[r], d);
+            const bool take_min = lower == (((g0 + r) & k) == 0);
+            v[r] = ((v[r] < o) == take_min) ? v[r] : o; // (equal keys: either copy)
+        }
+    }
+#pragma unroll
+    for (int j = E / 2; j >= 1; j >>= 1) {
+        if (j > jtop) continue;
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            if ((r & j) == 0) {
+                const bool up = ((g0 + r) & k) == 0;
+                const K x = v[r], y = v[r | j];
+                if ((x > y) == up) { v[r] = y; v[r | j] = x; }
+            }
+    }
+}
+template <typename K, int E>
+__device__ inline void bitonic_sort_lds_e(K* a, int n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int C = 64 * E;
+    const int g0 = wave * C + lane * E; // this lane's first key
+    const bool mine = g0 < n;           // (n is a power of two: a lane's E keys are all inside or all outside when n >= E)
+    K v[E];
+    auto load = [&]() {
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] = (g0 + r < n) ? a[g0 + r] : (K)~(K)0;
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int r = 0; r < E; ++r) if (g0 + r < n) a[g0 + r] = v[r];
+    };
+    __syncthreads();
+    // merge levels that fit a chunk: registers only
+    if (wave * C < n) { // wave-uniform: whole waves take part in the lane exchanges
+        load();
+        for (int k = 2; k <= min(n, C); k <<= 1) bitonic_chunk_stages<K, E>(v, g0, k, k >> 1);
+        store();
+    }
+    for (int k = 2 * C; k <= n; k <<= 1) {
+        for (int j = k >> 1; j >= C; j >>= 1) { // strides that cross chunks: through LDS
             __syncthreads();
             for (int t = threadIdx.x; t < n / 2; t += blockDim.x) {
                 const int lo = ((t / j) * 2 * j) + (t % j);
@@ -463,8 +522,36 @@ __device__ inline void bitonic_sort_lds(K* a, int n) {
                 if ((x > y) == up) { a[lo] = y; a[hi] = x; }
             }
         }
+        __syncthreads();
+        if (wave * C < n) {
+            load();
+            bitonic_chunk_stages<K, E>(v, g0, k, C >> 1);
+            store();
+        }
     }
     __syncthreads();
+}
+template <typename K>
+__device__ inline void bitonic_sort_lds(K* a, int n) {
+    const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x; // keys per lane so that the waves' chunks cover the array
+    if (per <= 1) bitonic_sort_lds_e<K, 1>(a, n);
+    else if (per <= 2) bitonic_sort_lds_e<K, 2>(a, n);
+    else if (per <= 4) bitonic_sort_lds_e<K, 4>(a, n);
+    else if (per <= 8) bitonic_sort_lds_e<K, 8>(a, n);
+    else { // (not reached with the capacities of this library: plain network, one barrier per stage)
+        for (int k = 2; k <= n; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                __syncthreads();
+                for (int t = threadIdx.x; t < n / 2; t += blockDim.x) {
+                    const int lo = ((t / j) * 2 * j) + (t % j);
+                    const int hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const K x = a[lo], y = a[hi];
+                    if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+                }
+            }
+        __syncthreads();
+    }
 }
 
 __device__ inline uint32_t float_order_key(float f) { // monotone: larger float -> larger key; -0 == +0
@@ -870,8 +957,19 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
                 // dx^2 and dy^2 are exact in f64 (24-bit factors), so the fused form rounds once, exactly like mul + mul + add
                 best = fmin(best, __fma_rn((double)dx, (double)dx, __dmul_rn((double)dy, (double)dy)));
             };
+            // (both candidate loops fetch four candidates before the first distance: the compiler leaves a one-candidate loop
+            // serial, one LDS round trip -- two in the cell lists -- per candidate)
+            auto visit_p = [&](float2 pj) {
+                const float dx = __fsub_rn(xi, pj.x), dy = __fsub_rn(yi, pj.y);
+                best = fmin(best, __fma_rn((double)dx, (double)dx, __dmul_rn((double)dy, (double)dy)));
+            };
             if (lo <= kAnmsBrute) {
-                for (int j = 0; j < lo; ++j) visit(j);
+                int j = 0;
+                for (; j + 4 <= lo; j += 4) {
+                    const float2 p0 = sxy[j], p1 = sxy[j + 1], p2 = sxy[j + 2], p3 = sxy[j + 3];
+                    visit_p(p0); visit_p(p1); visit_p(p2); visit_p(p3);
+                }
+                for (; j < lo; ++j) visit(j);
             } else {
                 const int ci = cof[i], cxi = ci % gx, cyi = ci / gx;
                 const int kmax = max(max(cxi, gx - 1 - cxi), max(cyi, gy - 1 - cyi));
@@ -889,10 +987,16 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
                         for (int cx = x0; cx <= x1; cx += step) {
                             if (cx < 0 || cx >= gx) continue;
                             const int c = cy * gx + cx;
-                            for (int t = coff[c], t1 = coff[c + 1]; t < t1; ++t) {
-                                const int j = clist[t];
-                                if (j >= lo) break; // the list ascends in rank
-                                visit(j);
+                            for (int t = coff[c], t1 = coff[c + 1]; t < t1; t += 4) { // the list ascends in rank: stop at the first j >= lo
+                                int jj[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) jj[q] = t + q < t1 ? (int)clist[t + q] : 0x7FFFFFFF;
+                                float2 pp[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) pp[q] = sxy[min(jj[q], N - 1)];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) if (jj[q] < lo) visit_p(pp[q]);
+                                if (jj[3] >= lo) break;
                             }
                         }
                     }
