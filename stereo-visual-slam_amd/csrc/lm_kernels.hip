@@ -91,7 +91,6 @@ struct LmKernelArgs {
     long long* dbg_cycles; // tuning aid (VSLAM_LM_PROFILE=1): 16 phase cycle counters per window, thread 0
     int dinv_lds;     // landmarks per window whose Dinv is kept in dynamic LDS (0 = none)
     int want_chi2;    // the caller passed a chi2 output array: scatter chi2 back to its edge order at the end
-    int dbg_skip;     // tuning aid (VSLAM_LM_SKIP): bit0 Schur hits, bit1 Cholesky, bit2 pose blocks, bit3 landmark blocks, bit4 eval, bit5 back-subst, bit6 setup lists
 };
 
 __device__ inline double wave_sum(double v) {
@@ -1397,7 +1396,6 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_window_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
         lds_attr_set = true;
     }
-    { const char* e = getenv("VSLAM_LM_SKIP"); ka.dbg_skip = e ? atoi(e) : 0; }
     static long long* d_cyc = nullptr; static int cyc_n = 0;
     if (getenv("VSLAM_LM_PROFILE")) {
         if (cyc_n < a.n_windows) { if (d_cyc) hipFree(d_cyc); hipMalloc((void**)&d_cyc, sizeof(long long) * 16 * a.n_windows); cyc_n = a.n_windows; }
@@ -1421,10 +1419,10 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipStreamSynchronize(stream);
         std::vector<long long> h(16 * (size_t)a.n_windows);
         hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(probe)"};
+        static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(setup: hit-list passes)"};
         double tot = 0;
         for (int i = 0; i < 16; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
-        fprintf(stderr, "  [lm profile] total %.0f ticks (clock64 = 100 MHz s_memtime units; really shader-clock cycles)\n", tot);
+        fprintf(stderr, "  [lm profile] total %.0f ticks (clock64 = 100 MHz s_memtime units = shader-clock cycles, thread 0 of every window)\n", tot);
     }
     return VSLAM_OK;
 }

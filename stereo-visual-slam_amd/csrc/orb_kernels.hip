@@ -617,27 +617,51 @@ __device__ inline float fast_atan2_dev(float y, float x) {
 
 // intensity-centroid angle by a 16-lane group (4 keypoints per wave): lane v of the group owns the row pair +-v, read
 // as 2 x 8 unaligned dwords (u = -15..16) issued together; |u| > umax[v] is masked out.
-__device__ inline float ic_angle_group16(const LevelView& V, int x, int y, bool valid) {
+// Per-lane constants of the intensity-centroid rows: lane v of a 16-lane group owns rows y+v and y-v of the 31x31 patch.  Byte t of
+// the 32-byte row window (t = u + 15) gets weight t inside the circular mask (|u| <= umax[v]) and 0 outside, plus a 0/1 mask byte:
+// sum(u * I) = dot(I, wt) - 15 * dot(I, wmask), all on v_dot4_u32_u8 (exact integer arithmetic).
+struct IcRowWeights { uint32_t wt[8], wmask[8]; };
+__device__ inline IcRowWeights ic_row_weights() {
     const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     const int v = threadIdx.x & 15;
     int dmax = 15;
 #pragma unroll
     for (int k = 0; k < 16; ++k) if (k == v) dmax = umax[k];
+    IcRowWeights w;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint32_t a = 0, m = 0;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const int t = 4 * q + bb, u = t - 15;
+            const bool in = t < 31 && u >= -dmax && u <= dmax;
+            a |= (in ? (uint32_t)t : 0u) << (8 * bb);
+            m |= (in ? 1u : 0u) << (8 * bb);
+        }
+        w.wt[q] = a; w.wmask[q] = m;
+    }
+    return w;
+}
+__device__ inline float ic_angle_group16(const LevelView& V, int x, int y, bool valid, const IcRowWeights& w) {
+    const int v = threadIdx.x & 15;
     int m10 = 0, vsum = 0;
     if (valid) {
         const uint8_t* cp = V.ptr + (size_t)(y + v) * V.pitch + x - 15;
         const uint8_t* cm = V.ptr + (size_t)(y - v) * V.pitch + x - 15;
+        // two unaligned 16-B loads per row: every lane reads its own row, so the cost is cache lines touched per instruction
         uint32_t wp[8], wm[8];
+        __builtin_memcpy(&wp[0], cp, 16); __builtin_memcpy(&wp[4], cp + 16, 16);
+        __builtin_memcpy(&wm[0], cm, 16); __builtin_memcpy(&wm[4], cm + 16, 16);
+        uint32_t sp = 0, smn = 0, tp = 0, tm = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { __builtin_memcpy(&wp[q], cp + 4 * q, 4); __builtin_memcpy(&wm[q], cm + 4 * q, 4); }
-#pragma unroll
-        for (int t = 0; t < 31; ++t) {
-            const int u = t - 15;
-            const int vp = (int)((wp[t >> 2] >> (8 * (t & 3))) & 0xFFu), vm = (int)((wm[t >> 2] >> (8 * (t & 3))) & 0xFFu);
-            const int in = (u >= -dmax && u <= dmax) ? 1 : 0;
-            vsum += in * (vp - vm);
-            m10 += in * u * (vp + vm); // row 0: vp == vm (same row read twice), halved below
+        for (int q = 0; q < 8; ++q) {
+            sp = __builtin_amdgcn_udot4(wp[q], w.wmask[q], sp, false);
+            smn = __builtin_amdgcn_udot4(wm[q], w.wmask[q], smn, false);
+            tp = __builtin_amdgcn_udot4(wp[q], w.wt[q], tp, false);
+            tm = __builtin_amdgcn_udot4(wm[q], w.wt[q], tm, false);
         }
+        vsum = (int)sp - (int)smn;
+        m10 = (int)(tp + tm) - 15 * (int)(sp + smn); // row 0: both windows are the same row, halved below
         if (v == 0) m10 >>= 1; // exact: m10 = 2 * sum(u * I) on the centre row
     }
     int m01 = v * vsum;
@@ -778,13 +802,14 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     vslam_keypoint* out = d_sel + ((size_t)b * kNLevels + l) * sel_cap;
     const int grp = threadIdx.x >> 4, ngrp = kSelBlock >> 4;
     const float scale = T.scale[l];
+    const IcRowWeights icw = ic_row_weights();
     for (int i0 = 0; i0 < nout; i0 += ngrp) { // uniform trip count: the group shuffles need whole waves
         const int i = i0 + grp;
         const bool valid = i < nout;
         const unsigned long long e = valid ? keep[i] : 0ull;
         const uint32_t raster = (uint32_t)(e >> 32);
         const int x = raster & 0xFFF, y = raster >> 12;
-        const float ang = ic_angle_group16(V, x, y, valid);
+        const float ang = ic_angle_group16(V, x, y, valid, icw);
         if (valid && (threadIdx.x & 15) == 0) {
             vslam_keypoint kp;
             kp.x = __fmul_rn((float)x, scale);
