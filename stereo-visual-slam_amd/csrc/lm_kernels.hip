@@ -1422,7 +1422,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(setup: hit-list passes)"};
         double tot = 0;
         for (int i = 0; i < 16; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
-        fprintf(stderr, "  [lm profile] total %.0f ticks (clock64 = 100 MHz s_memtime units = shader-clock cycles, thread 0 of every window)\n", tot);
+        fprintf(stderr, "  [lm profile] total %.0f cycles (clock64 = shader clock, thread 0 of every window; setup sub-splits not included)\n", tot);
     }
     return VSLAM_OK;
 }
