@@ -933,7 +933,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     } else {
                         const int jend = pair_ptr[p + 1];
                         int j = pair_ptr[p] + lane;
-                        if (pair_ptr[p] < jend) {
+                        if (pair_ptr[p] >= jend) continue; // no common landmark: the block stays zero (S was cleared), no butterfly
+                        {
                         int2 h = hits[min(j, jend - 1)];
                         int2 hn = hits[min(j + 64, jend - 1)];
                         double4 ra = recA[h.x & 0xFFFF], rb = recA[(unsigned)h.x >> 16];
