@@ -11,10 +11,12 @@
 //
 // gfx950 mapping: ONE WORKGROUP PER WINDOW runs the whole LM loop persistently (no host round trips; a batch of
 // windows fills the 256 CUs).  All sums are f64 with a FIXED order (no floating-point atomics):
-//   - evaluation + linearisation                : one keyframe-major pass per state: (pose, third) waves stream the pose's edge
-//                                                 list, write the 32-B records {X, Y, 1/Z, w} and accumulate Hpp, b_p on the
-//                                                 fly; trial states are linearised speculatively into spare buffers, so an
-//                                                 accepted trial needs no re-evaluation
+//   - evaluation + linearisation                : one keyframe-major pass per state: the edge lists are cut into 64-edge rows,
+//                                                 every wave streams a contiguous range of rows through register queues,
+//                                                 writes the 32-B records {X, Y, 1/Z, w} and accumulates Hpp, b_p on the fly;
+//                                                 trial states are linearised speculatively into spare buffers, so an
+//                                                 accepted trial needs no re-evaluation (one call site: the initial state goes
+//                                                 through the same code as a pseudo-iteration)
 //   - per-landmark blocks (Hll, b_l, Dinv), back-substitution : one lane per landmark; records are recomputed from the
 //                                                 landmark position and the observations (batched loads), not gathered;
 //                                                 Dinv of the first kDinvLds landmarks stays in LDS
@@ -22,10 +24,15 @@
 //                                                 precomputed 8-B hit list, diagonal pairs stream the keyframe's own list and
 //                                                 also produce the reduced right-hand side; single owner per block
 //   - wave reductions                           : halving butterfly (N sums cost ~N shuffles and end one per lane)
-//   - reduced system                            : blocked Cholesky + blocked triangular solves in LDS
+//   - reduced system                            : blocked left-looking Cholesky in LDS, the right-hand side rides along as an extra
+//                                                 row (forward substitution for free), backward substitution with the unknowns
+//                                                 in the lanes of one wave (readlane + FMA per unknown)
 // Landmarks and pixels are f32 at rest (quirk Q4); poses, accumulators and the LM state are f64.
-// No MFMA: the largest dense object is the 72x72 reduced system.  Bound: a mix of HBM-rate phases (evaluation, Schur
-// gathers) and f64 VALU at two waves per SIMD; see DESIGN.md section 5 for the phase split and counters.
+// No MFMA: the largest dense object is the 72x72 reduced system (and f64 MFMA has the vector rate on gfx950).  Bound: f64 VALU
+// issue at two waves per SIMD (256 VGPRs: the Schur accumulators) plus the serial reduced-system phases; machine facts used
+// below (tools/scratch/lat.hip): one wave issues a VALU op per 8 cycles, a dependent f64 FMA takes 8, an LDS round trip ~60, a
+// barrier of 8 waves ~210, and loops with run-time trip counts are NOT software-pipelined by the compiler -- every hot loop
+// here fetches the operands of several iterations before the first use.  See DESIGN.md section 5 for the phase split.
 #include "vslam_internal.h"
 
 #include <stdlib.h>
