@@ -61,6 +61,22 @@ def other_rooflines(prof, pipe, args):
         tops = 2.0 * macs / (k[0] / 1e3) / 1e12
         out.append({"kernel": "match_train_nearest_kernel", "bound": "mfma", "achieved": round(tops, 1), "peak": 5000.0, "unit": "TOP/s (int8)",
                     "frac": round(tops / 5000.0, 4), "note": "v_mfma_i32_32x32x32_i8; 4250 TOP/s sustained in tools/scratch/mfma_rate.hip"})
+    # what actually bounds the dominant kernel: VALU issue.  Wave-instructions per window and schedule come from the SQ counter
+    # pass (tools/profile_sq.sh -> profiles/traffic.json); every VALU op, f64 or not, takes a 4-cycle issue slot of its SIMD.
+    k = prof.get("lm_window_kernel")
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        wi = float(tj.get("valu_wave_insts_per_window_schedule", 0))
+    except Exception:
+        wi = 0.0
+    if k and k[0] > 0 and wi > 0 and pipe.lms_per_window == 3000 and pipe.n_kf == 10:
+        sets = k[2] if len(k) > 2 and k[2] else args.steps
+        t = k[0] / 1e3 / sets                                   # seconds per schedule batch
+        slots = 256 * 4 * 2.4e9 * t / 4.0                       # 256 CUs x 4 SIMDs, one VALU issue per 4 cycles at 2.4 GHz
+        used = wi * pipe.B
+        out.append({"kernel": "lm_window_kernel", "bound": "valu-issue", "achieved": round(used / t / 1e12, 3), "peak": round(256 * 4 * 2.4e9 / 4.0 / 1e12, 3),
+                    "unit": "T wave-instructions/s", "frac": round(used / slots, 4),
+                    "note": "SQ_INSTS_VALU of the BA schedule (profiles/r01c_ba_sq_issue_stall_summary.txt) over the live kernel time; two waves per SIMD (256 VGPRs)"})
     return out
 
 
