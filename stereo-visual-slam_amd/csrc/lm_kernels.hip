@@ -319,6 +319,24 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
     return ok;
 }
 
+// v - sum_{kk < 6 nK} a[kk] * b[kk] for two 16-B aligned LDS rows: the operands of block K + 1 are requested before the products
+// of block K are formed, and the sum runs in two independent chains (a dependent f64 FMA issues every 8 cycles).
+__device__ inline double row_dot_sub(double v, const double* a, const double* b, int nK) {
+    const double2* ra2 = reinterpret_cast<const double2*>(a);
+    const double2* rb2 = reinterpret_cast<const double2*>(b);
+    if (nK <= 0) return v;
+    double s0 = 0, s1 = 0;
+    double2 a0 = ra2[0], a1 = ra2[1], a2 = ra2[2], b0 = rb2[0], b1 = rb2[1], b2 = rb2[2];
+    for (int K = 1; K < nK; ++K) {
+        const double2 c0 = ra2[3 * K], c1 = ra2[3 * K + 1], c2 = ra2[3 * K + 2];
+        const double2 d0 = rb2[3 * K], d1 = rb2[3 * K + 1], d2 = rb2[3 * K + 2];
+        s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1); s0 = fma(a1.x, b1.x, s0); s1 = fma(a1.y, b1.y, s1); s0 = fma(a2.x, b2.x, s0); s1 = fma(a2.y, b2.y, s1);
+        a0 = c0; a1 = c1; a2 = c2; b0 = d0; b1 = d1; b2 = d2;
+    }
+    s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1); s0 = fma(a1.x, b1.x, s0); s1 = fma(a1.y, b1.y, s1); s0 = fma(a2.x, b2.x, s0); s1 = fma(a2.y, b2.y, s1);
+    return v - (s0 + s1);
+}
+
 template <bool IMPL>
 __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel(LmKernelArgs ka, int mode, int iters, int update_poses, int update_lms,
                                                             int classify, int reuse_csr) {
@@ -521,7 +539,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             ++idx;
                         }
                 }
-                const long long t_h = cyc ? clock64() : 0;
                 for (int base = l_lo; base < l_hi; base += 64) {
                     const int l = base + lane;
                     uint32_t w6[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -564,7 +581,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             ++idx;
                         }
                 }
-                if (cyc && tid == 0) cyc[15] += clock64() - t_h;
                 if (!pass && lane == 0) {
                     int idx = 0;
 #pragma unroll
@@ -996,15 +1012,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     for (int t = tid; t < nel; t += kLmBlock) {
                         const int I = J + t / 36, r = (t % 36) / 6, c = t % 6;
                         double v = sm.S[(6 * I + r) * np + 6 * J + c];
-                        // six products per step, operands fetched as 16-B pairs before the first FMA (the compiler does not
-                        // pipeline the scalar loop: one LDS round trip per product otherwise)
-                        const double2* ra2 = reinterpret_cast<const double2*>(&sm.S[(6 * I + r) * np]);
-                        const double2* rb2 = reinterpret_cast<const double2*>(&sm.S[(6 * J + c) * np]);
-                        for (int K = 0; K < J; ++K) {
-                            const double2 a0 = ra2[3 * K], a1 = ra2[3 * K + 1], a2 = ra2[3 * K + 2];
-                            const double2 b0 = rb2[3 * K], b1 = rb2[3 * K + 1], b2 = rb2[3 * K + 2];
-                            v -= a0.x * b0.x; v -= a0.y * b0.y; v -= a1.x * b1.x; v -= a1.y * b1.y; v -= a2.x * b2.x; v -= a2.y * b2.y;
-                        }
+                        v = row_dot_sub(v, &sm.S[(6 * I + r) * np], &sm.S[(6 * J + c) * np], J);
                         sm.S[(6 * I + r) * np + 6 * J + c] = v;
                     }
                     // the right-hand side rides along as one more row of the matrix: L y = bs is solved by the factorisation
@@ -1012,13 +1020,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     if (tid >= kLmBlock - 6) {
                         const int c = tid - (kLmBlock - 6);
                         double v = sm.bs[6 * J + c];
-                        const double2* ra2 = reinterpret_cast<const double2*>(&sm.bs[0]);
-                        const double2* rb2 = reinterpret_cast<const double2*>(&sm.S[(6 * J + c) * np]);
-                        for (int K = 0; K < J; ++K) {
-                            const double2 a0 = ra2[3 * K], a1 = ra2[3 * K + 1], a2 = ra2[3 * K + 2];
-                            const double2 b0 = rb2[3 * K], b1 = rb2[3 * K + 1], b2 = rb2[3 * K + 2];
-                            v -= a0.x * b0.x; v -= a0.y * b0.y; v -= a1.x * b1.x; v -= a1.y * b1.y; v -= a2.x * b2.x; v -= a2.y * b2.y;
-                        }
+                        v = row_dot_sub(v, &sm.bs[0], &sm.S[(6 * J + c) * np], J);
                         sm.bs[6 * J + c] = v;
                     }
                     __syncthreads();
@@ -1427,7 +1429,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipStreamSynchronize(stream);
         std::vector<long long> h(16 * (size_t)a.n_windows);
         hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(setup: hit-list passes)"};
+        static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(probe slot, unused)"};
         double tot = 0;
         for (int i = 0; i < 16; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
         fprintf(stderr, "  [lm profile] total %.0f cycles (clock64 = shader clock, thread 0 of every window; setup sub-splits not included)\n", tot);
