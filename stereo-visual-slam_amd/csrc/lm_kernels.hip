@@ -722,7 +722,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
                     lin_record(Rk, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
                     part += rho;
-                    if (with_lm) dstA[j] = make_double4(X, Y, Zi, wgt); // only the Schur passes read the records back
                     jac_pose(K, X, Y, Zi, A);
 #pragma unroll
                     for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
@@ -879,9 +878,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     const int p = sm.item[wave * kItemSlots + slot];
                     if (p == 0xFF) continue; // uniform per wave
                     const int k1 = sm.pk1[p], k2 = sm.pk2[p];
-                    double R1[9], R2[9]; // rotations of the pair, wave-uniform
+                    double R1[12], R2[12]; // poses of the pair, wave-uniform
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) { R1[i] = uniform_f64(sm.Rt[12 * k1 + i]); R2[i] = uniform_f64(sm.Rt[12 * k2 + i]); }
+                    for (int i = 0; i < 12; ++i) { R1[i] = uniform_f64(sm.Rt[12 * k1 + i]); R2[i] = uniform_f64(sm.Rt[12 * k2 + i]); }
                     double acc[36];
 #pragma unroll
                     for (int i = 0; i < 36; ++i) acc[i] = 0;
@@ -893,17 +892,21 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         double accb[6] = {0, 0, 0, 0, 0, 0}; // this keyframe's share of W Dinv b_l (reduced right-hand side)
                         if (jbeg < jend) { // (an empty list has no valid record to prefetch)
                         int ln = kf_lm[min(j, jend - 1)], lnn = kf_lm[min(j + 64, jend - 1)];
-                        double4 ra = recA[min(j, jend - 1)];
+                        float2 za = uvk2[min(j, jend - 1)];
+                        double pax = PC(P, 0, ln), pay = PC(P, 1, ln), paz = PC(P, 2, ln);
                         double2 Da, Db, Dc;
                         loadD(ln, Da, Db, Dc);
                         double g0 = PC(bl, 0, ln), g1 = PC(bl, 1, ln), g2 = PC(bl, 2, ln);
                         for (; j < jend; j += 64) {
                             const int lnnn = kf_lm[min(j + 128, jend - 1)];
-                            const double4 ran = recA[min(j + 64, jend - 1)];
+                            const float2 zan = uvk2[min(j + 64, jend - 1)];
+                            const double paxn = PC(P, 0, lnn), payn = PC(P, 1, lnn), pazn = PC(P, 2, lnn);
                             double2 Dan, Dbn, Dcn;
                             loadD(lnn, Dan, Dbn, Dcn);
                             const double g0n = PC(bl, 0, lnn), g1n = PC(bl, 1, lnn), g2n = PC(bl, 2, lnn);
                             double A1[12], B1[6];
+                            double4 ra; // the linearisation record {X, Y, 1/Z, w}, recomputed from the landmark and the observation
+                            { double ex_, ey_, c_, rho_; lin_record(R1, K, pax, pay, paz, za, delta, true, ra.x, ra.y, ra.z, ra.w, ex_, ey_, c_, rho_); }
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
                             jac_point(A1, R1, B1);
                             double BD[6];
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                                 for (int c = r; c < 6; ++c) acc[6 * r + c] = a_fma2(A1, c, m0, m1, acc[6 * r + c]);
                             }
-                            ra = ran; Da = Dan; Db = Dbn; Dc = Dcn; lnn = lnnn; g0 = g0n; g1 = g1n; g2 = g2n;
+                            za = zan; pax = paxn; pay = payn; paz = pazn; Da = Dan; Db = Dbn; Dc = Dcn; lnn = lnnn; g0 = g0n; g1 = g1n; g2 = g2n;
                         }
                         }
                         // 21 upper-triangle sums + the 6 right-hand-side sums, one value per lane after the butterfly
@@ -960,15 +963,20 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         {
                         int2 h = hits[min(j, jend - 1)];
                         int2 hn = hits[min(j + 64, jend - 1)];
-                        double4 ra = recA[h.x & 0xFFFF], rb = recA[(unsigned)h.x >> 16];
+                        float2 za = uvk2[h.x & 0xFFFF], zb = uvk2[(unsigned)h.x >> 16];
+                        double pax = PC(P, 0, h.y), pay = PC(P, 1, h.y), paz = PC(P, 2, h.y);
                         double2 Da, Db, Dc;
                         loadD(h.y, Da, Db, Dc);
                         for (; j < jend; j += 64) {
                             const int2 hnn = hits[min(j + 128, jend - 1)];
-                            const double4 ran = recA[hn.x & 0xFFFF], rbn = recA[(unsigned)hn.x >> 16];
+                            const float2 zan = uvk2[hn.x & 0xFFFF], zbn = uvk2[(unsigned)hn.x >> 16];
+                            const double paxn = PC(P, 0, hn.y), payn = PC(P, 1, hn.y), pazn = PC(P, 2, hn.y);
                             double2 Dan, Dbn, Dcn;
                             loadD(hn.y, Dan, Dbn, Dcn);
                             double A1[12], A2[12], B1[6], B2[6];
+                            double4 ra, rb; // both observations of the landmark, re-linearised (40 B of warm data instead of 64 B of records)
+                            { double ex_, ey_, c_, rho_; lin_record(R1, K, pax, pay, paz, za, delta, true, ra.x, ra.y, ra.z, ra.w, ex_, ey_, c_, rho_);
+                              lin_record(R2, K, pax, pay, paz, zb, delta, true, rb.x, rb.y, rb.z, rb.w, ex_, ey_, c_, rho_); }
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
                             jac_point(A1, R1, B1);
                             jac_pose(K, rb.x, rb.y, rb.z, A2);
@@ -992,7 +1000,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                                 for (int c = 0; c < 6; ++c) acc[6 * r + c] = a_fma2(A2, c, m0, m1, acc[6 * r + c]);
                             }
-                            ra = ran; rb = rbn; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
+                            za = zan; zb = zbn; pax = paxn; pay = payn; paz = pazn; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
                         }
                         }
                     }
