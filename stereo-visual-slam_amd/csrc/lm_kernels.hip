@@ -56,7 +56,7 @@ constexpr int kMaxNp = 6 * kMaxKf;
 constexpr int kMaxPairs = kMaxKf * (kMaxKf + 1) / 2;
 constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
 constexpr int kDinvLds = 2000;  // landmarks whose Dinv stays in LDS (48 B each: the 96 KB the static state leaves free)
-constexpr int kLin = 8;        // doubles per edge of linearisation scratch: two sets of {X, Y, 1/Z, w} (current state / trial state)
+constexpr int kLin = 2;        // doubles per edge of linearisation scratch: the Huber weight at the current state / at the trial state
 constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
 constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
 constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work items (keyframe pairs) per wave
@@ -265,6 +265,16 @@ __device__ inline void lin_record(const double* Rt, const double* K, double px, 
     if (with_lm) { const double Zc = Z + 1e-18; if (Zc != Z) Zi = rcp_nr(Zc); }
 }
 
+// camera-frame part of the record only (the Schur phases take the Huber weight from the evaluation pass): X, Y and the
+// reciprocal depth EdgeProjection's Jacobians use (optimization.cpp:66)
+__device__ inline void cam_point(const double* Rt, double px, double py, double pz, double& X, double& Y, double& Zi) {
+    X = Rt[0] * px + Rt[1] * py + Rt[2] * pz + Rt[9];
+    Y = Rt[3] * px + Rt[4] * py + Rt[5] * pz + Rt[10];
+    const double Z = Rt[6] * px + Rt[7] * py + Rt[8] * pz + Rt[11];
+    const double Zc = Z + 1e-18;
+    Zi = rcp_nr(Zc == Z ? Z : Zc);
+}
+
 __device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double Di[6]) {
     // symmetric [[a b c],[b d e],[c e f]] -> unique entries of the inverse (00 01 02 11 12 22)
     const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
@@ -393,8 +403,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // per-edge linearisation records, AoS so that gathers (by-pose lists, Schur hits) fetch one 32-B chunk per edge:
     // Two sets: every trial evaluation also records its state into the spare set; an accepted trial makes that set current,
     // so the next iteration starts without re-evaluating the state it already evaluated.
-    double4* recA = reinterpret_cast<double4*>(lin);                       // {X, Y, 1/Z, w}
-    double4* recA_alt = reinterpret_cast<double4*>(lin + 4 * (size_t)ne);
+    double* recW = lin;                    // Huber weight per edge, keyframe-major
+    double* recW_alt = lin + (size_t)ne;
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
 
     // ------------------------------------------------------------------ setup
@@ -657,7 +667,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         while (r.j >= r.jend && r.k + 1 < nk) { ++r.k; r.j = sm.kfp[r.k]; r.jend = sm.kfp[r.k + 1]; }
     };
     const int nrows = sm.rowp[nk], rows_per_wave = (nrows + kLmWaves - 1) / kLmWaves;
-    auto eval = [&](const double* Rt, const double* Pcur, double4* dstA, double* Hdst, double* bdst) -> double {
+    auto eval = [&](const double* Rt, const double* Pcur, double* dstW, double* Hdst, double* bdst) -> double {
         double part = 0;
         const long long t_ev = cyc ? clock64() : 0;
         const int ra = min(wave * rows_per_wave, nrows), rb = min(ra + rows_per_wave, nrows);
@@ -722,6 +732,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
                     lin_record(Rk, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
                     part += rho;
+                    if (with_lm) dstW[j] = wgt; // the Schur passes re-derive X, Y, 1/Z from the landmark; only the weight is kept
                     jac_pose(K, X, Y, Zi, A);
 #pragma unroll
                     for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
@@ -892,21 +903,21 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         double accb[6] = {0, 0, 0, 0, 0, 0}; // this keyframe's share of W Dinv b_l (reduced right-hand side)
                         if (jbeg < jend) { // (an empty list has no valid record to prefetch)
                         int ln = kf_lm[min(j, jend - 1)], lnn = kf_lm[min(j + 64, jend - 1)];
-                        float2 za = uvk2[min(j, jend - 1)];
+                        double wa = recW[min(j, jend - 1)];
                         double pax = PC(P, 0, ln), pay = PC(P, 1, ln), paz = PC(P, 2, ln);
                         double2 Da, Db, Dc;
                         loadD(ln, Da, Db, Dc);
                         double g0 = PC(bl, 0, ln), g1 = PC(bl, 1, ln), g2 = PC(bl, 2, ln);
                         for (; j < jend; j += 64) {
                             const int lnnn = kf_lm[min(j + 128, jend - 1)];
-                            const float2 zan = uvk2[min(j + 64, jend - 1)];
+                            const double wan = recW[min(j + 64, jend - 1)];
                             const double paxn = PC(P, 0, lnn), payn = PC(P, 1, lnn), pazn = PC(P, 2, lnn);
                             double2 Dan, Dbn, Dcn;
                             loadD(lnn, Dan, Dbn, Dcn);
                             const double g0n = PC(bl, 0, lnn), g1n = PC(bl, 1, lnn), g2n = PC(bl, 2, lnn);
                             double A1[12], B1[6];
-                            double4 ra; // the linearisation record {X, Y, 1/Z, w}, recomputed from the landmark and the observation
-                            { double ex_, ey_, c_, rho_; lin_record(R1, K, pax, pay, paz, za, delta, true, ra.x, ra.y, ra.z, ra.w, ex_, ey_, c_, rho_); }
+                            double4 ra; // the linearisation record {X, Y, 1/Z, w}: camera-frame part recomputed from the landmark
+                            cam_point(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
                             jac_point(A1, R1, B1);
                             double BD[6];
@@ -931,7 +942,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                                 for (int c = r; c < 6; ++c) acc[6 * r + c] = a_fma2(A1, c, m0, m1, acc[6 * r + c]);
                             }
-                            za = zan; pax = paxn; pay = payn; paz = pazn; Da = Dan; Db = Dbn; Dc = Dcn; lnn = lnnn; g0 = g0n; g1 = g1n; g2 = g2n;
+                            wa = wan; pax = paxn; pay = payn; paz = pazn; Da = Dan; Db = Dbn; Dc = Dcn; lnn = lnnn; g0 = g0n; g1 = g1n; g2 = g2n;
                         }
                         }
                         // 21 upper-triangle sums + the 6 right-hand-side sums, one value per lane after the butterfly
@@ -963,20 +974,20 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         {
                         int2 h = hits[min(j, jend - 1)];
                         int2 hn = hits[min(j + 64, jend - 1)];
-                        float2 za = uvk2[h.x & 0xFFFF], zb = uvk2[(unsigned)h.x >> 16];
+                        double wa = recW[h.x & 0xFFFF], wb = recW[(unsigned)h.x >> 16];
                         double pax = PC(P, 0, h.y), pay = PC(P, 1, h.y), paz = PC(P, 2, h.y);
                         double2 Da, Db, Dc;
                         loadD(h.y, Da, Db, Dc);
                         for (; j < jend; j += 64) {
                             const int2 hnn = hits[min(j + 128, jend - 1)];
-                            const float2 zan = uvk2[hn.x & 0xFFFF], zbn = uvk2[(unsigned)hn.x >> 16];
+                            const double wan = recW[hn.x & 0xFFFF], wbn = recW[(unsigned)hn.x >> 16];
                             const double paxn = PC(P, 0, hn.y), payn = PC(P, 1, hn.y), pazn = PC(P, 2, hn.y);
                             double2 Dan, Dbn, Dcn;
                             loadD(hn.y, Dan, Dbn, Dcn);
                             double A1[12], A2[12], B1[6], B2[6];
-                            double4 ra, rb; // both observations of the landmark, re-linearised (40 B of warm data instead of 64 B of records)
-                            { double ex_, ey_, c_, rho_; lin_record(R1, K, pax, pay, paz, za, delta, true, ra.x, ra.y, ra.z, ra.w, ex_, ey_, c_, rho_);
-                              lin_record(R2, K, pax, pay, paz, zb, delta, true, rb.x, rb.y, rb.z, rb.w, ex_, ey_, c_, rho_); }
+                            double4 ra, rb; // both observations of the landmark: 24 B of landmark + two weights instead of 64 B of records
+                            cam_point(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
+                            cam_point(R2, pax, pay, paz, rb.x, rb.y, rb.z); rb.w = wb;
                             jac_pose(K, ra.x, ra.y, ra.z, A1);
                             jac_point(A1, R1, B1);
                             jac_pose(K, rb.x, rb.y, rb.z, A2);
@@ -1000,7 +1011,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                                 for (int c = 0; c < 6; ++c) acc[6 * r + c] = a_fma2(A2, c, m0, m1, acc[6 * r + c]);
                             }
-                            za = zan; zb = zbn; pax = paxn; pay = payn; paz = pazn; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
+                            wa = wan; wb = wbn; pax = paxn; pay = payn; paz = pazn; Da = Dan; Db = Dbn; Dc = Dcn; hn = hnn;
                         }
                         }
                     }
@@ -1226,7 +1237,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             scale = block_sum(scale_part, sm.red) + 1e-3;
             } // !boot
             PH(9);
-            double tempChi = eval(boot ? sm.Rt : sm.RtTrial, (boot || !with_lm) ? P : Pt, boot ? recA : recA_alt, boot ? sm.Hpp : sm.HppT, boot ? sm.bp : sm.bpT);
+            double tempChi = eval(boot ? sm.Rt : sm.RtTrial, (boot || !with_lm) ? P : Pt, boot ? recW : recW_alt, boot ? sm.Hpp : sm.HppT, boot ? sm.bp : sm.bpT);
             if (boot) { currentChi = tempChi; break; }
             last_trial_is_current = false;
             PH(10);
@@ -1243,7 +1254,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = sm.TTrial[i];
                 for (int i = tid; i < nk * 12; i += kLmBlock) sm.Rt[i] = sm.RtTrial[i];
                 if (with_lm) { double* t = P; P = Pt; Pt = t; }
-                { double4* ta = recA; recA = recA_alt; recA_alt = ta; last_trial_is_current = true; }
+                { double* ta = recW; recW = recW_alt; recW_alt = ta; last_trial_is_current = true; }
                 for (int i = tid; i < nk * 36; i += kLmBlock) sm.Hpp[i] = sm.HppT[i];
                 for (int i = tid; i < np; i += kLmBlock) sm.bp[i] = sm.bpT[i];
                 __syncthreads();
