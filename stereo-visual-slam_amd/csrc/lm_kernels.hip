@@ -804,6 +804,15 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         const bool boot = it < 0;
         PH(1);
         if (it == 0 && st && tid == 0) st->chi2_init = currentChi;
+        // ---- trial loop.  Every trial starts with the landmark pass (blocks H_ll, b_l and, once lambda is known, D^-1 straight
+        // from the registers): H_ll is never stored except on the very first trial, whose lambda comes out of the pass itself.
+        // A rejected trial therefore repeats the pass with the new lambda instead of re-reading 48 B per landmark -- rejections
+        // are rare, the 144 KB of H_ll per iteration were 40 % of the kernel's write traffic.
+        double rho_gain = 0;
+        int qmax = 0;
+        bool again = true;
+        while (again) {
+        const bool lam_known = it > 0 || qmax > 0;
         // ---- buildSystem: landmark blocks
         double maxdiag = 0;
         if (with_lm && !boot) {
@@ -840,12 +849,14 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                     for (int q = 0; q < kLmE; ++q) if (b0[u] + q < b1[u]) add_edge(kk[u][q], zz[u][q]);
                     for (int e = b0[u] + kLmE; e < b1[u]; ++e) add_edge(kfi[e], uv2[e]); // rare: more than kLmE observations
+                    if (!lam_known) {
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) PC(Hll, i, l) = h[i];
+                        for (int i = 0; i < 6; ++i) PC(Hll, i, l) = h[i];
+                    }
 #pragma unroll
                     for (int i = 0; i < 3; ++i) PC(bl, i, l) = g[i];
                     maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
-                    if (it > 0) { // lambda of the first trial is already known: invert here and skip that trial's pass over Hll
+                    if (lam_known) { // invert here: no pass over stored blocks
                         double Di[6];
                         if (!inv3_sym(h[0] + lambda, h[1], h[2], h[3] + lambda, h[4], h[5] + lambda, Di)) sm.flag[1] = 1;
                         storeD(l, Di);
@@ -855,22 +866,18 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         }
         PH(2);
         PH(3);
-        if (it == 0) { // computeLambdaInit: tau * max |H_jj| over every vertex
+        if (it == 0 && qmax == 0) { // computeLambdaInit: tau * max |H_jj| over every vertex
             if (tid < np) maxdiag = fmax(maxdiag, fabs(sm.Hpp[36 * (tid / 6) + 7 * (tid % 6)]));
             lambda = 1e-5 * block_max(maxdiag, sm.red);
             ni = 2;
         }
-        // ---- trial loop
-        double rho_gain = 0;
-        int qmax = 0;
-        bool again = true;
-        while (again) {
+        {
             bool ok2 = true;
             double scale = 1.0;
             if (!boot) {
             if (with_lm) {
-                // Dinv = (Hll + lambda I)^-1 per landmark (the first trial of iterations > 0 got it from the landmark-block pass)
-                if (it == 0 || qmax > 0) {
+                // Dinv = (Hll + lambda I)^-1 per landmark on the first trial of a call (every other trial got it from the landmark pass)
+                if (!lam_known) {
                     int bad = 0;
                     for (int l = tid; l < nl; l += kLmBlock) {
                         if (!act[l]) continue;
@@ -1265,6 +1272,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             ++qmax;
             again = (rho_gain < 0) && qmax < 10;
         }
+        } // trials
         if (boot) continue;
         total_trials += qmax;
         if (st && tid == 0 && it < VSLAM_LM_MAX_ITERS) { st->chi2_iter[it] = currentChi; st->lambda_iter[it] = lambda; st->trials_iter[it] = qmax; }
