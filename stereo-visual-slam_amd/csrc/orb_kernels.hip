@@ -1153,7 +1153,13 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(BlurTable T, const uint8_
                                                       const uint8_t* __restrict__ d_pyr, size_t pyr_bytes, uint8_t* __restrict__ d_blur,
                                                       size_t blur_bytes) {
     const int b = blockIdx.y;
-    int tile = blockIdx.x, l = 0;
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2: with the tile index as the fast
+    // grid index, the two tiles that share a 128-B line (and the four that share a halo) always sat on different L2s and each
+    // fetched the line from memory.  The grid is padded to a multiple of 8 and XCD x walks the contiguous tile range
+    // [x * chunk, (x + 1) * chunk) of every image, so neighbours meet in one L2 a few workgroups apart.
+    const int chunk = gridDim.x >> 3;
+    int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3), l = 0;
+    if (tile >= T.tile_off[kNLevels]) return;
 #pragma unroll
     for (int k = 1; k < kNLevels; ++k) if (tile >= T.tile_off[k]) l = k;
     tile -= T.tile_off[l];
@@ -1212,7 +1218,7 @@ int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes
     BlurTable T;
     fill_blur_table(plan, &T);
     ProfScope prof__(stream, "orb_blur_kernel");
-    hipLaunchKernelGGL(orb_blur_kernel, dim3(T.tile_off[kNLevels], B), dim3(256), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(8 * ((T.tile_off[kNLevels] + 7) / 8), B), dim3(256), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
                        (size_t)plan.pyr_bytes, d_blur, (size_t)plan.blur_bytes);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
