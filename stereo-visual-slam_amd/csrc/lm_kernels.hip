@@ -13,7 +13,7 @@
 // windows fills the 256 CUs).  All sums are f64 with a FIXED order (no floating-point atomics):
 //   - evaluation + linearisation                : one keyframe-major pass per state: the edge lists are cut into 64-edge rows,
 //                                                 every wave streams a contiguous range of rows through register queues,
-//                                                 writes the 32-B records {X, Y, 1/Z, w} and accumulates Hpp, b_p on the fly;
+//                                                 keeps the Huber weight of every edge and accumulates Hpp, b_p on the fly;
 //                                                 trial states are linearised speculatively into spare buffers, so an
 //                                                 accepted trial needs no re-evaluation (one call site: the initial state goes
 //                                                 through the same code as a pseudo-iteration)
@@ -21,7 +21,8 @@
 //                                                 landmark position and the observations (batched loads), not gathered;
 //                                                 Dinv of the first kDinvLds landmarks stays in LDS
 //   - Schur blocks S[k1][k2]                    : one wave per keyframe pair, dealt by work; off-diagonal pairs walk a
-//                                                 precomputed 8-B hit list, diagonal pairs stream the keyframe's own list and
+//                                                 precomputed 8-B hit list (landmark + two weights per hit, the camera-frame points
+//                                                 are re-derived), diagonal pairs stream the keyframe's own list and
 //                                                 also produce the reduced right-hand side; single owner per block
 //   - wave reductions                           : halving butterfly (N sums cost ~N shuffles and end one per lane)
 //   - reduced system                            : blocked left-looking Cholesky in LDS, the right-hand side rides along as an extra
@@ -29,7 +30,8 @@
 //                                                 in the lanes of one wave (readlane + FMA per unknown)
 // Landmarks and pixels are f32 at rest (quirk Q4); poses, accumulators and the LM state are f64.
 // No MFMA: the largest dense object is the 72x72 reduced system (and f64 MFMA has the vector rate on gfx950).  Bound: f64 VALU
-// issue at two waves per SIMD (256 VGPRs: the Schur accumulators) plus the serial reduced-system phases; machine facts used
+// issue at two waves per SIMD (256 VGPRs: the Schur accumulators), the serial reduced-system phases and, first of all, the bytes
+// streamed per iteration (256 windows x 1.5 MB do not fit the Infinity Cache; see DESIGN.md for the calibrated counters); machine facts used
 // below (tools/scratch/lat.hip): one wave issues a VALU op per 8 cycles, a dependent f64 FMA takes 8, an LDS round trip ~60, a
 // barrier of 8 waves ~210, and loops with run-time trip counts are NOT software-pipelined by the compiler -- every hot loop
 // here fetches the operands of several iterations before the first use.  See DESIGN.md section 5 for the phase split.
@@ -399,10 +401,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + 16 * (size_t)w : nullptr;
     long long t_ph = cyc ? clock64() : 0;
 #define PH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); cyc[i] += t1__ - t_ph; t_ph = t1__; } } while (0)
-    // component-major (SoA) scratch: consecutive lanes touch consecutive addresses in every edge- or landmark-ordered loop
-    // per-edge linearisation records, AoS so that gathers (by-pose lists, Schur hits) fetch one 32-B chunk per edge:
-    // Two sets: every trial evaluation also records its state into the spare set; an accepted trial makes that set current,
-    // so the next iteration starts without re-evaluating the state it already evaluated.
+    // component-major (SoA) scratch: consecutive lanes touch consecutive addresses in every edge- or landmark-ordered loop.
+    // The only per-edge linearisation state that is STORED is the Huber weight (8 B, keyframe-major): the camera-frame point
+    // is re-derived from the landmark wherever it is needed -- the kernel is bound by the bytes it streams, and a stored 32-B
+    // record {X, Y, 1/Z, w} was read ~3.5 times per iteration.  Two sets: a trial evaluation records its weights into the
+    // spare set; an accepted trial makes that set current, so the next iteration needs no re-evaluation.
     double* recW = lin;                    // Huber weight per edge, keyframe-major
     double* recW_alt = lin + (size_t)ne;
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
@@ -480,9 +483,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     __syncthreads();
     if (!IMPL) {
         PH(13);
-        // ---- keyframe-major positions (ascending edge id inside a pose).  The per-edge linearisation records are STORED in this
-        // order: pose-wise phases stream them, Schur hits of a keyframe pair read two nearly contiguous runs, and landmark-wise
-        // phases stay coalesced because neighbouring landmarks (creation order) sit at neighbouring positions of the same pose.
+        // ---- keyframe-major positions (ascending edge id inside a pose).  The per-edge weights, observations and landmark ids are
+        // stored in this order: pose-wise phases stream them, Schur hits of a keyframe pair read two nearly contiguous runs, and
+        // landmark-wise phases stay coalesced because neighbouring landmarks (creation order) sit at neighbouring positions.
         // Every wave owns a contiguous edge range, loads it once per pass and ranks its edges per keyframe with ballots.
         const int e_lo = (int)((long long)ne * wave / kLmWaves), e_hi = (int)((long long)ne * (wave + 1) / kLmWaves);
         for (int pass = 0; pass < 2; ++pass) {
@@ -644,7 +647,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     int it = 0, total_trials = 0;
     vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
 
-    // error evaluation at (Rt, Pcur); store_lin also records the linearisation point (X, Y, 1/Z, w, e, B)
     // Every phase below is a chain of dependent gathers out of a per-window working set that lives in HBM (1.5 MB x
     // hundreds of windows), so each loop is written as batches: all loads of one dependency level for kEvalU items first,
     // then the arithmetic -- the per-thread summation order is unchanged.
@@ -654,8 +656,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // Evaluation + linearisation at (Rt, Pcur) in one keyframe-major pass.  The keyframe-major edge lists are cut into rows
     // of 64 edges (a row never straddles two keyframes); every wave owns a contiguous range of rows and streams it through
     // a register queue (landmark ids and observations four rows ahead, landmark positions two rows ahead: the lists come from
-    // HBM / Infinity Cache at ~1 us per dependent access, a row is ~0.5 us of arithmetic).  It writes the records
-    // {X, Y, 1/Z, w} for the Schur phase and accumulates the pose blocks (H_pp upper triangle, b_p) on the fly, so the errors
+    // HBM / Infinity Cache at ~1 us per dependent access, a row is ~0.5 us of arithmetic).  It writes the Huber
+    // weight of every edge for the Schur phase and accumulates the pose blocks (H_pp upper triangle, b_p) on the fly, so the errors
     // never have to be stored; when the keyframe changes the 27 sums are folded (butterfly) into slot (keyframe + wave) --
     // unique, because the waves' row ranges are ordered like the keyframes.  Returns the robust chi2.  Trial states go
     // through the same pass into the spare buffers: an accepted trial is already linearised.
@@ -903,8 +905,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                     for (int i = 0; i < 36; ++i) acc[i] = 0;
                     if (k1 == k2) { // every edge of keyframe k1 pairs with itself: one Jacobian, symmetric 2x2 core, upper triangle only
-                        // software-pipelined: the next hit's records are requested before the current hit is consumed
-                        // streams the keyframe's own records (j) with the landmark ids two steps and Dinv / b_l one step ahead
+                        // software-pipelined: streams the keyframe's own list (j) with the landmark ids two steps and the weight, the
+                        // landmark, Dinv and b_l one step ahead
                         const int jbeg = kf_ptr[k1], jend = kf_ptr[k1 + 1];
                         int j = jbeg + lane;
                         double accb[6] = {0, 0, 0, 0, 0, 0}; // this keyframe's share of W Dinv b_l (reduced right-hand side)

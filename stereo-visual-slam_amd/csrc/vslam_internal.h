@@ -158,10 +158,10 @@ struct LmWindowArgs {
     // scratch (sized by total_lm / total_edge)
     double* P;      // total_lm x 3   current landmark estimates
     double* Ptrial; // total_lm x 3
-    double* Hll;    // total_lm x 6
+    double* Hll;    // total_lm x 6 (only the first trial of a call stores it: its lambda comes out of the same pass)
     double* bl;     // total_lm x 3
     double* Dinv;   // total_lm x 6
-    double* lin;    // total_edge x 8 : two sets of {X, Y, 1/Z, w} records (current / trial state), keyframe-major
+    double* lin;    // total_edge x 2 : Huber weight per edge at the current / at the trial state, keyframe-major
     int32_t* lm_ptr;   // total_lm + n_windows (CSR by landmark, window-local edge ids, built in-kernel)
     int32_t* kf_ptr;   // n_windows x (MAX_KF + 1)
     int32_t* kf_edges; // total_edge: landmark id of the edge stored at keyframe-major position j
