@@ -66,6 +66,9 @@ typedef struct vslam_params {
     double match_gap_thr;          /* 30.0      visual_odometry.cpp:242                             */
     double huber_delta;            /* 5.991     optimization.cpp:154,205                            */
     double pnp_reproj_thr;         /* 4.0 px    visual_odometry.cpp:277                             */
+    double stereo_row_tol;         /* 2.0 px    epipolar gate of the L/R-match depth stage (vslam_triangulate*): a pair is kept
+                                      only if |vL - vR| <= tol and uL > uR; < 0 = off.  No counterpart in the reference, whose
+                                      depth is SGBM (row-constrained by construction, visual_odometry.cpp:159-174)         */
 } vslam_params;
 
 typedef struct vslam_lm_stats {
@@ -199,9 +202,11 @@ int vslam_check_motion(int num_inliers, const double T_c_l[7], double frame_gap)
  * edges {kf_idx, lm_idx, uv}; any edge order.  g2o LM + Schur + Huber(huber_delta), `iters` iterations.
  * flag_lm[e]: landmark whose is_inlier flag edge e writes (reference: feat.landmark_id_, :258-264; quirk Q1),
  * or NULL for flag_lm = lm_idx.  lm_inlier: n_lm flags, in/out (:224-266, edges visited in ascending index).
- * update_poses / update_lms: if_update_map / if_update_landmark (:272-287).  chi2_out (n_edge) optional. */
+ * update_poses / update_lms: if_update_map / if_update_landmark (:272-287).  chi2_out (n_edge) optional.
+ * K4 = {fx, fy, cx, cy}: the `const cv::Mat& K` argument of optimize_map / optimize_pose_only (optimization.hpp:137-139,
+ * :150-152), passed per call; NULL = the context's intrinsics (vslam_params.cam). */
 int vslam_local_ba(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, float* xyz, int n_edge,
-                   const int32_t* kf_idx, const int32_t* lm_idx, const float* uv, const int32_t* flag_lm,
+                   const int32_t* kf_idx, const int32_t* lm_idx, const float* uv, const double* K4, const int32_t* flag_lm,
                    int iters, int update_poses, int update_lms, uint8_t* lm_inlier, double* chi2_out,
                    double* chi2_threshold_out, vslam_lm_stats* stats);
 
@@ -209,7 +214,7 @@ int vslam_local_ba(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, float* xyz
 /* Replaces optimize_pose_only (optimization.cpp:290-436): unary PoseOnlyEdgeProjection edges, landmarks constant,
  * dense per-pose solve with one shared lambda, same chi2 classification, pose write-back (:429-435). */
 int vslam_pose_only_window(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, const float* xyz, int n_edge,
-                           const int32_t* kf_idx, const int32_t* lm_idx, const float* uv, const int32_t* flag_lm,
+                           const int32_t* kf_idx, const int32_t* lm_idx, const float* uv, const double* K4, const int32_t* flag_lm,
                            int iters, int update_poses, uint8_t* lm_inlier, double* chi2_out,
                            double* chi2_threshold_out, vslam_lm_stats* stats);
 
@@ -234,6 +239,7 @@ typedef struct vslam_ba_batch {
     double* d_chi2;               /* total_edge, out (last pass), caller's edge order; NULL = not wanted */
     vslam_lm_stats* d_stats;      /* n_windows (last pass) or NULL */
     int32_t total_lm, total_edge;
+    const double* K4;             /* HOST pointer to {fx, fy, cx, cy} (the optimisers' `const cv::Mat& K`), NULL = context intrinsics */
 } vslam_ba_batch;
 int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* batch, int schedule, int mode, int iters,
                        int update_poses, int update_lms);

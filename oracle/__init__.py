@@ -275,11 +275,11 @@ def find_3d_disparity(kps, disparity, T_c_w, cam=CAM_KITTI):
     return xyz, valid, rel
 
 
-def triangulate_dlt(uvL, uvR, T_c_w, cam=CAM_KITTI):
+def triangulate_dlt(uvL, uvR, T_c_w, cam=CAM_KITTI, row_tol=2.0):
     uvL = np.ascontiguousarray(uvL, np.float32).reshape(-1, 2); uvR = np.ascontiguousarray(uvR, np.float32).reshape(-1, 2)
     n = len(uvL)
     xyz = np.zeros((n, 3), np.float32); valid = np.zeros(n, np.uint8); rel = np.zeros(n, np.uint8)
-    lib().vo_triangulate_dlt(_p(uvL), _p(uvR), n, _p(_d(T_c_w, 7)), _p(_d(cam, 5)), _p(xyz), _p(valid), _p(rel))
+    lib().vo_triangulate_dlt(_p(uvL), _p(uvR), n, _p(_d(T_c_w, 7)), _p(_d(cam, 5)), C.c_double(row_tol), _p(xyz), _p(valid), _p(rel))
     return xyz, valid, rel
 
 

@@ -172,7 +172,7 @@ int vo_find_3d_disparity(const vo_keypoint* kps, int n, const float* disparity, 
     return nvalid;
 }
 
-int vo_triangulate_dlt(const float* uvL, const float* uvR, int n, const double T_c_w[7], const double cam[5],
+int vo_triangulate_dlt(const float* uvL, const float* uvR, int n, const double T_c_w[7], const double cam[5], double row_tol,
                        float* xyz_w, uint8_t* valid, uint8_t* reliable) {
     const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3], b = cam[4];
     int nvalid = 0;
@@ -197,6 +197,10 @@ int vo_triangulate_dlt(const float* uvL, const float* uvR, int n, const double T
         double Y = (r1 - n12 * Z) / n11;
         double rel[3] = {X, Y, Z};
         if (!(s22 > 0) || !isfinite(Z)) { rel[0] = rel[1] = 0; rel[2] = -1; }
+        /* epipolar gate of a rectified pair: same row within row_tol px, positive disparity (row_tol < 0: off).  The reference has
+         * no descriptor-matched stereo stage (its depth is SGBM, which searches along the row by construction); a cross-checked
+         * L/R descriptor match has no such constraint built in, so the stage that replaces SGBM applies it explicitly. */
+        if (row_tol >= 0 && (!(fabs((double)uvL[2 * i + 1] - (double)uvR[2 * i + 1]) <= row_tol) || !(uvL[2 * i] > uvR[2 * i]))) { rel[0] = rel[1] = 0; rel[2] = -1; }
         gate_and_store(rel, T_c_w, i, xyz_w, valid, reliable, &nvalid);
     }
     return nvalid;

@@ -152,8 +152,9 @@ int vo_find_3d_disparity(const vo_keypoint* kps, int n, const float* disparity, 
                          float* xyz_w, uint8_t* valid, uint8_t* reliable);
 
 /* north_star stage K8: rectified-stereo inhomogeneous DLT (4 equations, 3 unknowns, normal equations)
- * on matched (uL,vL),(uR,vR), then the same gates/outputs as set_ref_3d_position. */
-int vo_triangulate_dlt(const float* uvL, const float* uvR, int n, const double T_c_w[7], const double cam[5],
+ * on matched (uL,vL),(uR,vR), then the same gates/outputs as set_ref_3d_position.  row_tol: epipolar gate
+ * |vL - vR| <= row_tol and uL > uR (rectified pair); < 0 disables it. */
+int vo_triangulate_dlt(const float* uvL, const float* uvR, int n, const double T_c_w[7], const double cam[5], double row_tol,
                        float* xyz_w, uint8_t* valid, uint8_t* reliable);
 
 /* VO::check_motion_estimation (visual_odometry.cpp:316-346) */

@@ -30,7 +30,7 @@ class Params(C.Structure):
                 ("anms_num", C.c_int32), ("fast_threshold", C.c_int32), ("kp_capacity", C.c_int32),
                 ("cam", C.c_double * 5), ("depth_min", C.c_double), ("depth_max", C.c_double),
                 ("depth_reliable", C.c_double), ("match_ratio", C.c_double), ("match_gap_thr", C.c_double),
-                ("huber_delta", C.c_double), ("pnp_reproj_thr", C.c_double)]
+                ("huber_delta", C.c_double), ("pnp_reproj_thr", C.c_double), ("stereo_row_tol", C.c_double)]
 
 
 class LmStats(C.Structure):
@@ -49,7 +49,7 @@ class BaBatch(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("n_kf", C.c_int32), ("d_lm_off", C.c_void_p), ("d_edge_off", C.c_void_p),
                 ("d_T_c_w", C.c_void_p), ("d_xyz", C.c_void_p), ("d_reliable", C.c_void_p), ("d_lm_inlier", C.c_void_p),
                 ("d_kf_idx", C.c_void_p), ("d_lm_idx", C.c_void_p), ("d_uv", C.c_void_p), ("d_chi2", C.c_void_p),
-                ("d_stats", C.c_void_p), ("total_lm", C.c_int32), ("total_edge", C.c_int32)]
+                ("d_stats", C.c_void_p), ("total_lm", C.c_int32), ("total_edge", C.c_int32), ("K4", C.c_void_p)]
 
 
 # every symbol include/vslam_hip.h declares (checked by tests/test_abi.py)
@@ -315,31 +315,32 @@ class VO:
         return bool(self.lib.vslam_check_motion(int(num_inliers), _p(T), C.c_double(frame_gap)))
 
     # ------------------------------------------------------------ optimize_map / optimize_pose_only (optimization.cpp)
-    def _window(self, fn, name, T, xyz, kf_idx, lm_idx, uv, flag_lm, iters, update_poses, update_lms, lm_inlier, with_lms):
+    def _window(self, fn, name, T, xyz, kf_idx, lm_idx, uv, flag_lm, iters, update_poses, update_lms, lm_inlier, with_lms, K=None):
         T = np.ascontiguousarray(T, np.float64).reshape(-1, 7).copy()
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3).copy()
         kf_idx = np.ascontiguousarray(kf_idx, np.int32); lm_idx = np.ascontiguousarray(lm_idx, np.int32)
         uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
         fl = None if flag_lm is None else np.ascontiguousarray(flag_lm, np.int32)
+        K4 = None if K is None else np.ascontiguousarray(K, np.float64).reshape(4)  # {fx, fy, cx, cy}; None = context intrinsics
         inl = np.ones(len(xyz), np.uint8) if lm_inlier is None else np.ascontiguousarray(lm_inlier, np.uint8).copy()
         chi2 = np.zeros(len(kf_idx)); thr = C.c_double(); st = LmStats()
         if with_lms:
-            rc = fn(self.h, len(T), _p(T), len(xyz), _p(xyz), len(kf_idx), _p(kf_idx), _p(lm_idx), _p(uv), _p(fl), int(iters),
+            rc = fn(self.h, len(T), _p(T), len(xyz), _p(xyz), len(kf_idx), _p(kf_idx), _p(lm_idx), _p(uv), _p(K4), _p(fl), int(iters),
                     int(update_poses), int(update_lms), _p(inl), _p(chi2), C.byref(thr), C.byref(st))
         else:
-            rc = fn(self.h, len(T), _p(T), len(xyz), _p(xyz), len(kf_idx), _p(kf_idx), _p(lm_idx), _p(uv), _p(fl), int(iters),
+            rc = fn(self.h, len(T), _p(T), len(xyz), _p(xyz), len(kf_idx), _p(kf_idx), _p(lm_idx), _p(uv), _p(K4), _p(fl), int(iters),
                     int(update_poses), _p(inl), _p(chi2), C.byref(thr), C.byref(st))
         self._chk(rc, name)
         return dict(T=T, xyz=xyz, chi2=chi2, threshold=thr.value, lm_inlier=inl, stats=st.as_dict())
 
     def optimize_map(self, T, xyz, kf_idx, lm_idx, uv, if_update_map=True, if_update_landmark=False, num_ite=10, flag_lm=None,
-                     lm_inlier=None):
+                     lm_inlier=None, K=None):
         return self._window(self.lib.vslam_local_ba, "vslam_local_ba", T, xyz, kf_idx, lm_idx, uv, flag_lm, num_ite, if_update_map,
-                            if_update_landmark, lm_inlier, True)
+                            if_update_landmark, lm_inlier, True, K)
 
-    def optimize_pose_only(self, T, xyz, kf_idx, lm_idx, uv, if_update_map=True, num_ite=10, flag_lm=None, lm_inlier=None):
+    def optimize_pose_only(self, T, xyz, kf_idx, lm_idx, uv, if_update_map=True, num_ite=10, flag_lm=None, lm_inlier=None, K=None):
         return self._window(self.lib.vslam_pose_only_window, "vslam_pose_only_window", T, xyz, kf_idx, lm_idx, uv, flag_lm, num_ite,
-                            if_update_map, False, lm_inlier, False)
+                            if_update_map, False, lm_inlier, False, K)
 
     def ba_batch_dev(self, batch, schedule=1, mode=0, iters=10, update_poses=1, update_lms=0):
         self._chk(self.lib.vslam_ba_batch_dev(self.h, C.byref(batch), int(schedule), int(mode), int(iters), int(update_poses),

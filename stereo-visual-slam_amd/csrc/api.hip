@@ -55,7 +55,12 @@ void prof_end(hipStream_t s) {
     (void)hipEventRecord(r.e1, s);
     p->recs.push_back(r);
 }
-static Prof* g_ctx_prof_table[64] = {nullptr};
+// every entry point makes its context's device current and routes the stage profiler to that context's recorder
+#define VS_ENTER(c)                                                                         \
+    do {                                                                                    \
+        VS_HIP(hipSetDevice((c)->device));                                                  \
+        prof_set_current(((c)->prof && (c)->prof->on) ? (c)->prof : nullptr);               \
+    } while (0)
 
 // simple bump arena over one growable device allocation (host-buffer API only)
 struct Arena {
@@ -84,7 +89,7 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static CamParams cam_of(const Ctx* c) {
     CamParams cam;
     cam.fx = c->p.cam[0]; cam.fy = c->p.cam[1]; cam.cx = c->p.cam[2]; cam.cy = c->p.cam[3]; cam.b = c->p.cam[4];
-    cam.dmin = c->p.depth_min; cam.dmax = c->p.depth_max; cam.drel = c->p.depth_reliable;
+    cam.dmin = c->p.depth_min; cam.dmax = c->p.depth_max; cam.drel = c->p.depth_reliable; cam.row_tol = c->p.stereo_row_tol;
     return cam;
 }
 
@@ -145,7 +150,7 @@ void vslam_default_params(vslam_params* p) {
     p->orb_nfeatures = 3000; p->anms_num = 500; p->fast_threshold = 20; p->kp_capacity = 4096;
     p->cam[0] = 718.856; p->cam[1] = 718.856; p->cam[2] = 607.1928; p->cam[3] = 185.2157; p->cam[4] = 0.573;
     p->depth_min = 10; p->depth_max = 400; p->depth_reliable = 40;
-    p->match_ratio = 2.0; p->match_gap_thr = 30.0; p->huber_delta = 5.991; p->pnp_reproj_thr = 4.0;
+    p->match_ratio = 2.0; p->match_gap_thr = 30.0; p->huber_delta = 5.991; p->pnp_reproj_thr = 4.0; p->stereo_row_tol = 2.0;
 }
 
 const char* vslam_last_error(void) { return g_err; }
@@ -204,6 +209,12 @@ void vslam_destroy(vslam_ctx* ctx) {
     void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs,
                     c->match.d_train_best, c->match.d_q8, c->match.d_t8, c->d_stage};
     for (void* q : ptrs) if (q) hipFree(q);
+    if (c->prof) {
+        if (prof_current() == c->prof) prof_set_current(nullptr);
+        for (Prof::Rec& r : c->prof->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        for (hipEvent_t e : c->prof->pool) hipEventDestroy(e);
+        delete c->prof;
+    }
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -211,6 +222,7 @@ void vslam_destroy(vslam_ctx* ctx) {
 int vslam_sync(vslam_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return VSLAM_ERR_ARG;
+    VS_ENTER(c);
     VS_HIP(hipStreamSynchronize(c->stream));
     return VSLAM_OK;
 }
@@ -249,7 +261,7 @@ static int orb_host_call(vslam_ctx* ctx, const uint8_t* img, int w, int h, int s
     int rc = check_img(c, img, w, h, stride);
     if (rc) return rc;
     if (!kps || !n_out || cap <= 0 || (describe && !desc)) { set_error("null output"); return VSLAM_ERR_ARG; }
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     const int kc = c->p.kp_capacity;
     const size_t pitch = (w + 63) & ~63;
     if ((rc = arena_reserve(c, al256(pitch * h) + al256(sizeof(vslam_keypoint) * kc) + al256((size_t)kc * 32) + 1024))) return rc;
@@ -286,7 +298,7 @@ int vslam_anms(vslam_ctx* ctx, vslam_keypoint* kps, int n, int num, int* n_out) 
     if (!c || !kps || !n_out || n < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if (n > kMaxRows) { set_error("ANMS input %d > %d", n, kMaxRows); return VSLAM_ERR_CAPACITY; }
     if (n == 0) { *n_out = 0; return VSLAM_OK; }
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     int rc;
     if ((rc = arena_reserve(c, 2 * al256(sizeof(vslam_keypoint) * kMaxRows) + 1024))) return rc;
     Arena ar(c);
@@ -316,7 +328,7 @@ int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stri
     if (n == 0) { *n_out = 0; return VSLAM_OK; }
     for (int i = 0; i < n; ++i)
         if (kps[i].octave < 0 || kps[i].octave >= kNLevels) { set_error("keypoint %d: octave %d out of range", i, kps[i].octave); return VSLAM_ERR_ARG; }
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     const int kc = c->p.kp_capacity;
     const size_t pitch = (w + 63) & ~63;
     if ((rc = arena_reserve(c, al256(pitch * h) + 2 * al256(sizeof(vslam_keypoint) * kc) + al256((size_t)kc * 32) + 1024))) return rc;
@@ -349,12 +361,14 @@ int vslam_feature_detection_dev(vslam_ctx* ctx, const uint8_t* d_imgs, size_t im
                                 uint8_t* d_desc, int32_t* d_count) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_imgs || !d_kps || !d_desc || !d_count || pitch < c->p.img_w || img_bytes < (size_t)pitch * c->p.img_h) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
     return orb_pipeline(c, d_imgs, img_bytes, pitch, B, c->p.anms_num, 1, true, d_kps, d_desc, d_count);
 }
 
 int vslam_orb_status_dev(vslam_ctx* ctx, int B, int32_t* h_status) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !h_status || B <= 0 || B > c->p.max_batch) return VSLAM_ERR_ARG;
+    VS_ENTER(c);
     VS_HIP(hipMemcpyAsync(h_status, c->orb.d_status, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
     return VSLAM_OK;
@@ -367,6 +381,7 @@ int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stri
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_q || !d_t || !d_nq || !d_nt || !d_gap || !d_out || !d_nout || out_capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if (B > c->p.max_batch) { set_error("batch %d exceeds context max_batch %d", B, c->p.max_batch); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
     return launch_match(d_q, q_stride_bytes, d_nq, d_t, t_stride_bytes, d_nt, d_gap, gate, c->p.match_ratio, c->p.match_gap_thr, B, max_rows,
                         c->match.d_train_best, c->match.d_q8, c->match.d_t8, d_out, out_capacity, d_nout, c->stream);
 }
@@ -378,7 +393,7 @@ int vslam_feature_matching(vslam_ctx* ctx, const uint8_t* q, int nq, const uint8
     if (nq > kMaxRows || nt > kMaxRows) { set_error("matcher supports at most %d rows per side", kMaxRows); return VSLAM_ERR_CAPACITY; }
     *n_out = 0;
     if (nq == 0 || nt == 0) return VSLAM_OK; // empty set: no matches (reference: UB, quirk Q7)
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     int rc;
     const int rows = std::max(nq, nt);
     if ((rc = arena_reserve(c, 2 * al256((size_t)rows * 32) + al256(sizeof(vslam_dmatch) * nq) + 2048))) return rc;
@@ -410,7 +425,7 @@ int vslam_disparity_map_dev(vslam_ctx* ctx, const uint8_t* d_left, const uint8_t
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_left || !d_right || w <= 0 || h <= 0 || pitch < w || B < 0 || img_stride_bytes < (size_t)pitch * h ||
         (!d_disparity && !d_disp_i16 && !d_disp_raw_i16)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     return launch_sgbm(d_left, d_right, img_stride_bytes, pitch, w, h, B, d_disparity, d_disp_i16, d_disp_raw_i16, &c->d_sgbm, &c->sgbm_bytes,
                        &c->dev_bytes, c->stream);
 }
@@ -419,7 +434,7 @@ int vslam_disparity_map(vslam_ctx* ctx, const uint8_t* left, const uint8_t* righ
                         int16_t* disp_raw_i16) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !left || !right || w <= 0 || h <= 0 || stride < w || (!disparity && !disp_i16 && !disp_raw_i16)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     int rc;
     const size_t npix = (size_t)w * h;
     if ((rc = arena_reserve(c, 2 * al256((size_t)((w + 63) & ~63) * h) + al256(npix * 4) + 2 * al256(npix * 2) + 1024))) return rc;
@@ -445,7 +460,7 @@ int vslam_find_3d_disparity(vslam_ctx* ctx, const vslam_keypoint* kps, int n, co
     if (!c || n < 0 || !disparity || !T_c_w || w <= 0 || h <= 0 || dstride < w || (n > 0 && (!kps || !xyz_w || !valid || !reliable))) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if (n_valid) *n_valid = 0;
     if (n == 0) return VSLAM_OK;
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     int rc;
     if ((rc = arena_reserve(c, al256(sizeof(vslam_keypoint) * n) + al256(sizeof(float) * (size_t)dstride * h) + al256(12 * (size_t)n) + 2 * al256(n) + 1024))) return rc;
     Arena ar(c);
@@ -471,6 +486,7 @@ int vslam_find_3d_disparity_dev(vslam_ctx* ctx, const vslam_keypoint* d_kps, con
                                 int w, int h, const double* d_T_c_w, float* d_xyz_w, uint8_t* d_valid, uint8_t* d_reliable) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_kps || !d_n || !d_disparity || !d_T_c_w || !d_xyz_w || !d_valid || !d_reliable || kp_capacity <= 0 || w <= 0 || h <= 0 || B < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
     return launch_find3d_disparity_batch(d_kps, d_n, kp_capacity, B, d_disparity, w, h, d_T_c_w, cam_of(c), d_xyz_w, d_valid, d_reliable, c->stream);
 }
 
@@ -478,6 +494,7 @@ int vslam_triangulate_dev(vslam_ctx* ctx, const float* d_uvL, const float* d_uvR
                           const double* d_T_c_w, float* d_xyz_w, uint8_t* d_valid, uint8_t* d_reliable) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_uvL || !d_uvR || !d_n || !d_T_c_w || !d_xyz_w || !d_valid || !d_reliable || capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
     return launch_triangulate(d_uvL, d_uvR, d_n, capacity, B, d_T_c_w, cam_of(c), d_xyz_w, d_valid, d_reliable, c->stream);
 }
 
@@ -487,7 +504,7 @@ int vslam_triangulate(vslam_ctx* ctx, const float* uvL, const float* uvR, int n,
     if (!c || n < 0 || !T_c_w || (n > 0 && (!uvL || !uvR || !xyz_w || !valid || !reliable))) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if (n_valid) *n_valid = 0;
     if (n == 0) return VSLAM_OK;
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     int rc;
     if ((rc = arena_reserve(c, 2 * al256(8 * (size_t)n) + al256(12 * (size_t)n) + 2 * al256(n) + 2048))) return rc;
     Arena ar(c);
@@ -516,6 +533,7 @@ int vslam_gather_matched_uv_dev(vslam_ctx* ctx, const vslam_keypoint* d_kpsQ, co
                                 const vslam_dmatch* d_matches, const int32_t* d_nmatch, int match_capacity, int B, float* d_uvQ, float* d_uvT) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_kpsQ || !d_kpsT || !d_matches || !d_nmatch || !d_uvQ || !d_uvT || kp_capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
     return launch_gather_uv(d_kpsQ, d_kpsT, kp_capacity, d_matches, d_nmatch, match_capacity, B, d_uvQ, d_uvT, c->stream);
 }
 
@@ -536,6 +554,7 @@ int vslam_pnp_motion_only_dev(vslam_ctx* ctx, const float* d_xyz_w, const float*
                               double* d_T_c_w, int iters, uint8_t* d_inlier, int32_t* d_n_inliers) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_xyz_w || !d_uv || !d_n || !d_T_c_w || capacity <= 0 || iters < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
     PnpArgs p;
     memset(&p, 0, sizeof(p));
     p.xyz = d_xyz_w; p.uv = d_uv; p.n = d_n; p.capacity = capacity; p.B = B; p.T = d_T_c_w; p.iters = iters;
@@ -548,7 +567,7 @@ int vslam_pnp_motion_only(vslam_ctx* ctx, const float* xyz_w, const float* uv, i
                           int* n_inliers, vslam_lm_stats* stats) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !xyz_w || !uv || n <= 0 || !T_c_w || iters < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     int rc;
     if ((rc = arena_reserve(c, al256(12 * (size_t)n) + al256(8 * (size_t)n) + al256(n) + al256(sizeof(vslam_lm_stats)) + 2048))) return rc;
     Arena ar(c);
@@ -602,7 +621,7 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
     if (inlier && n > 0) memset(inlier, 0, (size_t)n);
     const int mp = 5, H = max_iters;
     if (n < mp || H == 0) return VSLAM_OK;
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     // 1. the subset sequence (host: a few hundred RNG draws)
     std::vector<float> hx((size_t)H * mp * 3), hu((size_t)H * mp * 2);
     std::vector<double> hT((size_t)H * 7);
@@ -693,7 +712,7 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
 // kernel's CSR contract), runs one pass on the GPU, un-permutes chi2 and applies the chi2 classification of
 // optimization.cpp:224-266 on the host with the caller's flag_lm (quirk Q1 lives in the caller's edge list).
 static int window_host(vslam_ctx* ctx, int mode, int n_kf, double* T_c_w, int n_lm, float* xyz, int n_edge, const int32_t* kf_idx,
-                       const int32_t* lm_idx, const float* uv, const int32_t* flag_lm, int iters, int update_poses, int update_lms,
+                       const int32_t* lm_idx, const float* uv, const double* K4, const int32_t* flag_lm, int iters, int update_poses, int update_lms,
                        uint8_t* lm_inlier, double* chi2_out, double* thr_out, vslam_lm_stats* stats) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || n_kf <= 0 || n_kf > VSLAM_MAX_KF || !T_c_w || n_lm <= 0 || !xyz || n_edge <= 0 || !kf_idx || !lm_idx || !uv || iters < 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
@@ -706,7 +725,7 @@ static int window_host(vslam_ctx* ctx, int mode, int n_kf, double* T_c_w, int n_
     for (int l = 0; l < n_lm; ++l) ptr[l + 1] += ptr[l];
     { std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1); for (int e = 0; e < n_edge; ++e) perm[fill[lm_idx[e]]++] = e; }
     for (int j = 0; j < n_edge; ++j) { const int e = perm[j]; skf[j] = kf_idx[e]; slm[j] = lm_idx[e]; suv[2 * j] = uv[2 * e]; suv[2 * j + 1] = uv[2 * e + 1]; }
-    VS_HIP(hipSetDevice(c->device));
+    VS_ENTER(c);
     int rc;
     const size_t need = al256(56 * (size_t)n_kf) + al256(12 * (size_t)n_lm) + al256(n_lm) + 3 * al256(4 * (size_t)n_edge) + al256(8 * (size_t)n_edge) * 2 +
                         al256(sizeof(vslam_lm_stats)) + 4096;
@@ -737,6 +756,7 @@ static int window_host(vslam_ctx* ctx, int mode, int n_kf, double* T_c_w, int n_
     a.n_windows = 1; a.n_kf = n_kf; a.lm_off = d_off; a.edge_off = d_off + 2; a.T = d_T; a.xyz = d_xyz; a.reliable = nullptr;
     a.lm_inlier = d_inl; a.kf_idx = d_kf; a.lm_idx = d_lm; a.uv = d_uv; a.chi2 = d_chi; a.stats = d_st; a.chi2_thr = d_thr;
     fill_K(c, a.K); a.huber_delta = c->p.huber_delta; a.total_lm = n_lm; a.total_edge = n_edge;
+    if (K4) memcpy(a.K, K4, sizeof(a.K)); // the caller's `const cv::Mat& K` (optimization.hpp:137-139)
     if ((rc = launch_lm_windows(a, 0, mode, iters, update_poses, update_lms, &c->lm, c->stream))) return rc;
     int32_t status = 0;
     if ((rc = lm_fetch_status(&c->lm, 1, &status, c->stream))) return rc;
@@ -749,7 +769,7 @@ static int window_host(vslam_ctx* ctx, int mode, int n_kf, double* T_c_w, int n_
     if (stats) VS_HIP(hipMemcpy(stats, d_st, sizeof(vslam_lm_stats), hipMemcpyDeviceToHost));
     if (chi2_out) memcpy(chi2_out, chi.data(), 8 * (size_t)n_edge);
     // adaptive threshold + flags (optimization.cpp:224-266), caller's edge order
-    double th = 5.991;
+    double th = c->p.huber_delta; // optimization.cpp:154: one variable (chi2_th) is both the Huber delta and the initial chi2 threshold
     for (int iteration = 0; iteration < 5; ++iteration) {
         int out = 0, in = 0;
         for (int e = 0; e < n_edge; ++e) { if (chi[e] > th) ++out; else ++in; }
@@ -766,16 +786,16 @@ static int window_host(vslam_ctx* ctx, int mode, int n_kf, double* T_c_w, int n_
 }
 
 int vslam_local_ba(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, float* xyz, int n_edge, const int32_t* kf_idx, const int32_t* lm_idx,
-                   const float* uv, const int32_t* flag_lm, int iters, int update_poses, int update_lms, uint8_t* lm_inlier, double* chi2_out,
+                   const float* uv, const double* K4, const int32_t* flag_lm, int iters, int update_poses, int update_lms, uint8_t* lm_inlier, double* chi2_out,
                    double* chi2_threshold_out, vslam_lm_stats* stats) {
-    return window_host(ctx, 0, n_kf, T_c_w, n_lm, xyz, n_edge, kf_idx, lm_idx, uv, flag_lm, iters, update_poses, update_lms, lm_inlier, chi2_out,
+    return window_host(ctx, 0, n_kf, T_c_w, n_lm, xyz, n_edge, kf_idx, lm_idx, uv, K4, flag_lm, iters, update_poses, update_lms, lm_inlier, chi2_out,
                        chi2_threshold_out, stats);
 }
 
 int vslam_pose_only_window(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, const float* xyz, int n_edge, const int32_t* kf_idx,
-                           const int32_t* lm_idx, const float* uv, const int32_t* flag_lm, int iters, int update_poses, uint8_t* lm_inlier,
+                           const int32_t* lm_idx, const float* uv, const double* K4, const int32_t* flag_lm, int iters, int update_poses, uint8_t* lm_inlier,
                            double* chi2_out, double* chi2_threshold_out, vslam_lm_stats* stats) {
-    return window_host(ctx, 1, n_kf, T_c_w, n_lm, const_cast<float*>(xyz), n_edge, kf_idx, lm_idx, uv, flag_lm, iters, update_poses, 0, lm_inlier,
+    return window_host(ctx, 1, n_kf, T_c_w, n_lm, const_cast<float*>(xyz), n_edge, kf_idx, lm_idx, uv, K4, flag_lm, iters, update_poses, 0, lm_inlier,
                        chi2_out, chi2_threshold_out, stats);
 }
 
@@ -783,18 +803,21 @@ int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* b, int schedule, in
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !b || b->n_windows <= 0 || !b->d_lm_off || !b->d_edge_off || !b->d_T_c_w || !b->d_xyz || !b->d_lm_inlier || !b->d_kf_idx ||
         !b->d_lm_idx || !b->d_uv || b->total_lm <= 0 || b->total_edge <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
     LmWindowArgs a;
     memset(&a, 0, sizeof(a));
     a.n_windows = b->n_windows; a.n_kf = b->n_kf; a.lm_off = b->d_lm_off; a.edge_off = b->d_edge_off; a.T = b->d_T_c_w; a.xyz = b->d_xyz;
     a.reliable = b->d_reliable; a.lm_inlier = b->d_lm_inlier; a.kf_idx = b->d_kf_idx; a.lm_idx = b->d_lm_idx; a.uv = b->d_uv;
     a.chi2 = b->d_chi2; a.stats = b->d_stats; a.chi2_thr = nullptr;
     fill_K(c, a.K); a.huber_delta = c->p.huber_delta; a.total_lm = b->total_lm; a.total_edge = b->total_edge;
+    if (b->K4) memcpy(a.K, b->K4, sizeof(a.K));
     return launch_lm_windows(a, schedule, mode, iters, update_poses, update_lms, &c->lm, c->stream);
 }
 
 int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !h_status || n_windows <= 0) return VSLAM_ERR_ARG;
+    VS_ENTER(c);
     return lm_fetch_status(&c->lm, n_windows, h_status, c->stream);
 }
 
@@ -802,10 +825,9 @@ int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status) {
 int vslam_profile_enable(vslam_ctx* ctx, int on) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return VSLAM_ERR_ARG;
-    Prof*& p = g_ctx_prof_table[c->device & 63];
-    if (!p) p = new Prof();
-    p->on = on != 0;
-    prof_set_current(on ? p : nullptr);
+    if (!c->prof) c->prof = new Prof();
+    c->prof->on = on != 0;
+    prof_set_current(on ? c->prof : nullptr);
     return VSLAM_OK;
 }
 
@@ -813,8 +835,9 @@ int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_o
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !out || !n_out || cap <= 0) return VSLAM_ERR_ARG;
     *n_out = 0;
-    Prof* p = g_ctx_prof_table[c->device & 63];
+    Prof* p = c->prof;
     if (!p) return VSLAM_OK;
+    VS_ENTER(c);
     VS_HIP(hipStreamSynchronize(c->stream));
     int n = 0;
     for (const Prof::Rec& r : p->recs) {
@@ -823,7 +846,7 @@ int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_o
         int k = 0;
         for (; k < n; ++k) if (strncmp(out[k].name, r.name, sizeof(out[k].name) - 1) == 0) break;
         if (k == n) {
-            if (n == cap) continue;
+            if (n == cap) { p->pool.push_back(r.e0); p->pool.push_back(r.e1); continue; } // (events go back to the pool either way)
             memset(&out[n], 0, sizeof(out[n]));
             strncpy(out[n].name, r.name, sizeof(out[n].name) - 1);
             ++n;
@@ -843,6 +866,7 @@ int vslam_build_pnp_inputs_dev(vslam_ctx* ctx, const vslam_dmatch* d_f2f, const 
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_f2f || !d_nf2f || !d_lr || !d_nlr || !d_xyz_lr || !d_valid_lr || !d_kps_cur || !d_kp2lr || !d_xyz_out || !d_uv_out || !d_nout ||
         match_capacity <= 0 || lr_capacity <= 0 || kp_capacity <= 0 || out_capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
     return launch_build_pnp_inputs(d_f2f, d_nf2f, match_capacity, d_lr, d_nlr, lr_capacity, d_xyz_lr, d_valid_lr, d_kps_cur, kp_capacity, B,
                                    d_kp2lr, d_xyz_out, d_uv_out, d_nout, out_capacity, c->stream);
 }
@@ -854,6 +878,7 @@ int vslam_dev_free(void* p) { if (p) VS_HIP(hipFree(p)); return VSLAM_OK; }
 int vslam_dev_upload(vslam_ctx* ctx, void* d, const void* h, size_t bytes) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return VSLAM_ERR_ARG;
+    VS_ENTER(c);
     VS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
     return VSLAM_OK;
@@ -861,6 +886,7 @@ int vslam_dev_upload(vslam_ctx* ctx, void* d, const void* h, size_t bytes) {
 int vslam_dev_download(vslam_ctx* ctx, void* h, const void* d, size_t bytes) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return VSLAM_ERR_ARG;
+    VS_ENTER(c);
     VS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
     return VSLAM_OK;
@@ -868,6 +894,7 @@ int vslam_dev_download(vslam_ctx* ctx, void* h, const void* d, size_t bytes) {
 int vslam_dev_memset(vslam_ctx* ctx, void* d, int value, size_t bytes) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return VSLAM_ERR_ARG;
+    VS_ENTER(c);
     VS_HIP(hipMemsetAsync(d, value, bytes, c->stream));
     return VSLAM_OK;
 }

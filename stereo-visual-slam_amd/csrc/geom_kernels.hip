@@ -93,6 +93,9 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
     const double Z = s2 / s22;
     double p[3] = {(r0 - n02 * Z) / n00, (0.0 - n12 * Z) / n11, Z};
     if (!(s22 > 0) || !isfinite(Z)) { p[0] = p[1] = 0; p[2] = -1; }
+    // epipolar gate of a rectified pair (a cross-checked descriptor match has no row constraint of its own; SGBM, the
+    // reference's depth source, searches along the row by construction): same row within row_tol px, positive disparity
+    if (cam.row_tol >= 0 && (!(fabs((double)l.y - (double)r.y) <= cam.row_tol) || !(l.x > r.x))) { p[0] = p[1] = 0; p[2] = -1; }
     gate_store(p, Rinv, tinv, cam, i, xyz, valid, rel);
 }
 

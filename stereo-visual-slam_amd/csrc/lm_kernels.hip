@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     if (last_trial_is_current) chi_pass(sm.Rt, P); else chi_pass(sm.RtTrial, with_lm ? Pt : P);
     // ------------------------------------------------------------------ chi2 classification (optimization.cpp:224-266)
     if (classify && !IMPL) {
-        double th = 5.991;
+        double th = delta; // optimization.cpp:154: chi2_th is both the Huber delta and the initial classification threshold
         for (int iteration = 0; iteration < 5; ++iteration) {
             double out = 0, in = 0;
             for (int j = tid; j < ntot; j += kLmBlock) {
@@ -1430,10 +1430,9 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     ka.want_chi2 = a.chi2 != nullptr;
     ka.dinv_lds = kDinvLds;
     const size_t dyn_lds = (size_t)kDinvLds * 6 * sizeof(double);
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) { // more than 64 KB of dynamic LDS needs the opt-in
+    if (!scratch->lds_opt_in) { // more than 64 KB of dynamic LDS needs the opt-in (once per context, i.e. per device)
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_window_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-        lds_attr_set = true;
+        scratch->lds_opt_in = true;
     }
     static long long* d_cyc = nullptr; static int cyc_n = 0;
     if (getenv("VSLAM_LM_PROFILE")) {

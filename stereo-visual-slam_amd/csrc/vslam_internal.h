@@ -126,7 +126,7 @@ int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const
                  uint32_t* d_train_best, int8_t* d_q8, int8_t* d_t8, vslam_dmatch* d_out, int out_capacity, int32_t* d_nout, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- geometry
-struct CamParams { double fx, fy, cx, cy, b, dmin, dmax, drel; };
+struct CamParams { double fx, fy, cx, cy, b, dmin, dmax, drel, row_tol; };
 int launch_find3d_disparity(const vslam_keypoint* d_kps, int n, const float* d_disp, int w, int h, int dstride,
                             const double* d_T, CamParams cam, float* d_xyz, uint8_t* d_valid, uint8_t* d_rel, hipStream_t stream);
 int launch_find3d_disparity_batch(const vslam_keypoint* d_kps, const int32_t* d_n, int kp_capacity, int B, const float* d_disp, int w, int h,
@@ -183,6 +183,7 @@ size_t sgbm_scratch_bytes(int w, int h, int B);
 struct LmScratch {
     void* buf = nullptr; size_t bytes = 0;
     int32_t* status = nullptr; int status_n = 0;
+    bool lds_opt_in = false; // the > 64 KB dynamic-LDS attribute of lm_window_kernel has been set on this context's device
 };
 int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms, LmScratch* scratch,
                       hipStream_t stream);
@@ -215,6 +216,7 @@ struct Ctx {
     // SGBM working set (cost volumes; grown on demand by vslam_disparity_map*)
     uint8_t* d_sgbm; size_t sgbm_bytes;
     LmScratch lm;
+    Prof* prof;           // stage profiler of this context (vslam_profile_enable); null until first enabled
 };
 
 } // namespace vslam

@@ -76,18 +76,19 @@ Graph build(std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_
     return g;
 }
 
-void run(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks, bool pose_only,
+void run(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks, const Mat33& K, bool pose_only,
          bool if_update_map, bool if_update_landmark, int num_ite, bool q1_quirk) {
     Graph g = build(keyframes, landmarks, pose_only, q1_quirk);
     if (g.kf_idx.empty() || g.kf_ids.empty()) return; // nothing to optimise (g2o would report "0 vertices")
     const int n_kf = (int)g.kf_ids.size(), n_lm = (int)g.lm_ids.size(), n_edge = (int)g.kf_idx.size();
     std::vector<uint8_t> inl((size_t)n_lm, 2); // 2 = untouched
+    const double K4[4] = {K[0], K[4], K[2], K[5]}; // fx, fy, cx, cy out of the 3x3 (optimization.cpp:47-48 reads the same four entries)
     int rc;
     if (pose_only)
-        rc = vslam_pose_only_window(ctx, n_kf, g.T.data(), n_lm, g.xyz.data(), n_edge, g.kf_idx.data(), g.lm_idx.data(), g.uv.data(), g.flag_lm.data(), num_ite,
+        rc = vslam_pose_only_window(ctx, n_kf, g.T.data(), n_lm, g.xyz.data(), n_edge, g.kf_idx.data(), g.lm_idx.data(), g.uv.data(), K4, g.flag_lm.data(), num_ite,
                                     if_update_map ? 1 : 0, inl.data(), nullptr, nullptr, nullptr);
     else
-        rc = vslam_local_ba(ctx, n_kf, g.T.data(), n_lm, g.xyz.data(), n_edge, g.kf_idx.data(), g.lm_idx.data(), g.uv.data(), g.flag_lm.data(), num_ite,
+        rc = vslam_local_ba(ctx, n_kf, g.T.data(), n_lm, g.xyz.data(), n_edge, g.kf_idx.data(), g.lm_idx.data(), g.uv.data(), K4, g.flag_lm.data(), num_ite,
                             if_update_map ? 1 : 0, (if_update_map && if_update_landmark) ? 1 : 0, inl.data(), nullptr, nullptr, nullptr);
     if (rc != VSLAM_OK) throw std::runtime_error(std::string("window optimisation failed: ") + vslam_last_error());
     for (int l = 0; l < n_lm; ++l)
@@ -105,13 +106,13 @@ void run(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>& keyframes, st
 } // namespace
 
 void optimize_map(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks,
-                  bool if_update_map, bool if_update_landmark, int num_ite, bool q1_quirk) {
-    run(ctx, keyframes, landmarks, false, if_update_map, if_update_landmark, num_ite, q1_quirk);
+                  const Mat33& K, bool if_update_map, bool if_update_landmark, int num_ite, bool q1_quirk) {
+    run(ctx, keyframes, landmarks, K, false, if_update_map, if_update_landmark, num_ite, q1_quirk);
 }
 
 void optimize_pose_only(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks,
-                        bool if_update_map, int num_ite, bool q1_quirk) {
-    run(ctx, keyframes, landmarks, true, if_update_map, false, num_ite, q1_quirk);
+                        const Mat33& K, bool if_update_map, int num_ite, bool q1_quirk) {
+    run(ctx, keyframes, landmarks, K, true, if_update_map, false, num_ite, q1_quirk);
 }
 
 } // namespace vslam

@@ -310,6 +310,10 @@ bool VO::tracking(bool& if_insert_keyframe) {
     for (const Feature& f : frame_last_.features_) descriptors_last.push_back(f.descriptor_); // :568-574
     std::vector<DMatch> feature_matches;
     feature_matching(descriptors_last, descriptors_detected, feature_matches);
+    last_num_detected_ = (int)keypoints_detected.size(); last_num_matches_ = (int)feature_matches.size();
+    last_match_hash_ = 1469598103934665603ULL;
+    for (const DMatch& m : feature_matches)
+        for (uint32_t v : {(uint32_t)m.queryIdx, (uint32_t)m.trainIdx, (uint32_t)m.distance}) { last_match_hash_ ^= v; last_match_hash_ *= 1099511628211ULL; }
     for (size_t i = 0; i < feature_matches.size(); ++i) { // :587-598
         const DMatch& m = feature_matches[i];
         Feature f((int)i, seq_, keypoints_detected[(size_t)m.trainIdx], descriptors_detected.row(m.trainIdx));

@@ -2,7 +2,8 @@
 // on top of the C-ABI.  Same public state and method names; OpenCV/ROS types are replaced by the PODs in types.hpp and
 // every arithmetic-heavy step is one C-ABI call into libvslam_hip.so.  Stereo depth has two sources: the reference's
 // own (dense SGBM disparity + Frame::find_3d, depth_source_ = DepthSGBM) and the north_star stage (right-image ORB,
-// L/R cross-check match, rectified DLT: depth_source_ = DepthStereoMatch, the default the headline bench measures).
+// L/R cross-check match, rectified DLT: depth_source_ = DepthStereoMatch, what the headline bench measures).  The defaults are the
+// reference's own algorithm (SGBM depth + RANSAC pose).
 #pragma once
 #include <string>
 #include <vector>
@@ -41,8 +42,11 @@ public:
     int curr_keyframe_id_ = 0;
     int curr_landmark_id_ = 0;
     int pnp_iterations_ = 10;
-    DepthSource depth_source_ = DepthStereoMatch;
-    PnpMode pnp_mode_ = PnpMotionOnlyLM;
+    DepthSource depth_source_ = DepthSGBM;   // the reference's algorithm by default (visual_odometry.cpp:159-217, :277)
+    PnpMode pnp_mode_ = PnpRansac;
+    // diagnostics of the latest tracking() call, for the CPU-path vs GPU-path trace comparison (not in the reference)
+    int last_num_detected_ = 0, last_num_matches_ = 0;
+    uint64_t last_match_hash_ = 0; // FNV-1a over (queryIdx, trainIdx, distance) of the gated frame-to-frame matches
 
     VO(std::string dataset, vslam_ctx* ctx, Map& map) : my_map_(map), source_(std::move(dataset)), ctx_(ctx) {}
 

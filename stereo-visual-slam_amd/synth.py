@@ -75,13 +75,19 @@ def _hash_u32(ix, iy, pid, seed):
     return h
 
 
-def _texture(a, b, pid, seed):
-    """blocky multi-octave texture in plane coordinates (metres) -> grey level float"""
+def _texture(a, b, pid, seed, px_per_m=None):
+    """blocky multi-octave texture in plane coordinates (metres) -> grey level float.  px_per_m (optional, per pixel): image
+    pixels per metre of plane along its most compressed direction; an octave whose cells project to less than ~4 px is faded
+    out (analytic anti-aliasing: point-sampling sub-pixel cells gives noise that differs between the two views of a stereo pair
+    and between consecutive frames, which no camera produces)."""
     val = np.full(a.shape, 110.0)
     for cell, amp, k in ((0.9, 70.0, 1), (0.22, 50.0, 2), (0.06, 30.0, 3)):
         ix = np.floor(a / cell).astype(np.int64); iy = np.floor(b / cell).astype(np.int64)
         h = _hash_u32(ix, iy, pid * 4 + k, seed)
-        val += amp * (((h >> np.uint32(8)) & np.uint32(0xFF)).astype(np.float64) / 255.0 - 0.5)
+        o = amp * (((h >> np.uint32(8)) & np.uint32(0xFF)).astype(np.float64) / 255.0 - 0.5)
+        if px_per_m is not None:
+            o = o * np.clip((cell * px_per_m - 2.0) / 2.0, 0.0, 1.0)
+        val += o
     return val
 
 
@@ -89,18 +95,24 @@ class Scene:
     """ground plane + fronto-parallel textured walls + far backdrop, in the world (= first camera) frame.
     Camera convention: x right, y down, z forward (KITTI)."""
 
-    def __init__(self, seed=0, n_walls=10):
+    def __init__(self, seed=0, n_walls=10, z_far=80.0, antialias=False, path=None):
+        """path (optional): (n, 2) camera centres (x, z) of the sequence that will be rendered; walls then keep at least 2 m of
+        lateral clearance from it (a camera driving through a wall loses every feature at once)."""
         rng = np.random.default_rng(seed)
         self.seed = int(seed)
+        self.antialias = bool(antialias)
         self.walls = []
         for i in range(n_walls):
-            z = rng.uniform(6.0, 80.0)
+            z = rng.uniform(6.0, z_far)
             side = rng.choice([-1.0, 1.0])
             x0 = side * rng.uniform(2.0, 12.0) + rng.uniform(-2, 2)
             wdt = rng.uniform(3.0, 10.0); hgt = rng.uniform(2.0, 6.0)
+            if path is not None:
+                xc = float(np.interp(z, path[:, 1], path[:, 0]))
+                x0 = xc + side * (rng.uniform(2.0, 9.0) + wdt / 2)
             self.walls.append((z, x0 - wdt / 2, x0 + wdt / 2, 1.65 - hgt, 1.65))
         self.ground_y = 1.65
-        self.back_z = 120.0
+        self.back_z = z_far + 40.0
 
     def render(self, T_c_w, w=W_KITTI, h=H_KITTI, cam=CAM, x_offset=0.0):
         """render the view of a camera with pose T_c_w (7: quat xyzw + t); x_offset shifts the optical centre
@@ -127,17 +139,36 @@ class Scene:
             best_t = np.where(ok, tt, best_t); pid = np.where(ok, 2, pid)
             A = np.where(ok, o[0] + tt * d[..., 0], A); Bc = np.where(ok, o[2] + tt * d[..., 2], Bc)
             for i, (z, x0, x1, y0, y1) in enumerate(self.walls):
-                tt = (z - o[2]) / d[..., 2]
-                X = o[0] + tt * d[..., 0]; Y = o[1] + tt * d[..., 1]
-                ok = (tt > 0) & (tt < best_t) & (X >= x0) & (X <= x1) & (Y >= y0) & (Y <= y1)
-                best_t = np.where(ok, tt, best_t); pid = np.where(ok, 3 + i, pid)
-                A = np.where(ok, X, A); Bc = np.where(ok, Y, Bc)
+                # only the pixels inside the projected bounding box of the wall can hit it (all four corners in front of the
+                # camera: the image of the quad is the convex hull of its corners); walls behind the camera are skipped
+                cw = np.array([[x0, y0, z], [x1, y0, z], [x0, y1, z], [x1, y1, z]]) - o
+                cc = cw @ Rwc  # camera frame (rows: corner . columns of Rwc = R rows)
+                if cc[:, 2].max() <= 0.05:
+                    continue
+                sl = (slice(0, h), slice(0, w))
+                if cc[:, 2].min() > 0.05:
+                    uu = fx * cc[:, 0] / cc[:, 2] + cx; vv = fy * cc[:, 1] / cc[:, 2] + cy
+                    u0, u1 = int(np.floor(uu.min())) - 1, int(np.ceil(uu.max())) + 2
+                    v0, v1 = int(np.floor(vv.min())) - 1, int(np.ceil(vv.max())) + 2
+                    if u1 <= 0 or v1 <= 0 or u0 >= w or v0 >= h:
+                        continue
+                    sl = (slice(max(v0, 0), min(v1, h)), slice(max(u0, 0), min(u1, w)))
+                ds = d[sl]
+                tt = (z - o[2]) / ds[..., 2]
+                X = o[0] + tt * ds[..., 0]; Y = o[1] + tt * ds[..., 1]
+                ok = (tt > 0) & (tt < best_t[sl]) & (X >= x0) & (X <= x1) & (Y >= y0) & (Y <= y1)
+                best_t[sl] = np.where(ok, tt, best_t[sl]); pid[sl] = np.where(ok, 3 + i, pid[sl])
+                A[sl] = np.where(ok, X, A[sl]); Bc[sl] = np.where(ok, Y, Bc[sl])
         # texture lookup once per pixel, for the winning plane only
         for p in np.unique(pid):
             if p == 0:
                 continue
             m = pid == p
-            img[m] = _texture(A[m], Bc[m], int(p), self.seed)
+            ppm = None
+            if self.antialias:  # pixels per metre of plane: fronto-parallel planes f / Z; the ground is compressed along z: f * height / Z^2
+                Zm = np.maximum(best_t[m], 1e-3)
+                ppm = fx / Zm * (0.25 if p == 1 else 1.0) if p != 2 else fy * abs(self.ground_y - o[1]) / (Zm * Zm)
+            img[m] = _texture(A[m], Bc[m], int(p), self.seed, ppm)
         depth = best_t * 1.0  # z-depth along camera axis since d_cam.z == 1
         return np.clip(np.rint(img), 0, 255).astype(np.uint8), depth
 
@@ -156,10 +187,15 @@ def trajectory(n_frames, seed=0):
 
 
 def stereo_sequence(n_frames, seed=0, w=W_KITTI, h=H_KITTI):
-    """list of (left u8, right u8, T_c_w, depth_left)"""
-    sc = Scene(seed)
+    """list of (left u8, right u8, T_c_w, depth_left).  Walls are spread over the whole path (about 1 m per frame) so that
+    the last frames still see structure within the 10-40 m reliable-depth range (visual_odometry.cpp:194,201)."""
+    traj = trajectory(n_frames, seed)
+    centres = np.array([-R_from_quat(T[:4]).T @ T[4:] for T in traj])
+    far = centres[-1] + 200.0 * (R_from_quat(traj[-1][:4]).T @ np.array([0, 0, 1.0]))  # the last heading extended beyond the walls
+    path = np.vstack([centres[:, [0, 2]], far[[0, 2]]])
+    sc = Scene(seed, n_walls=10 + n_frames // 2, z_far=80.0 + 1.2 * n_frames, antialias=True, path=path)
     out = []
-    for T in trajectory(n_frames, seed):
+    for T in traj:
         L, depth = sc.render(T, w, h)
         Rr, _ = sc.render(T, w, h, x_offset=BASELINE)
         out.append((L, Rr, T, depth))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity sweep (not part of pytest: minutes of runtime).  Sizes and seeds are drawn at random;
-any mismatch prints the reproducer and exits non-zero.  usage: python tools/fuzz_parity.py [--seconds 120] [--seed 0]"""
+any mismatch prints the reproducer and exits non-zero.  usage: python tests/fuzz_parity.py [--seconds 120] [--seed 0]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,7 +1,11 @@
-"""GPU end-to-end: the C++ host mirror (VO / Map / optimize_* over the C-ABI) runs the reference's loop and BA schedule
-(run_vslam.cpp:40-71) on a synthetic KITTI-shaped stereo sequence and recovers the ground-truth trajectory."""
+"""GPU end-to-end, row A15 + BASELINE config 1: the reference's loop and BA schedule (run_vslam.cpp:40-82) run by the C++ host
+mirror (VO / Map / optimize_* over the C-ABI) on a rendered KITTI-shaped stereo sequence of 50 pairs -- once through
+libvslam_hip.so (GPU path) and once through the CPU oracle behind the same C-ABI (oracle/cpu_shim.c -> oracle/run_vslam_cpu).
+The two per-frame traces must agree: identical integer decisions (tracking state, keyframe ids, match index sets by hash, inlier
+counts, map sizes), poses within 1e-4.  The ground-truth check of round 1 is kept as a sanity bound on the trajectory itself."""
+import json
 import os
-import subprocess
+import sys
 import tempfile
 
 import numpy as np
@@ -9,58 +13,48 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST = os.path.join(ROOT, "stereo-visual-slam_amd", "host")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import trajectory_parity as tp  # noqa: E402
+
+N_FRAMES = 50  # BASELINE.json configs[0]: "first 50 stereo pairs"
 
 
-def test_run_vslam_driver_recovers_trajectory(synth):
-    subprocess.check_call(["make", "-C", HOST, "-s", "-j8"])
-    n = 30
+@pytest.fixture(scope="module")
+def sequence(synth):
+    tp.build()
     with tempfile.TemporaryDirectory() as d:
-        gt = synth.write_pgm_sequence(d + "/", n, seed=5)
-        path_len = np.linalg.norm(-synth.R_from_quat(gt[-1][:4]).T @ gt[-1][4:])
-        for q1 in (0, 1):
-            traj = os.path.join(d, "traj%d.txt" % q1)
-            out = subprocess.run([os.path.join(HOST, "run_vslam"), d + "/", str(n), "1", "1500", traj, str(q1)], capture_output=True, text=True, timeout=300)
-            assert out.returncode == 0, out.stdout + out.stderr
-            assert "VO IS LOST" not in out.stdout
-            rows = np.loadtxt(traj)
-            assert rows.shape[1] == 13 and len(rows) >= 10  # only keyframes are written (map.cpp:120, :198)
-            ids = rows[:, 0].astype(int)
-            assert len(set(ids)) == len(ids)
-            err = []
-            for r in rows:
-                T = gt[int(r[0])]
-                Rwc = synth.R_from_quat(T[:4]).T
-                pos = -Rwc @ T[4:]
-                est_R = r[1:].reshape(3, 4)[:, :3]; est_t = r[1:].reshape(3, 4)[:, 3]
-                err.append(np.linalg.norm(est_t - pos))
-                assert np.allclose(est_R @ est_R.T, np.eye(3), atol=1e-6)
-            ba_runs = int(out.stdout.split("ba_runs")[1].split()[0])
-            assert ba_runs >= 1, out.stdout   # the 5+5+10+10 schedule ran on a full 10-keyframe window
-            if q1 == 0:   # features looked up by id: every written keyframe is within 5 % of the path length
-                assert max(err) < 0.05 * path_len + 0.2, (err, path_len)
-            else:         # reference-faithful quirk Q1 (feature_id used as an index): BA edges can pair a landmark with the
-                          # wrong pixel, so single keyframes may be pulled away; the trajectory as a whole still holds
-                assert np.median(err) < 0.05 * path_len + 0.2, (err, path_len)
+        gt = synth.write_pgm_sequence(d + "/", N_FRAMES, seed=5, fmt="png")  # KITTI's own file type: exercises the PNG reader
+        yield d, gt
 
 
-def test_run_vslam_driver_with_sgbm_depth(synth):
-    """same loop with the reference's own depth source (VO::disparity_map = SGBM on the device, + Frame::find_3d) and its
-    own pose stage (RANSAC control flow of solvePnPRansac + refinement)"""
-    subprocess.check_call(["make", "-C", HOST, "-s", "-j8"])
-    n = 24
-    with tempfile.TemporaryDirectory() as d:
-        gt = synth.write_pgm_sequence(d + "/", n, seed=6, fmt="png")  # KITTI's own file type: exercises the PNG reader
-        path_len = np.linalg.norm(-synth.R_from_quat(gt[-1][:4]).T @ gt[-1][4:])
-        traj = os.path.join(d, "traj_sgbm.txt")
-        out = subprocess.run([os.path.join(HOST, "run_vslam"), d + "/", str(n), "1", "1500", traj, "0", "1", "1"], capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stdout + out.stderr
-        assert "VO IS LOST" not in out.stdout
-        rows = np.loadtxt(traj)
-        assert rows.shape[1] == 13 and len(rows) >= 8
-        err = []
-        for r in rows:
-            T = gt[int(r[0])]
-            pos = -synth.R_from_quat(T[:4]).T @ T[4:]
-            err.append(np.linalg.norm(r[1:].reshape(3, 4)[:, 3] - pos))
-        assert np.median(err) < 0.05 * path_len + 0.2 and max(err) < 0.1 * path_len + 0.3, (err, path_len)
+def _ground_truth_errors(traj_path, gt, synth):
+    rows = np.loadtxt(traj_path, ndmin=2)
+    err = []
+    for r in rows:
+        T = gt[int(r[0])]
+        pos = -synth.R_from_quat(T[:4]).T @ T[4:]
+        M = r[1:].reshape(3, 4)
+        assert np.allclose(M[:, :3] @ M[:, :3].T, np.eye(3), atol=1e-6)
+        err.append(np.linalg.norm(M[:, 3] - pos))
+    return rows, np.array(err)
+
+
+# (q1 quirk, depth source, pose stage): the reference's own algorithm (SGBM + RANSAC) and the north_star stages (L/R match + DLT,
+# motion-only LM), each with the reference's feature_id-as-index behaviour (Q1) on and off
+# ANMS 500 is the reference's own setting (visual_odometry.cpp:82), 1500 the BASELINE config-2 shape
+@pytest.mark.parametrize("anms,q1,depth,pnp", [(1500, 1, 1, 1), (500, 0, 1, 1), (1500, 1, 0, 0), (500, 0, 0, 0)])
+def test_gpu_path_matches_cpu_path(sequence, synth, anms, q1, depth, pnp):
+    d, gt = sequence
+    tag = "%d_%d%d%d" % (anms, q1, depth, pnp)
+    res = tp.run_config(d + "/", N_FRAMES, anms, q1, depth, pnp, d, tag)
+    print(json.dumps(res))
+    assert res["lines_gpu"] == res["lines_cpu"] and res["n_frames"] == N_FRAMES, res
+    assert res["identical_integers"], res["first_integer_mismatch"]
+    assert res["poses_within_tol"], res["first_pose_mismatch"]
+    assert res["traj_same_frames"] and res["traj_max_abs_diff"] < 1e-3, res  # estimated_traj.txt is written with 6 significant digits
+    assert res["n_keyframes"] >= 10 and res["n_ba"] >= 1, res                   # the 5+5+10+10 schedule ran on full 10-keyframe windows
+    # sanity against the rendered ground truth (the parity above says nothing about the trajectory being any good)
+    path_len = np.linalg.norm(-synth.R_from_quat(gt[-1][:4]).T @ gt[-1][4:])
+    rows, err = _ground_truth_errors(os.path.join(d, "traj_%s_gpu.txt" % tag), gt, synth)
+    assert rows.shape[1] == 13 and len(set(rows[:, 0].astype(int))) == len(rows)
+    assert np.median(err) < 0.05 * path_len + 0.2, (err, path_len)
