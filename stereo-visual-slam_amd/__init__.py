@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libvslam_hip.so")
+# VSLAM_LIB: path of an alternative build of the SAME library (kernel tuning variants, tools/build_variant.sh); never a fallback
+_SO = os.environ.get("VSLAM_LIB") or os.path.join(_HERE, "libvslam_hip.so")
 
 VSLAM_OK, VSLAM_ERR_ARG, VSLAM_ERR_HIP, VSLAM_ERR_CAPACITY, VSLAM_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 MAX_KF = 12

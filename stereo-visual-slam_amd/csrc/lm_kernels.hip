@@ -57,7 +57,10 @@ constexpr int kMaxKf = VSLAM_MAX_KF;
 constexpr int kMaxNp = 6 * kMaxKf;
 constexpr int kMaxPairs = kMaxKf * (kMaxKf + 1) / 2;
 constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
-constexpr int kDinvLds = 2000;  // landmarks whose Dinv stays in LDS (48 B each: the 96 KB the static state leaves free)
+#ifndef VSLAM_LM_DINV_LDS
+#define VSLAM_LM_DINV_LDS 2000
+#endif
+constexpr int kDinvLds = VSLAM_LM_DINV_LDS;  // landmarks whose Dinv stays in LDS (48 B each: the 96 KB the static state leaves free)
 constexpr int kLin = 2;        // doubles per edge of linearisation scratch: the Huber weight at the current state / at the trial state
 constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
 constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
