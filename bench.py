@@ -50,14 +50,32 @@ def algorithmic_bytes(kernel, pipe, anms_num):
     return 0, "n/a"
 
 
-def other_rooflines(prof, pipe, args):
-    """the one MFMA kernel of the path (the matcher's Hamming table) against the dense int8 peak; informative only"""
+def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
+    """every other kernel family of the step against the roofline that bounds it; informative (the dominant kernel has `roofline`)"""
     out = []
+    # ORB family: compulsory bytes of the whole family per step (SURVEY 8d: image read once + 60 B per keypoint written once) over each
+    # kernel's own time, and over the family's time
+    orb_alg, _ = algorithmic_bytes("orb_", pipe, args.anms)
+    orb_total_ms = 0.0
+    for name in ("orb_resize_kernel", "orb_pyramid_kernel", "orb_fast_kernel", "orb_select_kernel", "orb_anms_kernel", "orb_blur_kernel", "orb_describe_kernel"):
+        k = prof.get(name)
+        if not k or k[0] <= 0:
+            continue
+        ms = k[0] / n_steps
+        orb_total_ms += ms
+        gbs = orb_alg / (ms / 1e3) / 1e9
+        out.append({"kernel": name, "bound": "hbm", "ms_per_step": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 5), "note": "ORB-family algorithmic bytes per step over THIS kernel's time"})
+    if orb_total_ms > 0:
+        gbs = orb_alg / (orb_total_ms / 1e3) / 1e9
+        out.append({"kernel": "orb_* (family)", "bound": "hbm", "ms_per_step": round(orb_total_ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(orb_alg),
+                    "frac_of_copy_ceiling": round(gbs / copy_gbs, 5) if copy_gbs > 0 else None})
     k = prof.get("match_train_nearest_kernel")
     if k and k[0] > 0:
         n = float(args.anms)
         items = pipe.B + max(pipe.B - 1, 0)                      # L/R call + frame-to-frame call per step
-        macs = items * n * n * 256.0 * args.steps               # +-1 byte products per step
+        macs = items * n * n * 256.0 * n_steps                  # +-1 byte products per step
         tops = 2.0 * macs / (k[0] / 1e3) / 1e12
         out.append({"kernel": "match_train_nearest_kernel", "bound": "mfma", "achieved": round(tops, 1), "peak": 5000.0, "unit": "TOP/s (int8)",
                     "frac": round(tops / 5000.0, 4), "note": "v_mfma_i32_32x32x32_i8; 4250 TOP/s sustained in tools/scratch/mfma_rate.hip"})
@@ -70,7 +88,7 @@ def other_rooflines(prof, pipe, args):
     except Exception:
         wi = 0.0
     if k and k[0] > 0 and wi > 0 and pipe.lms_per_window == 3000 and pipe.n_kf == 10:
-        sets = k[2] if len(k) > 2 and k[2] else args.steps
+        sets = k[2] if len(k) > 2 and k[2] else n_steps
         t = k[0] / 1e3 / sets                                   # seconds per schedule batch
         slots = 256 * 4 * 2.4e9 * t / 4.0                       # 256 CUs x 4 SIMDs, one VALU issue per 4 cycles at 2.4 GHz
         used = wi * pipe.B
@@ -80,48 +98,88 @@ def other_rooflines(prof, pipe, args):
     return out
 
 
-def cpu_baseline(pipe, anms_num, n_keyframes=64):  # ~14 s of single-thread CPU work
-    """the CPU oracle (single thread) on a bounded sample of the same workload: `n_keyframes` stereo keyframes + windows"""
-    import oracle as O
-    from stereo_visual_slam_amd import synth
-    B, w = pipe.B, pipe.w
-    imgs = pipe.h_imgs
-    n_keyframes = min(n_keyframes, B)
-    win = synth.ba_window(n_kf=pipe.n_kf, n_lm=int(pipe.lms_per_window), seed=100)
-    t0 = time.perf_counter()
-    prev = None
-    for b in range(n_keyframes):
-        kL, dL = O.feature_detection(imgs[b][:, :w], 3000, anms_num)
-        kR, dR = O.feature_detection(imgs[B + b][:, :w], 3000, anms_num)
-        m = O.feature_matching(dL, dR, 1.0)
-        uvL = np.stack([kL["x"][m["queryIdx"]], kL["y"][m["queryIdx"]]], 1)
-        uvR = np.stack([kR["x"][m["trainIdx"]], kR["y"][m["trainIdx"]]], 1)
-        ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
-        xyz, valid, rel = O.triangulate_dlt(uvL, uvR, ident)
-        if prev is not None:
-            pk, pd, pm, pxyz, pvalid = prev
-            f = O.feature_matching(pd, dL, 1.0)
-            kp2lr = -np.ones(len(pk), np.int64); kp2lr[pm["queryIdx"]] = np.arange(len(pm))
-            li = kp2lr[f["queryIdx"]]
-            ok = (li >= 0) & (pvalid[np.maximum(li, 0)] != 0)
-            if ok.sum() >= 4:
-                O.pnp_motion_only(pxyz[li[ok]], np.stack([kL["x"][f["trainIdx"][ok]], kL["y"][f["trainIdx"][ok]]], 1), ident, iters=10)
-        prev = (kL, dL, m, xyz, valid)
-        # local BA schedule (run_vslam.cpp:58-71)
-        T = win["T0"].copy(); inl = np.ones(len(win["xyz"]), np.uint8)
-        for iters, upd in ((5, False), (5, False), (10, True)):
-            act = inl.astype(bool)[win["lm_idx"]]
-            T2, _, chi2, _ = O.local_ba(T, win["xyz"], win["kf_idx"][act], win["lm_idx"][act], win["uv"][act], iters=iters)
-            _, inl, _, _ = O.chi2_classify(chi2, win["lm_idx"][act], inl)
-            if upd:
-                T = T2
-        act = inl.astype(bool)[win["lm_idx"]]
-        O.pose_only_window(T, win["xyz"], win["kf_idx"][act], win["lm_idx"][act], win["uv"][act], iters=10)
-    dt = time.perf_counter() - t0
-    return dict(value=n_keyframes / dt, unit="keyframes/s", cores=1, kind="port",
-                sample="%d stereo keyframes (2 ORB images, L/R + frame-to-frame match, DLT, motion-only LM, BA schedule on one "
-                       "10x%d window) through oracle/libvo_oracle.so, single thread, %.1f s; host has %d cores"
-                       % (n_keyframes, int(pipe.lms_per_window), dt, os.cpu_count()))
+def _pose_diff(a, b):
+    """(translation RMSE [m], quaternion RMSE, max |diff| relative to max(|value|, 1e-2)) between two (n, 7) pose arrays"""
+    a = np.asarray(a, np.float64).reshape(-1, 7); b = np.asarray(b, np.float64).reshape(-1, 7)
+    q = np.where((np.sum(a[:, :4] * b[:, :4], 1) < 0)[:, None], -b[:, :4], b[:, :4])  # q and -q are the same rotation
+    d = np.concatenate([a[:, :4] - q, a[:, 4:] - b[:, 4:]], 1)
+    return (float(np.sqrt((d[:, 4:] ** 2).sum(1).mean())), float(np.sqrt((d[:, :4] ** 2).sum(1).mean())),
+            float((np.abs(d) / np.maximum(np.abs(a), 1e-2)).max()))
+
+
+def cpu_baseline(pipe, out, anms_num, n_single=24, per_core=2, chunk_len=8):
+    """The CPU oracle (a "port": the reference itself is unbuildable here) on bounded samples of the same workload, on this
+    host: one thread in-process (and, on the way, the GPU's poses / counts are checked against the oracle's on that sample),
+    then all cores through a pool of worker processes (oracle/cpu_keyframe.py)."""
+    import multiprocessing as mp
+    import tempfile
+    from oracle import cpu_keyframe as W
+    B, U = pipe.B, pipe.unique_frames
+    tmp = tempfile.NamedTemporaryFile(suffix=".npy", dir="/dev/shm" if os.path.isdir("/dev/shm") else None, delete=False)
+    tmp.close()
+    uniq = np.concatenate([pipe.h_imgs_unique_left, pipe.h_imgs_unique_right])
+    np.save(tmp.name, uniq)
+    init_args = (tmp.name, pipe.w, anms_num, pipe.n_kf, int(pipe.lms_per_window), pipe.window_seed0)
+    try:
+        # ---- one thread, and parity of the GPU step on the same keyframes
+        W.init(*init_args)
+        n1 = min(n_single, B)
+        t0 = time.perf_counter()
+        prev, pnp_o, pnp_g, ba_o, ba_g, int_mismatch = None, [], [], [], [], 0
+        for b in range(n1):
+            cur = W.front_end(pipe.frame_of[b])
+            int_mismatch += int(out["cnt"][b] != len(cur[0])) + int(out["cnt"][B + b] != cur[5]) + int(out["nlr"][b] != len(cur[2]))
+            if prev is not None:
+                T, npts, ninl, nf = W.track(prev, cur)
+                int_mismatch += int(out["nf2f"][b - 1] != nf) + int(out["pn"][b - 1] != npts) + int(out["ninl"][b - 1] != ninl)
+                if npts >= 6:
+                    pnp_o.append(T); pnp_g.append(out["Tpnp"][b - 1])
+            Tb, inl = W.ba_schedule(pipe.h_windows[b % pipe.unique_windows])
+            ba_o.append(Tb); ba_g.append(out["ba_T"][b])
+            lo, hi = pipe.h_lm_off[b], pipe.h_lm_off[b + 1]
+            int_mismatch += int((out["ba_inl"][lo:hi] != inl).sum())
+            prev = cur
+        dt1 = time.perf_counter() - t0
+        pt, pq, pr = _pose_diff(np.array(pnp_g), np.array(pnp_o)) if pnp_o else (None, None, None)
+        bt, bq, br = _pose_diff(np.array(ba_g), np.array(ba_o))
+        parity = dict(keyframes_checked=n1, integer_mismatches=int_mismatch, pnp_translation_rmse_m=pt, pnp_quaternion_rmse=pq, pnp_max_rel_diff=pr,
+                      ba_translation_rmse_m=bt, ba_quaternion_rmse=bq, ba_max_rel_diff=br,
+                      note="GPU step vs oracle on the same inputs: counts of keypoints / LR / f2f matches / PnP points / PnP inliers and BA landmark "
+                           "flags must be identical (integer_mismatches = 0); poses: motion-only LM of keyframe b-1 -> b, and the 10 window poses "
+                           "after the 5+5+10+10 schedule")
+        # ---- all cores
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        all_cores = None
+        if cores > 1:
+            n_all = int(min(max(per_core * cores, 64), 2048))
+            n_all = (n_all + chunk_len - 1) // chunk_len * chunk_len
+            period = max(2 * (U - 1), 1)
+            frames = [(t if t < U else period - t) for t in (b % period for b in range(n_all))]
+            tasks = [(b0, min(b0 + chunk_len, n_all), frames, pipe.unique_windows) for b0 in range(0, n_all, chunk_len)]
+            ctx = mp.get_context("spawn")  # workers import numpy + the oracle only; nothing of this process's HIP state is forked
+            with ctx.Pool(min(cores, len(tasks)), initializer=W.init, initargs=init_args) as pool:
+                pool.map(W.warm, range(4 * min(cores, len(tasks))), chunksize=1)  # every worker started and initialised
+                t0 = time.perf_counter()
+                done = sum(pool.map(W.chunk, tasks, chunksize=1))
+                dta = time.perf_counter() - t0
+            all_cores = dict(value=done / dta, unit="keyframes/s", cores=min(cores, len(tasks)), keyframes=done, seconds=round(dta, 2))
+    finally:
+        os.unlink(tmp.name)
+    res = dict(unit="keyframes/s", kind="port",
+               single_thread=dict(value=n1 / dt1, cores=1, keyframes=n1, seconds=round(dt1, 2)),
+               sample=("oracle/libvo_oracle.so per stereo keyframe: 2 ORB images (3000 -> ANMS %d -> rBRIEF), L/R + frame-to-frame match, DLT, "
+                       "motion-only LM, BA schedule 5+5+10+10 on one 10x%d window; single thread: %d keyframes in %.1f s" % (anms_num, int(pipe.lms_per_window), n1, dt1)))
+    if all_cores:
+        res.update(value=all_cores["value"], cores=all_cores["cores"])
+        res["sample"] += "; all cores: %d keyframes in %.1f s on %d worker processes (chunks of %d with a 1-frame front-end halo); host has %d cores" % (
+            all_cores["keyframes"], all_cores["seconds"], all_cores["cores"], chunk_len, os.cpu_count())
+    else:
+        res.update(value=n1 / dt1, cores=1)
+    return res, parity
 
 
 def main():
@@ -129,13 +187,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is repeated this many times; the median is reported")
     ap.add_argument("--batch", type=int, default=256, help="stereo keyframes per GPU per step")
     ap.add_argument("--anms", type=int, default=1500, help="keypoints per image after ANMS (BASELINE config 2: ~1500; reference: 500)")
     ap.add_argument("--landmarks", type=int, default=3000)
+    ap.add_argument("--unique-frames", type=int, default=64, help="rendered stereo keyframes (one sequence, laid over the batch as a ping-pong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--depth", choices=["match", "sgbm"], default="match",
                     help="stereo depth stage: north_star L/R match + DLT (default, BASELINE metric) or the reference's SGBM + find_3d")
+    ap.add_argument("--sequence", type=int, default=0, metavar="F",
+                    help="BASELINE config 5: one F-frame sequence split into contiguous chunks with a 1-frame halo across the ranks, relative poses "
+                         "gathered over RCCL and chained on rank 0 (stereo-visual-slam_amd/sharding.py); 0 = independent batches per rank")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -151,44 +214,71 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
 
     from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    from stereo_visual_slam_amd import sharding
     B = args.batch
-    pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
-                            with_ba=not args.no_ba, depth=args.depth)
+    seq_mode = args.sequence > 0
+    if seq_mode:  # config 5: this rank's contiguous chunk of ONE sequence, plus the frame before it (halo)
+        assert args.sequence >= 2 * world, "--sequence needs at least two frames per rank"
+        lo, hi = sharding.shard_range(args.sequence, rank, world)
+        h_lo = sharding.halo_start(lo)
+        B = hi - h_lo
+        pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=0, verbose=args.verbose and rank == 0,
+                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence))
+    else:
+        pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
+                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames)
     dev = pipe.dev
-    from stereo_visual_slam_amd.sharding import gather_poses
+    chained = [None]
 
     def one_step():
         pipe.step()
-        if world > 1:  # throughput-mode pose gather (RCCL over xGMI), 56 B per keyframe; ordered after the step on its stream
+        if seq_mode:   # ragged gather of the per-frame relative poses (56 B each), chained into one trajectory on rank 0
             with torch.cuda.stream(pipe.stream):
-                gather_poses(pipe.d_Tpnp, dist)
+                rel = pipe.d_Tpnp[:max(B - 1, 0)]  # item i = T_{h_lo+i+1, h_lo+i}: exactly the poses this rank owns (sharding.owned_pose_range)
+                chained[0] = sharding.gather_and_chain(rel, args.sequence, dist, world, rank)
+        elif world > 1:  # throughput-mode pose gather (RCCL over xGMI), 56 B per keyframe; ordered after the step on its stream
+            with torch.cuda.stream(pipe.stream):
+                sharding.gather_poses(pipe.d_Tpnp, dist)
 
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
+    copy_gbs = pipe.vo.hbm_copy_probe(1 << 30, 5) if rank == 0 else 0.0
     pipe.vo.profile_enable(True)
     pipe.vo.profile_read()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    rep_s = []
+    for rep in range(max(args.repeats, 1)):   # every repeat: EXACTLY `steps` steps between barrier + synchronize brackets, max over ranks
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        rep_s.append(el)
     prof = pipe.vo.profile_read()
     pipe.vo.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = float(np.median(rep_s))
+    n_timed_steps = args.steps * len(rep_s)
+    # a step that overflowed an ORB capacity or whose BA windows were rejected must not count as processed keyframes
+    n_img = pipe.B if args.depth == "sgbm" else 2 * pipe.B
+    orb_bad = int((pipe.vo.orb_status(n_img) != 0).sum())
+    ba_bad = int((pipe.vo.ba_status(pipe.B) != 0).sum()) if pipe.with_ba else 0
+    if orb_bad or ba_bad:
+        raise SystemExit("bench invalid: %d images overflowed an ORB capacity, %d BA windows were rejected" % (orb_bad, ba_bad))
 
     if rank == 0:
         out = pipe.download()
-        value = world * B * args.steps / elapsed
+        units = args.sequence if seq_mode else world * B   # keyframes all ranks processed per step (halo frames are not counted twice)
+        value = units * args.steps / elapsed
         kern = sorted(prof.items(), key=lambda kv: -kv[1][0])
         dom, (dom_ms, dom_launches, dom_calls) = kern[0]
         alg, formula = algorithmic_bytes(dom, pipe, args.anms)
@@ -201,28 +291,40 @@ def main():
                 traffic = int(tj["hbm_bytes_per_launch_set"])
         except Exception:
             traffic = None
+        nt = max(B - 1, 1)
         res = {
             "metric": "stereo keyframes/sec (ORB+match+tri+local-BA), KITTI-00 1241x376",
             "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if seq_mode else "weak", "vs_baseline": None,
             "dtype": "u8+f64", "data": "synthetic",
-            "config": {"workload": ("stereo keyframe hot path: ORB(3000)->ANMS(%d)->rBRIEF on L+R 1241x376, L/R + frame-to-frame BF-Hamming "
-                                    "cross-check match, DLT triangulation, motion-only LM pose (10 its), local BA 10 KF x %d landmarks "
-                                    "(5+5+10 LM + 10 pose-only)%s" % (args.anms, args.landmarks, "" if not args.no_ba else " [BA disabled]"))
+            "config": {"workload": ("stereo keyframe hot path, north_star stages (NOT the reference's SGBM depth / solvePnPRansac pose, which are built "
+                                    "and selectable: --depth sgbm, host driver): ORB(3000)->ANMS(%d)->rBRIEF on L+R 1241x376, L/R + frame-to-frame "
+                                    "BF-Hamming cross-check match, epipolar-gated DLT triangulation, motion-only LM pose (10 its), local BA 10 KF x %d "
+                                    "landmarks (5+5+10 LM + 10 pose-only)%s" % (args.anms, args.landmarks, "" if not args.no_ba else " [BA disabled]"))
                                    + (" [depth stage swapped for the reference's own: SGBM disparity + find_3d; not the BASELINE metric]" if args.depth == "sgbm" else ""),
-                       "batch_keyframes_per_gpu": B, "image": "1241x376 u8", "parallelism": "%d independent replicas, sharded keyframes" % world},
+                       "batch_keyframes_per_gpu": B, "image": "1241x376 u8",
+                       "unique_inputs": "%d rendered stereo keyframes of one sequence (ping-pong over the batch), %d unique BA windows" % (
+                           pipe.unique_frames, pipe.unique_windows if pipe.with_ba else 0),
+                       "parallelism": ("one %d-frame sequence in %d contiguous chunks with a 1-frame halo, relative poses gathered and chained on rank 0" % (args.sequence, world))
+                                      if seq_mode else "%d independent replicas, sharded keyframes" % world},
+            "timing": {"repeats": len(rep_s), "ms_per_step_each": [round(1e3 * x / args.steps, 4) for x in rep_s], "reported": "median",
+                       "spread_pct": round(100.0 * (max(rep_s) - min(rep_s)) / elapsed, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "copy_ceiling_gbs": round(copy_gbs, 1), "frac_of_copy_ceiling": round(achieved / copy_gbs, 6) if copy_gbs > 0 else None,
                          "algorithmic_bytes_per_launch_set": int(alg), "formula": formula,
                          "avg_ms_per_launch_set": round(1e3 * per_bracket_s, 4), "kernel_launches_per_set": dom_launches // max(dom_calls, 1)},
-            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kern},
-            "other_rooflines": other_rooflines(prof, pipe, args),
-            "stats": {"keypoints_per_image": float(out["cnt"].mean()), "lr_matches": float(out["nlr"].mean()),
-                      "f2f_matches": float(out["nf2f"][:max(B - 1, 1)].mean()), "pnp_points": float(out["pn"][:max(B - 1, 1)].mean()),
-                      "pnp_inliers": float(out["ninl"][:max(B - 1, 1)].mean())},
+            "kernels_ms_per_step": {k: round(v[0] / n_timed_steps, 4) for k, v in kern},
+            "other_rooflines": other_rooflines(prof, pipe, args, n_timed_steps, copy_gbs),
+            "stats": {"keypoints_per_image": float(out["cnt"].mean()), "lr_matches": float(out["nlr"].mean()), "lr_matches_min": int(out["nlr"].min()),
+                      "f2f_matches": float(out["nf2f"][:nt].mean()), "pnp_points": float(out["pn"][:nt].mean()), "pnp_points_min": int(out["pn"][:nt].min()),
+                      "pnp_inliers": float(out["ninl"][:nt].mean()), "pnp_inliers_min": int(out["ninl"][:nt].min()),
+                      "orb_status_nonzero": orb_bad, "ba_status_nonzero": ba_bad},
         }
-        if world == 1 and not args.no_cpu_baseline and not args.no_ba and args.depth == "match":
-            res["cpu_baseline"] = cpu_baseline(pipe, args.anms)
+        if seq_mode and chained[0] is not None:
+            res["trajectory"] = {"frames": int(len(chained[0])), "final_position": [float(x) for x in sharding.camera_centre(chained[0][-1])]}
+        if world == 1 and not args.no_cpu_baseline and not args.no_ba and args.depth == "match" and not seq_mode:
+            res["cpu_baseline"], res["pose_rmse_vs_oracle"] = cpu_baseline(pipe, out, args.anms)
         print(json.dumps(res), flush=True)
     pipe.close()
     if world > 1:

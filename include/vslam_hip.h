@@ -272,6 +272,10 @@ typedef struct vslam_kernel_time {
 int vslam_profile_enable(vslam_ctx* ctx, int on);
 int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_out);
 
+/* Measurement aid: a float4 streaming copy of `bytes` (read + write), `reps` launches timed with hipEvents on the context
+ * stream; *gbs_out = moved GB/s.  The achievable-bandwidth figure reported next to the 8 TB/s HBM spec. */
+int vslam_hbm_copy_probe(vslam_ctx* ctx, size_t bytes, int reps, double* gbs_out);
+
 /* ------------------------------------------------------------------ raw device memory helpers ---------- */
 /* For hosts without their own device allocator (the C++ mirror in host/); bench.py passes torch tensors. */
 int vslam_dev_alloc(void** p, size_t bytes);

@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
-    "vslam_profile_enable", "vslam_profile_read", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_find_3d_disparity_dev",
+    "vslam_profile_enable", "vslam_profile_read", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_find_3d_disparity_dev",
 ]
 
 
@@ -361,6 +361,12 @@ class VO:
         buf = (KernelTime * 32)(); n = C.c_int()
         self._chk(self.lib.vslam_profile_read(self.h, buf, 32, C.byref(n)), "vslam_profile_read")
         return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches, buf[i].calls) for i in range(n.value)}
+
+    def hbm_copy_probe(self, nbytes=1 << 30, reps=5):
+        """GB/s (read + write) of a float4 streaming copy on this GPU, timed on the context stream"""
+        g = C.c_double()
+        self._chk(self.lib.vslam_hbm_copy_probe(self.h, C.c_size_t(nbytes), int(reps), C.byref(g)), "vslam_hbm_copy_probe")
+        return g.value
 
     def ba_status(self, n_windows):
         st = np.zeros(n_windows, np.int32)

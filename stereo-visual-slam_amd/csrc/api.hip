@@ -871,6 +871,35 @@ int vslam_build_pnp_inputs_dev(vslam_ctx* ctx, const vslam_dmatch* d_f2f, const 
                                    d_kp2lr, d_xyz_out, d_uv_out, d_nout, out_capacity, c->stream);
 }
 
+// float4 streaming copy of `bytes` (src -> dst, both allocated here), `reps` timed launches after one warm-up, hipEvents on the
+// context stream: *gbs_out = (bytes read + bytes written) / time.  The achievable-HBM figure bench.py reports next to the spec peak.
+int vslam_hbm_copy_probe(vslam_ctx* ctx, size_t bytes, int reps, double* gbs_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !gbs_out || bytes < (1u << 20) || reps <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
+    bytes &= ~(size_t)15;
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = VSLAM_OK;
+    float ms = 0.f;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        set_error("copy probe: allocation failed"); rc = VSLAM_ERR_HIP;
+    } else {
+        (void)hipMemsetAsync(a, 1, bytes, c->stream);
+        rc = launch_hbm_copy_probe(a, b, bytes, c->stream);
+        (void)hipEventRecord(e0, c->stream);
+        for (int r = 0; r < reps && rc == VSLAM_OK; ++r) rc = launch_hbm_copy_probe(a, b, bytes, c->stream);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { set_error("copy probe: timing failed"); rc = VSLAM_ERR_HIP; }
+    }
+    if (rc == VSLAM_OK) *gbs_out = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------- raw device memory helpers
 // (for hosts that do not bring their own allocator; bench.py uses torch tensors instead)
 int vslam_dev_alloc(void** p, size_t bytes) { if (!p) return VSLAM_ERR_ARG; VS_HIP(hipMalloc(p, bytes)); return VSLAM_OK; }

@@ -141,6 +141,8 @@ int launch_build_pnp_inputs(const vslam_dmatch* d_m, const int32_t* d_nm, int ma
 int launch_gather_uv(const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT, int kp_capacity, const vslam_dmatch* d_m,
                      const int32_t* d_nm, int match_capacity, int B, float* d_uvQ, float* d_uvT, hipStream_t stream);
 
+int launch_hbm_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t stream);
+
 // ----------------------------------------------------------------------------------------------- LM
 struct LmWindowArgs {
     int n_windows, n_kf;

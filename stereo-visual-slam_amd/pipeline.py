@@ -19,10 +19,15 @@ from . import synth
 
 
 class KeyframePipeline:
-    def __init__(self, B, device=0, anms_num=1500, n_lm=3000, n_kf=10, unique_scenes=4, unique_windows=4, seed=0, verbose=False,
-                 with_ba=True, depth="match"):
+    def __init__(self, B, device=0, anms_num=1500, n_lm=3000, n_kf=10, unique_frames=64, unique_windows=None, seed=0, verbose=False,
+                 with_ba=True, depth="match", frame_range=None):
         """depth = "match": north_star stage (right-image ORB, L/R match, DLT); "sgbm": the reference's own depth path
-        (VO::disparity_map + Frame::find_3d on the left keypoints; the right image is only consumed by SGBM)"""
+        (VO::disparity_map + Frame::find_3d on the left keypoints; the right image is only consumed by SGBM).
+        Inputs: ONE rendered sequence of `unique_frames` consecutive stereo keyframes, laid over the batch as a ping-pong
+        (0, 1, ..., n-1, n-2, ..., 1, 0, 1, ...), so that every item b >= 1 and its predecessor are adjacent frames of the same
+        scene (driving the sequence backwards is as valid a frame-to-frame pair as driving it forwards); `unique_windows` BA
+        windows (default: one per batch item).  frame_range = (first, last + 1, F): sequence mode -- the batch is the contiguous
+        chunk [first, last] of an F-frame sequence (frame f shows ping-pong frame f of the SAME rendered scene on every rank)."""
         assert depth in ("match", "sgbm")
         self.depth = depth
         self.B = B
@@ -41,18 +46,24 @@ class KeyframePipeline:
         d = self.dev
         # ---- inputs: 2B images [left 0..B-1 | right 0..B-1]; consecutive keyframes of `unique_scenes` short sequences
         imgs = np.zeros((2 * B, self.h, self.pitch), np.uint8)
-        per = 4  # frames per rendered sequence; the batch tiles `unique_scenes` sequences of `per` consecutive keyframes
-        seqs = {}
+        n_u = max(2, min(unique_frames, B if frame_range is None else int(frame_range[2]))) if (B > 1 or frame_range is not None) else 1
+        seq = synth.stereo_sequence(n_u, seed=seed, w=self.w, h=self.h)
+        if verbose:
+            print("rendered %d stereo keyframes" % n_u, flush=True)
+        period = max(2 * (n_u - 1), 1)
+        f0 = 0
+        if frame_range is not None:
+            f0 = int(frame_range[0])
+            assert int(frame_range[1]) - f0 == B
+        self.frame_of = [(t if t < n_u else period - t) for t in ((f0 + b) % period for b in range(B))]
         for b in range(B):
-            s, f = (b // per) % unique_scenes, b % per
-            if s not in seqs:
-                seqs[s] = synth.stereo_sequence(per, seed=seed + s, w=self.w, h=self.h)
-                if verbose:
-                    print("rendered sequence", s, flush=True)
-            L, R, _, _ = seqs[s][f]
+            L, R, _, _ = seq[self.frame_of[b]]
             imgs[b, :, :self.w] = L
             imgs[B + b, :, :self.w] = R
+        self.unique_frames = n_u
         self.h_imgs = imgs
+        self.h_imgs_unique_left = np.stack([np.pad(f[0], ((0, 0), (0, self.pitch - self.w))) for f in seq])
+        self.h_imgs_unique_right = np.stack([np.pad(f[1], ((0, 0), (0, self.pitch - self.w))) for f in seq])
         self.d_imgs = torch.from_numpy(imgs).to(d)
         # ---- ORB outputs
         self.d_kps = torch.zeros((2 * B, self.cap, 28), dtype=torch.uint8, device=d)
@@ -87,7 +98,11 @@ class KeyframePipeline:
         self.d_ninl = torch.zeros(B, dtype=torch.int32, device=d)
         # ---- local-BA windows
         if with_ba:
-            wins = [synth.ba_window(n_kf=n_kf, n_lm=n_lm, seed=seed + 100 + i) for i in range(unique_windows)]
+            unique_windows = B if unique_windows is None else max(1, min(unique_windows, B))
+            self.unique_windows = unique_windows
+            self.window_seed0 = seed + 100
+            wins = [synth.ba_window_fast(n_kf=n_kf, n_lm=n_lm, seed=self.window_seed0 + i) for i in range(unique_windows)]
+            self.h_windows = wins
             lm_off, e_off = [0], [0]
             T0, xyz, kf, lm, uv = [], [], [], [], []
             for b in range(B):
@@ -106,6 +121,7 @@ class KeyframePipeline:
             self.ba_inl = torch.ones(lm_off[-1], dtype=torch.uint8, device=d)
             self.ba_chi2 = torch.zeros(e_off[-1], dtype=torch.float64, device=d)
             self.total_lm, self.total_edge = lm_off[-1], e_off[-1]
+            self.h_lm_off = np.array(lm_off, np.int64)
             self.edges_per_window = e_off[-1] / B
             self.lms_per_window = lm_off[-1] / B
             bb = BaBatch()

@@ -300,6 +300,39 @@ def ba_window(n_kf=10, n_lm=3000, seed=2, sigma_px=0.5, outlier_frac=0.05, pose_
     return dict(T_true=T_true, T0=T0, xyz=xyz, kf_idx=kf_idx, lm_idx=lm_idx, uv=uv.astype(np.float32), outlier=is_out)
 
 
+def ba_window_fast(n_kf=10, n_lm=3000, seed=2, sigma_px=0.5, outlier_frac=0.05, pose_sigma=0.02, min_obs=2, max_obs=5):
+    """same construction as ba_window, vectorised over the landmarks so that a bench can afford one
+    UNIQUE window per batch item; a different random stream than ba_window (not interchangeable seed for seed)."""
+    rng = np.random.default_rng(seed)
+    Rwc = np.eye(3); p = np.zeros(3)
+    Rs, ts = [], []
+    for k in range(n_kf):
+        Rs.append(Rwc.T.copy()); ts.append(-Rwc.T @ p)
+        Rwc = Rwc @ rot_y(0.02); p = p + Rwc @ np.array([0, 0, 1.0])
+    Rs = np.array(Rs); ts = np.array(ts)
+    T_true = np.array([se3_from_Rt(Rs[k], ts[k]) for k in range(n_kf)])
+    nobs = rng.integers(min_obs, max_obs + 1, n_lm)
+    k0 = (rng.random(n_lm) * (n_kf - nobs + 1)).astype(np.int64)
+    order = np.argsort(k0, kind="stable")  # landmark ids follow creation order (first observing keyframe)
+    nobs, k0 = nobs[order], k0[order]
+    km = k0 + nobs // 2
+    Z = rng.uniform(10, 40, n_lm); u = rng.uniform(150, W_KITTI - 150, n_lm); v = rng.uniform(60, H_KITTI - 60, n_lm)
+    pc = np.stack([(u - CX) / FX * Z, (v - CY) / FY * Z, Z], 1)
+    xyz = np.einsum("nij,nj->ni", np.transpose(Rs[km], (0, 2, 1)), pc - ts[km]).astype(np.float32)  # R^T (pc - t)
+    lm_idx = np.repeat(np.arange(n_lm), nobs)
+    kf_idx = (np.repeat(k0, nobs) + (np.arange(len(lm_idx)) - np.repeat(np.cumsum(nobs) - nobs, nobs))).astype(np.int64)
+    pw = xyz[lm_idx].astype(np.float64)
+    pcam = np.einsum("nij,nj->ni", Rs[kf_idx], pw) + ts[kf_idx]
+    keep = pcam[:, 2] >= 1.0
+    kf_idx, lm_idx, pcam = kf_idx[keep], lm_idx[keep], pcam[keep]
+    uv = np.stack([FX * pcam[:, 0] / pcam[:, 2] + CX, FY * pcam[:, 1] / pcam[:, 2] + CY], 1)
+    uv = uv + rng.normal(0, sigma_px, uv.shape)
+    is_out = rng.random(len(uv)) < outlier_frac
+    uv[is_out] += rng.uniform(-30, 30, (int(is_out.sum()), 2))
+    T0 = np.array([perturb_pose(T, rng, pose_sigma) for T in T_true])
+    return dict(T_true=T_true, T0=T0, xyz=xyz, kf_idx=kf_idx.astype(np.int32), lm_idx=lm_idx.astype(np.int32), uv=uv.astype(np.float32), outlier=is_out)
+
+
 # --------------------------------------------------------------------------- dataset on disk (C++ driver)
 def write_pgm(path, img):
     with open(path, "wb") as f:

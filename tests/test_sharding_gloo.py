@@ -55,3 +55,94 @@ def test_two_rank_pose_gather():
         assert allp.shape == (total, 7) and np.array_equal(allp, want)
         assert np.array_equal(eq, np.repeat(np.arange(world, dtype=np.float64), 3)[:, None] * np.ones((1, 7)))
         assert tmax == float(world)
+
+
+# ---------------------------------------------------------------------------------------------- sequence mode (BASELINE config 5)
+def _rel_pose(j):
+    """deterministic relative pose T_{j,j-1} of global frame j (forward ~1 m, small yaw/pitch), numpy (7,)"""
+    rng = np.random.default_rng(1000 + j)
+    w = rng.normal(0, 0.03, 3); th = np.linalg.norm(w)
+    q = np.concatenate([np.sin(th / 2) * w / th, [np.cos(th / 2)]])
+    return np.concatenate([q, rng.normal(0, 0.05, 3) + np.array([0, 0, -1.0])])
+
+
+def _chain_reference(F):
+    """plain sequential chaining T_j = T_{j,j-1} T_{j-1} in numpy, the definition the scan must reproduce"""
+    def mul(A, B):
+        ax, ay, az, aw = A[:4]; bx, by, bz, bw = B[:4]
+        q = np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+        x, y, z, w = A[:4]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        return np.concatenate([q / np.linalg.norm(q), R @ B[4:] + A[4:]])
+    T = [np.array([0, 0, 0, 1, 0, 0, 0.0])]
+    for j in range(1, F):
+        T.append(mul(_rel_pose(j), T[-1]))
+    return np.array(T)
+
+
+def test_halo_and_owned_ranges():
+    from stereo_visual_slam_amd.sharding import halo_start, owned_pose_range, shard_range
+    for F in (2, 7, 50, 4541):
+        for world in (1, 2, 3, 8):
+            if F < 2 * world:
+                continue
+            covered = []
+            for r in range(world):
+                lo, hi = shard_range(F, r, world)
+                h = halo_start(lo)
+                assert h == (lo - 1 if lo > 0 else 0)
+                produced = list(range(h + 1, hi))          # a rank that processes frames [h, hi) estimates T_{j,j-1} for j = h+1 .. hi-1
+                assert produced == list(range(*owned_pose_range(F, r, world)))
+                covered += produced
+            assert covered == list(range(1, F))             # every relative pose exactly once, in frame order
+
+
+def test_chain_poses_scan_equals_sequential():
+    from stereo_visual_slam_amd.sharding import chain_poses
+    for F in (2, 3, 17, 50, 129):
+        rel = torch.tensor(np.array([_rel_pose(j) for j in range(1, F)]), dtype=torch.float64)
+        got = chain_poses(rel).numpy(); want = _chain_reference(F)
+        assert got.shape == (F, 7) and np.allclose(got, want, rtol=0, atol=1e-12)
+
+
+def _seq_worker(rank, world, port, F, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stereo_visual_slam_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(F, rank, world)
+        h = sharding.halo_start(lo)
+        # what the per-rank pipeline produces: one relative pose per processed frame except the first (halo or frame 0)
+        local = torch.tensor(np.array([_rel_pose(j) for j in range(h + 1, hi)]).reshape(-1, 7), dtype=torch.float64)
+        traj = sharding.gather_and_chain(local, F, dist, world, rank)
+        q.put((rank, None if traj is None else traj.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_seq(world, F):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, F, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_sequence_sharding_two_and_three_ranks_match_single_rank():
+    """config 5 host logic with injected poses: contiguous chunks + 1-frame halo, ragged gather, chaining on rank 0 == the
+    single-rank trajectory of the same 50-frame sequence"""
+    F = 50
+    want = _chain_reference(F)
+    for world in (2, 3):
+        res = _run_seq(world, F)
+        assert all(res[r] is None for r in range(1, world))
+        assert res[0].shape == (F, 7) and np.allclose(res[0], want, rtol=0, atol=1e-12)
