@@ -182,13 +182,14 @@ int vslam_pnp_motion_only(vslam_ctx* ctx, const float* xyz_w, const float* uv, i
 int vslam_pnp_motion_only_dev(vslam_ctx* ctx, const float* d_xyz_w, const float* d_uv, const int32_t* d_n, int capacity, int B,
                               double* d_T_c_w, int iters, uint8_t* d_inlier, int32_t* d_n_inliers);
 
-/* RANSAC in front of the motion-only stage: the control flow of cv::solvePnPRansac(pts3d, pts2d, K, Mat(), rvec, tvec,
- * false, 100, 4.0, 0.99, inliers) at visual_odometry.cpp:277 -- OpenCV's RNG (seed (uint64)-1, multiply-with-carry) and
- * 5-point subset draw, the strict "more inliers than max(best, 4)" acceptance, RANSACUpdateNumIters, refinement on the
- * inliers of the best model, mask = RANSAC mask.  All `max_iters` hypotheses are solved and scored in parallel on the device
- * (they do not depend on each other); the adaptive stopping rule is then replayed over the counts in order, so the result is
- * that of the sequential loop.  Deviations from OpenCV (minimal solver = least-squares LM from T_c_w instead of EPnP; f64
- * reprojection errors) are listed in oracle/ransac.c.  T_c_w in: pose guess, out: refined pose (untouched on failure).
+/* The reference's own pose stage: cv::solvePnPRansac(pts3d, pts2d, K, Mat(), rvec, tvec, false, 100, 4.0, 0.99, inliers) at
+ * visual_odometry.cpp:277 -- OpenCV's RNG (seed (uint64)-1, multiply-with-carry) and 5-point subset draw, EPnP on every subset
+ * from scratch (no pose guess: useExtrinsicGuess = false), f32 squared reprojection errors against (float)(reproj_err^2), the
+ * strict "more inliers than max(best, 4)" acceptance, RANSACUpdateNumIters, refinement on the inliers of the best model, mask =
+ * RANSAC mask.  All `max_iters` hypotheses are solved (one wave each) and scored in parallel on the device (they do not depend on
+ * each other); the adaptive stopping rule is then replayed over the counts in order, so the result is that of the sequential loop.
+ * Remaining deviations from OpenCV (the final refinement is this library's least-squares LM, not CvLevMarq; the eigen-solver's
+ * basis for the null space of the 5-point system) are listed in oracle/ransac.c / epnp.c.  T_c_w: OUTPUT only (untouched on failure).
  * Returns VSLAM_OK; *n_inliers = 0 means RANSAC found no model (reference: solvePnPRansac returns false). */
 int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters,
                      double reproj_err, double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run);

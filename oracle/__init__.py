@@ -29,7 +29,7 @@ class OrbLayout(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orb.c", "match.c", "geom.c", "lm.c", "sgbm.c", "ransac.c", "vo_oracle.h", "orb_pattern.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb.c", "match.c", "geom.c", "lm.c", "sgbm.c", "ransac.c", "epnp.c", "cpu_shim.c", "vo_oracle.h", "orb_pattern.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -356,9 +356,32 @@ def ransac_update_num_iters(p, ep, model_points, max_iters):
     return f(p, ep, model_points, max_iters)
 
 
-def pnp_ransac(xyz, uv, T0, K=K_KITTI, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+def epnp(xyz, uv, K=K_KITTI):
+    """EPnP pose (R 3x3, t 3, mean reprojection error) of n >= 4 correspondences; err < 0: degenerate"""
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
-    T = _d(T0, 7).copy(); inl = np.zeros(max(len(xyz), 1), np.uint8); it = C.c_int()
+    R = np.zeros(9); t = np.zeros(3)
+    f = lib().vo_epnp; f.restype = C.c_double
+    err = f(_p(xyz), _p(uv), len(xyz), _p(_d(K, 4)), _p(R), _p(t))
+    return R.reshape(3, 3), t, err
+
+
+def jacobi_eig12(A):
+    A = np.ascontiguousarray(A, np.float64).reshape(12, 12).copy(); V = np.zeros((12, 12))
+    lib().vo_jacobi_eig12(_p(A), _p(V))
+    return np.diag(A).copy(), V
+
+
+def pnp_ransac_hypothesis(xyz, uv, it, K=K_KITTI, reproj_err=4.0):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    T = np.zeros(7); sub = np.zeros(5, np.int32)
+    n = lib().vo_pnp_ransac_hypothesis(_p(xyz), _p(uv), len(xyz), _p(_d(K, 4)), int(it), C.c_double(reproj_err), _p(T), _p(sub))
+    return T, n, sub
+
+
+def pnp_ransac(xyz, uv, T0=None, K=K_KITTI, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+    """T0 is ignored (kept for call compatibility): like the reference's call, no pose guess is consumed"""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    T = np.array([0, 0, 0, 1, 0, 0, 0], np.float64) if T0 is None else _d(T0, 7).copy(); inl = np.zeros(max(len(xyz), 1), np.uint8); it = C.c_int()
     n = lib().vo_pnp_ransac(_p(xyz), _p(uv), len(xyz), _p(_d(K, 4)), _p(T), int(max_iters), C.c_double(reproj_err), C.c_double(confidence),
                             int(lm_iters), _p(inl), C.byref(it))
     return T, inl[:len(xyz)], n, it.value

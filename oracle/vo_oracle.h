@@ -200,8 +200,16 @@ int vo_pnp_motion_only(const float* xyz_w, const float* uv, int n, const double 
  * for the restated control flow (RNG, subset draw, acceptance rule, adaptive iteration count) and the documented deviations. */
 int vo_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
 int vo_ransac_subsets(int count, int model_points, int max_iters, int32_t* subsets);
-int vo_pnp_ransac(const float* xyz_w, const float* uv, int n, const double K[4], double T_c_w[7], int max_iters, double reproj_err,
+int vo_pnp_ransac(const float* xyz_w, const float* uv, int n, const double K[4], double T_c_w[7] /* out */, int max_iters, double reproj_err,
                   double confidence, int lm_iters, uint8_t* inlier, int* iters_run);
+int vo_pnp_ransac_hypothesis(const float* xyz_w, const float* uv, int n, const double K[4], int it, double reproj_err, double T[7], int32_t subset[5]);
+
+/* EPnP (the minimal solver of solvePnPRansac; OpenCV 3.2 modules/calib3d/src/epnp.cpp restated, see epnp.c).  R row-major 3 x 3,
+ * t: world -> camera.  Returns the mean reprojection error of the chosen candidate, < 0 for a degenerate configuration. */
+double vo_epnp(const float* xyz, const float* uv, int n, const double K4[4], double R[9], double t[3]);
+void vo_jacobi_eig12(double* A /* 12 x 12 symmetric, destroyed: eigenvalues on the diagonal */, double* V /* eigenvectors in columns */);
+void vo_jacobi_eig3(double* A, double* V);
+void vo_rotmat_to_quat(const double R[9], double q[4]);
 
 #ifdef __cplusplus
 }

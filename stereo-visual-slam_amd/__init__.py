@@ -289,11 +289,12 @@ class VO:
                                                        int(match_cap), int(B), _p(d_uvQ), _p(d_uvT)), "vslam_gather_matched_uv_dev")
 
     # ------------------------------------------------------------ VO::motion_estimation (north_star motion-only stage)
-    def motion_estimation_ransac(self, xyz_w, uv, T_guess, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
-        """RANSAC front of VO::motion_estimation (cv::solvePnPRansac(..., 100, 4.0, 0.99), visual_odometry.cpp:277).
+    def motion_estimation_ransac(self, xyz_w, uv, T_init=None, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+        """VO::motion_estimation's pose stage (cv::solvePnPRansac(..., false, 100, 4.0, 0.99), visual_odometry.cpp:277): EPnP per
+        5-point hypothesis, no pose guess is consumed (T_init only pre-fills the output, which stays untouched on failure).
         Returns (T, inlier mask, n_inliers, iterations evaluated); n_inliers == 0 means no model was found."""
         xyz = np.ascontiguousarray(xyz_w, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
-        T = np.ascontiguousarray(T_guess, np.float64).copy(); n = len(xyz)
+        T = np.array([0, 0, 0, 1, 0, 0, 0], np.float64) if T_init is None else np.ascontiguousarray(T_init, np.float64).copy(); n = len(xyz)
         inl = np.zeros(max(n, 1), np.uint8); ni = C.c_int(); it = C.c_int()
         self._chk(self.lib.vslam_pnp_ransac(self.h, _p(xyz), _p(uv), n, _p(T), int(max_iters), C.c_double(reproj_err), C.c_double(confidence),
                                             int(lm_iters), _p(inl), C.byref(ni), C.byref(it)), "vslam_pnp_ransac")

@@ -158,7 +158,7 @@ const char* vslam_version(void) { return "vslam_hip 0.1 (gfx950)"; }
 const char* vslam_kernel_names(void) {
     return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_blur_kernel orb_describe_kernel match_expand_kernel match_train_nearest_kernel "
            "match_finalize_kernel sgbm_prefilter_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel sgbm_lrcheck_kernel "
-           "sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel sgbm_ccl_apply_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel pnp_hypothesis_count_kernel";
+           "sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel sgbm_ccl_apply_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel";
 }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
@@ -619,17 +619,18 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
     if (n_inliers) *n_inliers = 0;
     if (iters_run) *iters_run = 0;
     if (inlier && n > 0) memset(inlier, 0, (size_t)n);
-    const int mp = 5, H = max_iters;
-    if (n < mp || H == 0) return VSLAM_OK;
+    const int mp = 5;
+    if (n < mp || max_iters == 0) return VSLAM_OK;
     VS_ENTER(c);
+    const bool single = n == mp;          // ptsetreg.cpp: count == modelPoints -> one model from all points, every point an inlier
+    const int H = single ? 1 : max_iters;
     // 1. the subset sequence (host: a few hundred RNG draws)
     std::vector<float> hx((size_t)H * mp * 3), hu((size_t)H * mp * 2);
-    std::vector<double> hT((size_t)H * 7);
-    std::vector<int32_t> hn((size_t)H, mp);
     uint64_t state = 0xFFFFFFFFFFFFFFFFULL;
     for (int it = 0; it < H; ++it) {
         int idx[5];
-        for (int i = 0; i < mp; ++i)
+        for (int i = 0; i < mp; ++i) {
+            if (single) { idx[i] = i; continue; }
             for (;;) {
                 const int v = (int)(cv_rng_next(state) % (unsigned)n);
                 int j = 0;
@@ -637,56 +638,55 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
                 idx[i] = v;
                 if (j == i) break;
             }
+        }
         for (int i = 0; i < mp; ++i) {
             memcpy(&hx[((size_t)it * mp + i) * 3], xyz_w + 3 * (size_t)idx[i], 12);
             memcpy(&hu[((size_t)it * mp + i) * 2], uv + 2 * (size_t)idx[i], 8);
         }
-        memcpy(&hT[(size_t)it * 7], T_c_w, 56);
     }
     int rc;
-    if ((rc = arena_reserve(c, al256(hx.size() * 4) + al256(hu.size() * 4) + al256(hT.size() * 8) + 2 * al256((size_t)H * 4) + 2 * al256(12 * (size_t)n) +
-                                   2 * al256(8 * (size_t)n) + 2 * al256(n) + 4096))) return rc;
+    if ((rc = arena_reserve(c, al256(hx.size() * 4) + al256(hu.size() * 4) + al256((size_t)H * 96) + al256((size_t)H * 56) + 2 * al256((size_t)H * 4) +
+                                   2 * al256(12 * (size_t)n) + 2 * al256(8 * (size_t)n) + 2 * al256(n) + 4096))) return rc;
     Arena ar(c);
     float* d_hx = arena_take<float>(ar, hx.size()); float* d_hu = arena_take<float>(ar, hu.size());
-    double* d_hT = arena_take<double>(ar, hT.size()); int32_t* d_hn = arena_take<int32_t>(ar, H); int32_t* d_cnt = arena_take<int32_t>(ar, H);
+    double* d_Rt = arena_take<double>(ar, (size_t)H * 12); double* d_hT = arena_take<double>(ar, (size_t)H * 7);
+    int32_t* d_ok = arena_take<int32_t>(ar, H); int32_t* d_cnt = arena_take<int32_t>(ar, H);
     float* d_x = arena_take<float>(ar, 3 * (size_t)n); float* d_u = arena_take<float>(ar, 2 * (size_t)n);
     float* d_ix = arena_take<float>(ar, 3 * (size_t)n); float* d_iu = arena_take<float>(ar, 2 * (size_t)n);
     uint8_t* d_mask = arena_take<uint8_t>(ar, n); double* d_T = arena_take<double>(ar, 7); int32_t* d_n1 = arena_take<int32_t>(ar, 2);
     VS_HIP(hipMemcpyAsync(d_hx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_hu, hu.data(), hu.size() * 4, hipMemcpyHostToDevice, c->stream));
-    VS_HIP(hipMemcpyAsync(d_hT, hT.data(), hT.size() * 8, hipMemcpyHostToDevice, c->stream));
-    VS_HIP(hipMemcpyAsync(d_hn, hn.data(), (size_t)H * 4, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_x, xyz_w, 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_u, uv, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    // 2. every hypothesis: least-squares LM on its 5 points (no robust kernel), then its inlier count over all points
-    PnpArgs p;
-    memset(&p, 0, sizeof(p));
-    p.xyz = d_hx; p.uv = d_hu; p.n = d_hn; p.capacity = mp; p.B = H; p.T = d_hT; p.iters = lm_iters;
-    fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err;
-    if ((rc = launch_pnp(p, &c->lm, c->stream))) return rc;
-    if ((rc = launch_pnp_hypothesis_count(d_x, d_u, n, d_hT, H, p.K, reproj_err, d_cnt, c->stream))) return rc;
-    std::vector<int32_t> cnt(H);
-    VS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
+    // 2. every hypothesis: EPnP on its 5 points (one wave each), then its inlier count over all points
+    double K[4];
+    fill_K(c, K);
+    if ((rc = launch_pnp_epnp(d_hx, d_hu, H, K, d_Rt, d_hT, d_ok, c->stream))) return rc;
+    std::vector<int32_t> cnt(H), okv(H);
+    if (!single && (rc = launch_pnp_count_inliers(d_x, d_u, n, d_Rt, d_ok, 0, H, K, reproj_err, d_cnt, nullptr, c->stream))) return rc;
+    if (!single) VS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(okv.data(), d_ok, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
     // 3. replay of the sequential loop over the counts (ptsetreg.cpp: strict improvement, adaptive iteration count)
-    int best = -1, max_good = 0, niters = H, it = 0;
-    for (it = 0; it < niters; ++it)
-        if (cnt[it] > std::max(max_good, mp - 1)) {
-            best = it; max_good = cnt[it];
-            niters = ransac_update_num_iters(confidence, (double)(n - max_good) / n, mp, niters);
-        }
+    int best = -1, max_good = 0, it = 0;
+    if (single) { if (okv[0]) { best = 0; max_good = n; } }
+    else {
+        int niters = H;
+        for (it = 0; it < niters; ++it)
+            if (okv[it] && cnt[it] > std::max(max_good, mp - 1)) {
+                best = it; max_good = cnt[it];
+                niters = ransac_update_num_iters(confidence, (double)(n - max_good) / n, mp, niters);
+            }
+    }
     if (iters_run) *iters_run = it;
     if (best < 0) return VSLAM_OK;
-    // 4. mask of the best model, refinement on its inliers
-    std::vector<uint8_t> mask(n);
-    int32_t nn = n;
-    VS_HIP(hipMemcpyAsync(d_n1, &nn, 4, hipMemcpyHostToDevice, c->stream));
-    memset(&p, 0, sizeof(p));
-    p.xyz = d_x; p.uv = d_u; p.n = d_n1; p.capacity = n; p.B = 1; p.T = d_hT + 7 * (size_t)best; p.iters = 0;
-    fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err; p.inlier = d_mask; p.n_inliers = d_n1 + 1;
-    if ((rc = launch_pnp(p, &c->lm, c->stream))) return rc; // (0 LM iterations: only the inlier test at the hypothesis pose)
-    VS_HIP(hipMemcpyAsync(mask.data(), d_mask, n, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipStreamSynchronize(c->stream));
+    // 4. mask of the best model, refinement on its inliers (solvePnP on the inliers; deviation R2 of oracle/ransac.c)
+    std::vector<uint8_t> mask(n, 1);
+    if (!single) {
+        if ((rc = launch_pnp_count_inliers(d_x, d_u, n, d_Rt, d_ok, best, 1, K, reproj_err, nullptr, d_mask, c->stream))) return rc;
+        VS_HIP(hipMemcpyAsync(mask.data(), d_mask, n, hipMemcpyDeviceToHost, c->stream));
+        VS_HIP(hipStreamSynchronize(c->stream));
+    }
     std::vector<float> ix, iu;
     for (int i = 0; i < n; ++i) if (mask[i]) { ix.insert(ix.end(), xyz_w + 3 * (size_t)i, xyz_w + 3 * (size_t)i + 3); iu.insert(iu.end(), uv + 2 * (size_t)i, uv + 2 * (size_t)i + 2); }
     const int m = (int)(iu.size() / 2);
@@ -694,8 +694,9 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
     VS_HIP(hipMemcpyAsync(d_ix, ix.data(), ix.size() * 4, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_iu, iu.data(), iu.size() * 4, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_T, d_hT + 7 * (size_t)best, 56, hipMemcpyDeviceToDevice, c->stream));
-    nn = m;
+    int32_t nn = m;
     VS_HIP(hipMemcpyAsync(d_n1, &nn, 4, hipMemcpyHostToDevice, c->stream));
+    PnpArgs p;
     memset(&p, 0, sizeof(p));
     p.xyz = d_ix; p.uv = d_iu; p.n = d_n1; p.capacity = m; p.B = 1; p.T = d_T; p.iters = lm_iters;
     fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err;

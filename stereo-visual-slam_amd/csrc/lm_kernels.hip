@@ -1346,38 +1346,6 @@ __global__ __launch_bounds__(256) void pnp_inlier_kernel(const float* __restrict
     if (threadIdx.x == 0 && n_inl) n_inl[b] = cnt;
 }
 
-// RANSAC scoring: inliers of ALL hypotheses over one shared point set (block = hypothesis); same test as above
-__global__ __launch_bounds__(256) void pnp_hypothesis_count_kernel(const float* __restrict__ xyz, const float* __restrict__ uv, int n,
-                                                                  const double* __restrict__ d_T, const double K0, const double K1, const double K2,
-                                                                  const double K3, double thr2, int32_t* __restrict__ counts) {
-    const int hyp = blockIdx.x;
-    __shared__ double Rt[12];
-    __shared__ int cnt;
-    if (threadIdx.x == 0) { expand_pose(d_T + 7 * hyp, Rt); cnt = 0; }
-    __syncthreads();
-    const double K[4] = {K0, K1, K2, K3};
-    int mine = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        double X, Y, Z, ex, ey;
-        project_err(Rt, K, (double)xyz[3 * i], (double)xyz[3 * i + 1], (double)xyz[3 * i + 2], uv[2 * i], uv[2 * i + 1], X, Y, Z, ex, ey);
-        const double c = ex * ex + ey * ey;
-        mine += isfinite(c) && c <= thr2;
-    }
-    atomicAdd(&cnt, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) counts[hyp] = cnt;
-}
-
-int launch_pnp_hypothesis_count(const float* d_xyz, const float* d_uv, int n, const double* d_T, int n_hyp, const double K[4], double reproj_thr,
-                                int32_t* d_counts, hipStream_t stream) {
-    if (n_hyp <= 0) return VSLAM_OK;
-    ProfScope prof__(stream, "pnp_hypothesis_count_kernel");
-    hipLaunchKernelGGL(pnp_hypothesis_count_kernel, dim3(n_hyp), dim3(256), 0, stream, d_xyz, d_uv, n, d_T, K[0], K[1], K[2], K[3], reproj_thr * reproj_thr,
-                       d_counts);
-    VS_HIP(hipGetLastError());
-    return VSLAM_OK;
-}
-
 // (LmScratch, owned by the context and grown on demand, is declared in vslam_internal.h)
 static int ensure(void** p, size_t* have, size_t need) {
     if (*have >= need) return VSLAM_OK;

@@ -1,0 +1,426 @@
+// pnp_kernels.hip -- the minimal solver and the scoring of the RANSAC pose stage.
+//
+// Replaces what cv::solvePnPRansac(pts3d, pts2d, K, Mat(), rvec, tvec, false, 100, 4.0, 0.99, inliers) does per hypothesis
+// (/root/reference/src/stereo_visual_slam_main/visual_odometry.cpp:277): OpenCV 3.2 solves every 5-point subset with EPnP
+// (solvepnp.cpp: SOLVEPNP_EPNP for more than four points; epnp.cpp = Lepetit / Moreno-Noguer / Fua 2009) and counts the points
+// whose f32 squared reprojection error is <= (float)(4 * 4) (PnPRansacCallback::computeError, ptsetreg.cpp findInliers).
+//
+// gfx950 mapping: the hypotheses do not depend on each other, so ALL of them are solved at once, ONE WAVE PER HYPOTHESIS:
+//   - the 12 x 12 symmetric eigenproblem of M^T M (the only O(n^3) piece) runs wave-parallel in LDS: cyclic Jacobi with a
+//     round-robin ordering, 6 disjoint rotations per round, three element-parallel phases (J^T A, (.) J, V J) of 144 elements
+//     over the 64 lanes;
+//   - the small sequential algebra around it (3 x 3 eigenproblems, 6 x {3,4,5} least squares, five Gauss-Newton steps on the
+//     betas, absolute orientation) is done by lane 0.
+// Every floating-point operation is performed in the same order as the CPU oracle's restatement, with IEEE division / sqrt and
+// no FMA contraction (this file is compiled with -ffp-contract=off): the hypothesis poses agree to the bit, so the inlier masks
+// (integers) can be compared exactly.  The basis of the 2-dimensional null space of a 5-point system is a property of the
+// eigen-solver (OpenCV's SVD would return another one); see DESIGN.md.
+#include "vslam_internal.h"
+
+namespace vslam {
+
+constexpr int kSweeps12 = 10, kSweeps3 = 8;
+
+__device__ inline void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
+    if (apq == 0.0) { c = 1.0; s = 0.0; return; }
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    c = 1.0 / sqrt(t * t + 1.0);
+    s = t * c;
+}
+
+__device__ inline void rr_pair(int round, int k, int& p, int& q) {
+    int a, b;
+    if (k == 0) { a = 11; b = round; }
+    else { a = (round + k) % 11; b = (round - k + 11) % 11; }
+    p = a < b ? a : b; q = a < b ? b : a;
+}
+
+// symmetric 3 x 3, sequential cyclic Jacobi (one lane)
+__device__ inline void jacobi_eig3(double* A, double* V) {
+    for (int i = 0; i < 9; ++i) V[i] = (i / 3 == i % 3) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < kSweeps3; ++sweep)
+        for (int r = 0; r < 3; ++r) {
+            const int p = r == 2 ? 1 : 0, q = r == 0 ? 1 : 2;
+            double c, s;
+            jacobi_cs(A[p * 3 + p], A[q * 3 + q], A[p * 3 + q], c, s);
+            for (int j = 0; j < 3; ++j) {
+                const double ap = A[p * 3 + j], aq = A[q * 3 + j];
+                A[p * 3 + j] = c * ap - s * aq; A[q * 3 + j] = s * ap + c * aq;
+            }
+            for (int i = 0; i < 3; ++i) {
+                const double ap = A[i * 3 + p], aq = A[i * 3 + q];
+                A[i * 3 + p] = c * ap - s * aq; A[i * 3 + q] = s * ap + c * aq;
+                const double vp = V[i * 3 + p], vq = V[i * 3 + q];
+                V[i * 3 + p] = c * vp - s * vq; V[i * 3 + q] = s * vp + c * vq;
+            }
+        }
+}
+
+// least squares of an m x n system (m = 6, n <= 5), Householder QR, one lane
+__device__ inline void qr_solve(double* A, double* b, int m, int n, double* x) {
+    for (int k = 0; k < n; ++k) {
+        double norm2 = 0;
+        for (int i = k; i < m; ++i) norm2 += A[i * n + k] * A[i * n + k];
+        const double norm = sqrt(norm2);
+        if (norm == 0.0) continue;
+        const double alpha = A[k * n + k] > 0 ? -norm : norm;
+        A[k * n + k] -= alpha;
+        double vtv = 0;
+        for (int i = k; i < m; ++i) vtv += A[i * n + k] * A[i * n + k];
+        if (vtv != 0.0) {
+            for (int j = k + 1; j < n; ++j) {
+                double dot = 0;
+                for (int i = k; i < m; ++i) dot += A[i * n + k] * A[i * n + j];
+                const double f = 2.0 * dot / vtv;
+                for (int i = k; i < m; ++i) A[i * n + j] -= f * A[i * n + k];
+            }
+            double dot = 0;
+            for (int i = k; i < m; ++i) dot += A[i * n + k] * b[i];
+            const double f = 2.0 * dot / vtv;
+            for (int i = k; i < m; ++i) b[i] -= f * A[i * n + k];
+        }
+        A[k * n + k] = alpha;
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        double s = b[k];
+        for (int j = k + 1; j < n; ++j) s -= A[k * n + j] * x[j];
+        x[k] = A[k * n + k] != 0.0 ? s / A[k * n + k] : 0.0;
+    }
+}
+
+__device__ inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ inline double dist2(const double* a, const double* b) {
+    return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+
+constexpr int kMp = 5; // model points of solvePnPRansac for n > 4
+
+struct EpnpShared {
+    double A[144], V[144], B[144];
+    double m[kMp][2][12];               // rows of M
+    double cc[12], ss[12];
+    int partner[12];
+    double pws[kMp * 3], us[kMp * 2], alphas[kMp * 4], pcs[kMp * 3];
+    double cws[4][3], ccs[4][3];
+    double v[4][12];
+    double L[60], rho[6];
+    int ok;
+};
+
+__device__ inline void find_betas(int N, const double* L, const double* rho, double* betas) {
+    const int nc = N == 1 ? 4 : (N == 2 ? 3 : 5);
+    double A[30], b[6], x[5];
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < nc; ++j) {
+            const int col = N == 1 ? (j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 3 : 6))) : j;
+            A[i * nc + j] = L[10 * i + col];
+        }
+        b[i] = rho[i];
+    }
+    qr_solve(A, b, 6, nc, x);
+    if (N == 1) {
+        if (x[0] < 0) { betas[0] = sqrt(-x[0]); betas[1] = -x[1] / betas[0]; betas[2] = -x[2] / betas[0]; betas[3] = -x[3] / betas[0]; }
+        else { betas[0] = sqrt(x[0]); betas[1] = x[1] / betas[0]; betas[2] = x[2] / betas[0]; betas[3] = x[3] / betas[0]; }
+    } else {
+        if (x[0] < 0) { betas[0] = sqrt(-x[0]); betas[1] = (x[2] < 0) ? sqrt(-x[2]) : 0.0; }
+        else { betas[0] = sqrt(x[0]); betas[1] = (x[2] > 0) ? sqrt(x[2]) : 0.0; }
+        if (x[1] < 0) betas[0] = -betas[0];
+        betas[2] = N == 3 ? x[3] / betas[0] : 0.0;
+        betas[3] = 0.0;
+    }
+}
+
+__device__ inline void gauss_newton(const double* L, const double* rho, double* betas) {
+    for (int it = 0; it < 5; ++it) {
+        double A[24], b[6], x[4];
+        for (int i = 0; i < 6; ++i) {
+            const double* r = L + 10 * i;
+            A[i * 4 + 0] = 2 * r[0] * betas[0] + r[1] * betas[1] + r[3] * betas[2] + r[6] * betas[3];
+            A[i * 4 + 1] = r[1] * betas[0] + 2 * r[2] * betas[1] + r[4] * betas[2] + r[7] * betas[3];
+            A[i * 4 + 2] = r[3] * betas[0] + r[4] * betas[1] + 2 * r[5] * betas[2] + r[8] * betas[3];
+            A[i * 4 + 3] = r[6] * betas[0] + r[7] * betas[1] + r[8] * betas[2] + 2 * r[9] * betas[3];
+            b[i] = rho[i] - (r[0] * betas[0] * betas[0] + r[1] * betas[0] * betas[1] + r[2] * betas[1] * betas[1] + r[3] * betas[0] * betas[2] +
+                             r[4] * betas[1] * betas[2] + r[5] * betas[2] * betas[2] + r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] +
+                             r[8] * betas[2] * betas[3] + r[9] * betas[3] * betas[3]);
+        }
+        qr_solve(A, b, 6, 4, x);
+        for (int i = 0; i < 4; ++i) betas[i] += x[i];
+    }
+}
+
+__device__ inline void estimate_R_and_t(const EpnpShared& e, double fu, double fv, double uc, double vc, double R[9], double t[3]) {
+    const int n = kMp;
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
+    for (int j = 0; j < 3; ++j) { pc0[j] /= n; pw0[j] /= n; }
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k) abt[3 * j + k] += (e.pcs[3 * i + j] - pc0[j]) * (e.pws[3 * i + k] - pw0[k]);
+    double S[9], V[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) S[a * 3 + b] = abt[a] * abt[b] + abt[3 + a] * abt[3 + b] + abt[6 + a] * abt[6 + b];
+    jacobi_eig3(S, V);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2 - a; ++b) if (S[ord[b + 1] * 4] > S[ord[b] * 4]) { const int tt = ord[b]; ord[b] = ord[b + 1]; ord[b + 1] = tt; }
+    double Vs[9], U[9];
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Vs[r * 3 + c] = V[r * 3 + ord[c]];
+    Vs[2] = Vs[3] * Vs[7] - Vs[6] * Vs[4]; Vs[5] = Vs[6] * Vs[1] - Vs[0] * Vs[7]; Vs[8] = Vs[0] * Vs[4] - Vs[3] * Vs[1];
+    for (int c = 0; c < 2; ++c) {
+        double u[3], nrm = 0;
+        for (int r = 0; r < 3; ++r) { u[r] = abt[r * 3] * Vs[c] + abt[r * 3 + 1] * Vs[3 + c] + abt[r * 3 + 2] * Vs[6 + c]; nrm += u[r] * u[r]; }
+        nrm = sqrt(nrm);
+        for (int r = 0; r < 3; ++r) U[r * 3 + c] = nrm > 0 ? u[r] / nrm : (r == c ? 1.0 : 0.0);
+    }
+    U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i * 3 + j] = U[i * 3] * Vs[j * 3] + U[i * 3 + 1] * Vs[j * 3 + 1] + U[i * 3 + 2] * Vs[j * 3 + 2];
+    for (int i = 0; i < 3; ++i) t[i] = pc0[i] - dot3(R + 3 * i, pw0);
+}
+
+__device__ inline double compute_R_and_t(EpnpShared& e, const double* betas, double fu, double fv, double uc, double vc, double R[9], double t[3]) {
+    for (int j = 0; j < 4; ++j) for (int k = 0; k < 3; ++k) e.ccs[j][k] = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            for (int k = 0; k < 3; ++k) e.ccs[j][k] += betas[i] * e.v[i][3 * j + k];
+    for (int i = 0; i < kMp; ++i) {
+        const double* a = e.alphas + 4 * i;
+        for (int j = 0; j < 3; ++j) e.pcs[3 * i + j] = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] + a[3] * e.ccs[3][j];
+    }
+    if (e.pcs[2] < 0.0) {
+        for (int j = 0; j < 4; ++j) for (int k = 0; k < 3; ++k) e.ccs[j][k] = -e.ccs[j][k];
+        for (int i = 0; i < 3 * kMp; ++i) e.pcs[i] = -e.pcs[i];
+    }
+    estimate_R_and_t(e, fu, fv, uc, vc, R, t);
+    double sum = 0;
+    for (int i = 0; i < kMp; ++i) {
+        const double* pw = e.pws + 3 * i;
+        const double Xc = dot3(R, pw) + t[0], Yc = dot3(R + 3, pw) + t[1], inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
+        const double ue = uc + fu * Xc * inv_Zc, ve = vc + fv * Yc * inv_Zc;
+        const double du = e.us[2 * i] - ue, dv = e.us[2 * i + 1] - ve;
+        sum += sqrt(du * du + dv * dv);
+    }
+    return sum / kMp;
+}
+
+__device__ inline void rotmat_to_quat(const double R[9], double q[4]) {
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) { const double s = sqrt(tr + 1.0) * 2; q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
+    else if (R[0] > R[4] && R[0] > R[8]) { const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
+    else if (R[4] > R[8]) { const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s; }
+    else { const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double sgn = q[3] < 0 ? -1.0 : 1.0;
+    for (int i = 0; i < 4; ++i) q[i] = sgn * q[i] / n;
+}
+
+// one wave (= one 64-thread workgroup) per hypothesis: hx / hu hold the 5 points of every subset (H x 5 x 3 f32, H x 5 x 2 f32)
+__global__ __launch_bounds__(64) void pnp_epnp_kernel(const float* __restrict__ hx, const float* __restrict__ hu, double fu, double fv, double uc, double vc,
+                                                     double* __restrict__ Rt /* H x 12: R row-major, t */, double* __restrict__ T /* H x 7 */,
+                                                     int32_t* __restrict__ ok_out) {
+    __shared__ EpnpShared e;
+    const int h = blockIdx.x, lane = threadIdx.x;
+    const float* xyz = hx + (size_t)h * kMp * 3;
+    const float* uv = hu + (size_t)h * kMp * 2;
+    if (lane == 0) {
+        e.ok = 1;
+        for (int i = 0; i < kMp; ++i) {
+            for (int j = 0; j < 3; ++j) e.pws[3 * i + j] = (double)xyz[3 * i + j];
+            const float xn = (float)(((double)uv[2 * i] - uc) * (1.0 / fu)), yn = (float)(((double)uv[2 * i + 1] - vc) * (1.0 / fv));
+            e.us[2 * i] = (double)xn * fu + uc;
+            e.us[2 * i + 1] = (double)yn * fv + vc;
+        }
+        // choose_control_points
+        e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
+        for (int i = 0; i < kMp; ++i) for (int j = 0; j < 3; ++j) e.cws[0][j] += e.pws[3 * i + j];
+        for (int j = 0; j < 3; ++j) e.cws[0][j] /= kMp;
+        double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V3[9];
+        for (int i = 0; i < kMp; ++i) {
+            double d[3];
+            for (int j = 0; j < 3; ++j) d[j] = e.pws[3 * i + j] - e.cws[0][j];
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a * 3 + b] += d[a] * d[b];
+        }
+        jacobi_eig3(C, V3);
+        int ord[3] = {0, 1, 2};
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2 - a; ++b) if (C[ord[b + 1] * 4] > C[ord[b] * 4]) { const int tt = ord[b]; ord[b] = ord[b + 1]; ord[b + 1] = tt; }
+        for (int i = 1; i < 4; ++i) {
+            const int col = ord[i - 1];
+            const double ev = C[col * 4] > 0 ? C[col * 4] : 0.0;
+            const double k = sqrt(ev / kMp);
+            int big = 0; // sign convention of the principal directions: largest-magnitude component positive (first on ties)
+            for (int j = 1; j < 3; ++j) if (fabs(V3[j * 3 + col]) > fabs(V3[big * 3 + col])) big = j;
+            const double sg = V3[big * 3 + col] < 0 ? -1.0 : 1.0;
+            for (int j = 0; j < 3; ++j) e.cws[i][j] = e.cws[0][j] + k * (sg * V3[j * 3 + col]);
+        }
+        // compute_barycentric_coordinates
+        double cc[9], ci[9];
+        for (int i = 0; i < 3; ++i) for (int j = 1; j < 4; ++j) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
+        const double c00 = cc[4] * cc[8] - cc[5] * cc[7], c01 = cc[5] * cc[6] - cc[3] * cc[8], c02 = cc[3] * cc[7] - cc[4] * cc[6];
+        const double det = cc[0] * c00 + cc[1] * c01 + cc[2] * c02;
+        if (det == 0.0 || !isfinite(det)) e.ok = 0;
+        const double id = 1.0 / det;
+        ci[0] = c00 * id; ci[1] = (cc[2] * cc[7] - cc[1] * cc[8]) * id; ci[2] = (cc[1] * cc[5] - cc[2] * cc[4]) * id;
+        ci[3] = c01 * id; ci[4] = (cc[0] * cc[8] - cc[2] * cc[6]) * id; ci[5] = (cc[2] * cc[3] - cc[0] * cc[5]) * id;
+        ci[6] = c02 * id; ci[7] = (cc[1] * cc[6] - cc[0] * cc[7]) * id; ci[8] = (cc[0] * cc[4] - cc[1] * cc[3]) * id;
+        for (int i = 0; i < kMp; ++i) {
+            const double* pi = e.pws + 3 * i;
+            double* a = e.alphas + 4 * i;
+            for (int j = 0; j < 3; ++j)
+                a[1 + j] = ci[3 * j] * (pi[0] - e.cws[0][0]) + ci[3 * j + 1] * (pi[1] - e.cws[0][1]) + ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
+            a[0] = 1.0 - a[1] - a[2] - a[3];
+            for (int j = 0; j < 4; ++j) { // fill_M
+                e.m[i][0][3 * j] = a[j] * fu; e.m[i][0][3 * j + 1] = 0.0; e.m[i][0][3 * j + 2] = a[j] * (uc - e.us[2 * i]);
+                e.m[i][1][3 * j] = 0.0; e.m[i][1][3 * j + 1] = a[j] * fv; e.m[i][1][3 * j + 2] = a[j] * (vc - e.us[2 * i + 1]);
+            }
+        }
+    }
+    __syncthreads();
+    if (!e.ok) { // wave-uniform
+        if (lane == 0) ok_out[h] = 0;
+        return;
+    }
+    // M^T M, element-parallel; per element the same sum order as the sequential accumulation over the points
+    for (int el = lane; el < 144; el += 64) {
+        const int a = el / 12, b = el % 12;
+        double acc = 0;
+        for (int i = 0; i < kMp; ++i) acc += e.m[i][0][a] * e.m[i][0][b] + e.m[i][1][a] * e.m[i][1][b];
+        e.A[el] = acc;
+        e.V[el] = a == b ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < kSweeps12; ++sweep)
+        for (int round = 0; round < 11; ++round) {
+            if (lane < 6) {
+                int p, q; double c, s;
+                rr_pair(round, lane, p, q);
+                jacobi_cs(e.A[p * 12 + p], e.A[q * 12 + q], e.A[p * 12 + q], c, s);
+                e.partner[p] = q; e.partner[q] = p; e.cc[p] = c; e.cc[q] = c; e.ss[p] = -s; e.ss[q] = s;
+            }
+            __syncthreads();
+            for (int el = lane; el < 144; el += 64) { const int i = el / 12, j = el % 12; e.B[el] = e.cc[i] * e.A[el] + e.ss[i] * e.A[e.partner[i] * 12 + j]; }
+            __syncthreads();
+            for (int el = lane; el < 144; el += 64) { const int i = el / 12, j = el % 12; e.A[el] = e.cc[j] * e.B[el] + e.ss[j] * e.B[i * 12 + e.partner[j]]; }
+            __syncthreads();
+            double nv[3];
+            for (int u = 0, el = lane; el < 144; el += 64, ++u) { const int i = el / 12, j = el % 12; nv[u] = e.cc[j] * e.V[el] + e.ss[j] * e.V[i * 12 + e.partner[j]]; }
+            __syncthreads();
+            for (int u = 0, el = lane; el < 144; el += 64, ++u) e.V[el] = nv[u];
+            __syncthreads();
+        }
+    if (lane == 0) {
+        int ord[12];
+        for (int i = 0; i < 12; ++i) ord[i] = i;
+        for (int a = 0; a < 4; ++a) {
+            int best = a;
+            for (int b = a + 1; b < 12; ++b) if (e.A[ord[b] * 13] < e.A[ord[best] * 13]) best = b;
+            const int tmp = ord[best];
+            for (int b = best; b > a; --b) ord[b] = ord[b - 1];
+            ord[a] = tmp;
+        }
+        for (int i = 0; i < 4; ++i) for (int r = 0; r < 12; ++r) e.v[i][r] = e.V[r * 12 + ord[i]];
+        // compute_L_6x10, compute_rho
+        {
+            double dv[4][6][3];
+            for (int i = 0; i < 4; ++i) {
+                int a = 0, b = 1;
+                for (int j = 0; j < 6; ++j) {
+                    for (int c = 0; c < 3; ++c) dv[i][j][c] = e.v[i][3 * a + c] - e.v[i][3 * b + c];
+                    b++;
+                    if (b > 3) { a++; b = a + 1; }
+                }
+            }
+            for (int i = 0; i < 6; ++i) {
+                double* row = e.L + 10 * i;
+                row[0] = dot3(dv[0][i], dv[0][i]);
+                row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
+                row[2] = dot3(dv[1][i], dv[1][i]);
+                row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
+                row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
+                row[5] = dot3(dv[2][i], dv[2][i]);
+                row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
+                row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
+                row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
+                row[9] = dot3(dv[3][i], dv[3][i]);
+            }
+        }
+        e.rho[0] = dist2(e.cws[0], e.cws[1]); e.rho[1] = dist2(e.cws[0], e.cws[2]); e.rho[2] = dist2(e.cws[0], e.cws[3]);
+        e.rho[3] = dist2(e.cws[1], e.cws[2]); e.rho[4] = dist2(e.cws[1], e.cws[3]); e.rho[5] = dist2(e.cws[2], e.cws[3]);
+        double best_err = -1, R[9], t[3];
+        for (int N = 1; N <= 3; ++N) {
+            double betas[4], Rn[9], tn[3];
+            find_betas(N, e.L, e.rho, betas);
+            gauss_newton(e.L, e.rho, betas);
+            const double err = compute_R_and_t(e, betas, fu, fv, uc, vc, Rn, tn);
+            if (N == 1 || err < best_err) {
+                best_err = err;
+                for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+                for (int i = 0; i < 3; ++i) t[i] = tn[i];
+            }
+        }
+        bool fin = true;
+        for (int i = 0; i < 9; ++i) fin = fin && isfinite(R[i]);
+        for (int i = 0; i < 3; ++i) fin = fin && isfinite(t[i]);
+        double q[4] = {0, 0, 0, 1};
+        if (fin) rotmat_to_quat(R, q);
+        for (int i = 0; i < 9; ++i) Rt[(size_t)h * 12 + i] = R[i];
+        for (int i = 0; i < 3; ++i) Rt[(size_t)h * 12 + 9 + i] = t[i];
+        for (int i = 0; i < 4; ++i) T[(size_t)h * 7 + i] = q[i];
+        for (int i = 0; i < 3; ++i) T[(size_t)h * 7 + 4 + i] = t[i];
+        ok_out[h] = fin ? 1 : 0;
+    }
+}
+
+// PnPRansacCallback::computeError + findInliers: inliers of every hypothesis over the shared point set (block = hypothesis);
+// mask (optional) receives the per-point flags of hypothesis `mask_hyp`
+__global__ __launch_bounds__(256) void pnp_count_inliers_kernel(const float* __restrict__ xyz, const float* __restrict__ uv, int n, const double* __restrict__ Rt,
+                                                               const int32_t* __restrict__ ok, double fx, double fy, double cx, double cy, float thr2,
+                                                               int32_t* __restrict__ counts, int hyp0, uint8_t* __restrict__ mask) {
+    const int hyp = hyp0 + blockIdx.x;
+    __shared__ double sR[12];
+    __shared__ int cnt;
+    if (threadIdx.x < 12) sR[threadIdx.x] = Rt[(size_t)hyp * 12 + threadIdx.x];
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    if (ok[hyp])
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+            double x = sR[0] * X + sR[1] * Y + sR[2] * Z + sR[9];
+            double y = sR[3] * X + sR[4] * Y + sR[5] * Z + sR[10];
+            double z = sR[6] * X + sR[7] * Y + sR[8] * Z + sR[11];
+            z = z ? 1. / z : 1;
+            x *= z; y *= z;
+            const float pu = (float)(x * fx + cx), pv = (float)(y * fy + cy);
+            const float du = uv[2 * i] - pu, dv = uv[2 * i + 1] - pv;
+            float err = 0.f;
+            err += du * du;
+            err += dv * dv;
+            const bool in = err <= thr2;
+            if (mask) mask[i] = in;
+            mine += in;
+        }
+    else if (mask)
+        for (int i = threadIdx.x; i < n; i += 256) mask[i] = 0;
+    atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && counts) counts[hyp] = cnt;
+}
+
+int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[4], double* d_Rt, double* d_T, int32_t* d_ok, hipStream_t stream) {
+    if (H <= 0) return VSLAM_OK;
+    ProfScope prof__(stream, "pnp_epnp_kernel");
+    hipLaunchKernelGGL(pnp_epnp_kernel, dim3(H), dim3(64), 0, stream, d_hx, d_hu, K[0], K[1], K[2], K[3], d_Rt, d_T, d_ok);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+int launch_pnp_count_inliers(const float* d_xyz, const float* d_uv, int n, const double* d_Rt, const int32_t* d_ok, int hyp0, int n_hyp, const double K[4],
+                             double reproj_thr, int32_t* d_counts, uint8_t* d_mask, hipStream_t stream) {
+    if (n_hyp <= 0) return VSLAM_OK;
+    ProfScope prof__(stream, "pnp_count_inliers_kernel");
+    hipLaunchKernelGGL(pnp_count_inliers_kernel, dim3(n_hyp), dim3(256), 0, stream, d_xyz, d_uv, n, d_Rt, d_ok, K[0], K[1], K[2], K[3],
+                       (float)(reproj_thr * reproj_thr), d_counts, hyp0, d_mask);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+} // namespace vslam

@@ -198,8 +198,10 @@ struct PnpArgs {
     uint8_t* inlier; int32_t* n_inliers; vslam_lm_stats* stats;
 };
 int launch_pnp(const PnpArgs& a, LmScratch* scratch, hipStream_t stream);
-int launch_pnp_hypothesis_count(const float* d_xyz, const float* d_uv, int n, const double* d_T, int n_hyp, const double K[4], double reproj_thr,
-                                int32_t* d_counts, hipStream_t stream);
+// pnp_kernels.hip: EPnP of H 5-point subsets (one wave each) -> R|t (H x 12), pose (H x 7), ok flag; f32 inlier scoring of hypotheses
+int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[4], double* d_Rt, double* d_T, int32_t* d_ok, hipStream_t stream);
+int launch_pnp_count_inliers(const float* d_xyz, const float* d_uv, int n, const double* d_Rt, const int32_t* d_ok, int hyp0, int n_hyp, const double K[4],
+                             double reproj_thr, int32_t* d_counts, uint8_t* d_mask, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- context
 struct Ctx {

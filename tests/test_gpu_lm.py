@@ -97,17 +97,18 @@ def test_local_ba_rejects_bad_graph(vo, pkg, synth):
 
 
 # ---------------------------------------------------------------- RANSAC front of the motion-only stage
-@pytest.mark.parametrize("M,outl,seed", [(400, 0.35, 9), (120, 0.15, 3), (60, 0.0, 2), (900, 0.5, 7)])
+@pytest.mark.parametrize("M,outl,seed", [(400, 0.35, 9), (120, 0.15, 3), (60, 0.0, 2), (900, 0.5, 7), (6, 0.0, 4), (5, 0.0, 5), (37, 0.6, 11), (2000, 0.25, 12)])
 def test_pnp_ransac_parity(vo, oracle, synth, M, outl, seed):
-    """vslam_pnp_ransac vs oracle/ransac.c: same subset sequence, same accepted hypothesis, same number of iterations,
-    identical inlier mask, pose within 1e-4 (cv::solvePnPRansac control flow, visual_odometry.cpp:277)"""
+    """vslam_pnp_ransac vs oracle/ransac.c: same subset sequence, EPnP per hypothesis (no pose guess), same accepted hypothesis,
+    same number of iterations, identical inlier mask (f32 error rule), pose within 1e-4 (cv::solvePnPRansac, visual_odometry.cpp:277)"""
     p = synth.pnp_problem(M=M, seed=seed, outlier_frac=outl, sigma_px=0.4)
-    gT, ginl, gn, git = vo.motion_estimation_ransac(p["xyz"], p["uv"], p["T0"])
-    wT, winl, wn, wit = oracle.pnp_ransac(p["xyz"], p["uv"], p["T0"])
+    gT, ginl, gn, git = vo.motion_estimation_ransac(p["xyz"], p["uv"])
+    wT, winl, wn, wit = oracle.pnp_ransac(p["xyz"], p["uv"])
     assert git == wit and gn == wn
     assert np.array_equal(ginl, winl)
     assert np.allclose(gT, wT, rtol=RTOL, atol=1e-7)
-    assert gn >= (1 - outl) * M * 0.8
+    if M >= 60:
+        assert gn >= (1 - outl) * M * 0.8
 
 
 def test_pnp_ransac_too_few_points(vo, synth):
