@@ -194,6 +194,12 @@ int vslam_pnp_motion_only_dev(vslam_ctx* ctx, const float* d_xyz_w, const float*
 int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters,
                      double reproj_err, double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run);
 
+/* The same call, additionally returning every hypothesis: models_Rt = max_iters x 12 doubles ([R row-major | t] of the EPnP model of
+ * subset i), models_count = its inlier count over all points (-1: degenerate subset).  For diagnostics and the parity tests. */
+int vslam_pnp_ransac_models(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters, double reproj_err,
+                            double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run, double* models_Rt,
+                            int32_t* models_count);
+
 /* VO::check_motion_estimation (visual_odometry.cpp:316-346); host arithmetic (scalar). returns 1/0. */
 int vslam_check_motion(int num_inliers, const double T_c_l[7], double frame_gap);
 

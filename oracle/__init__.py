@@ -371,6 +371,12 @@ def jacobi_eig12(A):
     return np.diag(A).copy(), V
 
 
+def epnp_subset(xyz, uv, subset, K=K_KITTI):
+    """EPnP model [R | t] (12,) of the given 5 point indices, or None if degenerate"""
+    R, t, err = epnp(np.asarray(xyz, np.float32)[list(subset)], np.asarray(uv, np.float32)[list(subset)], K)
+    return None if err < 0 else np.concatenate([R.reshape(9), t])
+
+
 def pnp_ransac_hypothesis(xyz, uv, it, K=K_KITTI, reproj_err=4.0):
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
     T = np.zeros(7); sub = np.zeros(5, np.int32)

@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
-    "vslam_profile_enable", "vslam_profile_read", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_find_3d_disparity_dev",
+    "vslam_profile_enable", "vslam_profile_read", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
 ]
 
 
@@ -299,6 +299,16 @@ class VO:
         self._chk(self.lib.vslam_pnp_ransac(self.h, _p(xyz), _p(uv), n, _p(T), int(max_iters), C.c_double(reproj_err), C.c_double(confidence),
                                             int(lm_iters), _p(inl), C.byref(ni), C.byref(it)), "vslam_pnp_ransac")
         return T, inl[:n], ni.value, it.value
+
+    def motion_estimation_ransac_models(self, xyz_w, uv, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+        """diagnostic form: (T, mask, n_inliers, iterations, models (max_iters, 12) [R | t], counts (max_iters,))"""
+        xyz = np.ascontiguousarray(xyz_w, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        T = np.array([0, 0, 0, 1, 0, 0, 0], np.float64); n = len(xyz)
+        inl = np.zeros(max(n, 1), np.uint8); ni = C.c_int(); it = C.c_int()
+        models = np.zeros((max_iters, 12)); counts = np.zeros(max_iters, np.int32)
+        self._chk(self.lib.vslam_pnp_ransac_models(self.h, _p(xyz), _p(uv), n, _p(T), int(max_iters), C.c_double(reproj_err), C.c_double(confidence),
+                                                   int(lm_iters), _p(inl), C.byref(ni), C.byref(it), _p(models), _p(counts)), "vslam_pnp_ransac_models")
+        return T, inl[:n], ni.value, it.value, models, counts
 
     def motion_estimation(self, xyz_w, uv, T_guess, iters=10):
         xyz = np.ascontiguousarray(xyz_w, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)

@@ -612,8 +612,8 @@ static int ransac_update_num_iters(double p, double ep, int model_points, int ma
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
 }
 
-int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters, double reproj_err,
-                     double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run) {
+static int pnp_ransac_impl(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters, double reproj_err,
+                           double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run, double* models_Rt, int32_t* models_count) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !xyz_w || !uv || n < 0 || !T_c_w || max_iters < 0 || max_iters > 4096 || lm_iters < 0 || !(reproj_err > 0)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if (n_inliers) *n_inliers = 0;
@@ -666,7 +666,9 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
     if (!single && (rc = launch_pnp_count_inliers(d_x, d_u, n, d_Rt, d_ok, 0, H, K, reproj_err, d_cnt, nullptr, c->stream))) return rc;
     if (!single) VS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipMemcpyAsync(okv.data(), d_ok, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
+    if (models_Rt) VS_HIP(hipMemcpyAsync(models_Rt, d_Rt, (size_t)H * 96, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
+    if (models_count) for (int i = 0; i < H; ++i) models_count[i] = okv[i] ? (single ? n : cnt[i]) : -1;
     // 3. replay of the sequential loop over the counts (ptsetreg.cpp: strict improvement, adaptive iteration count)
     int best = -1, max_good = 0, it = 0;
     if (single) { if (okv[0]) { best = 0; max_good = n; } }
@@ -706,6 +708,18 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
     if (inlier) memcpy(inlier, mask.data(), n);
     if (n_inliers) *n_inliers = max_good;
     return VSLAM_OK;
+}
+
+int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters, double reproj_err,
+                     double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run) {
+    return pnp_ransac_impl(ctx, xyz_w, uv, n, T_c_w, max_iters, reproj_err, confidence, lm_iters, inlier, n_inliers, iters_run, nullptr, nullptr);
+}
+
+// diagnostic form: additionally returns every hypothesis model ([R row-major | t], 12 doubles each) and its inlier count (-1: degenerate)
+int vslam_pnp_ransac_models(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters, double reproj_err,
+                            double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run, double* models_Rt, int32_t* models_count) {
+    if (!models_Rt || !models_count) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    return pnp_ransac_impl(ctx, xyz_w, uv, n, T_c_w, max_iters, reproj_err, confidence, lm_iters, inlier, n_inliers, iters_run, models_Rt, models_count);
 }
 
 // ---------------------------------------------------------------------------------------------- window optimisation

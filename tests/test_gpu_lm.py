@@ -111,6 +111,22 @@ def test_pnp_ransac_parity(vo, oracle, synth, M, outl, seed):
         assert gn >= (1 - outl) * M * 0.8
 
 
+@pytest.mark.parametrize("M,outl,seed", [(257, 0.45, 75512239), (80, 0.2, 1), (1500, 0.3, 2)])
+def test_pnp_ransac_hypothesis_models_bit_exact(vo, oracle, synth, M, outl, seed):
+    """every one of the 100 EPnP hypothesis models ([R | t], f64) equals the oracle's to the BIT (same operation order, IEEE div / sqrt,
+    no FMA contraction), and so does its f32-rule inlier count"""
+    p = synth.pnp_problem(M=M, seed=seed, outlier_frac=outl, sigma_px=0.4)
+    T, inl, n, it, models, counts = vo.motion_estimation_ransac_models(p["xyz"], p["uv"])
+    subs = oracle.ransac_subsets(M, 100)
+    for h in range(100):
+        m = oracle.epnp_subset(p["xyz"], p["uv"], subs[h])
+        if m is None:
+            assert counts[h] == -1
+            continue
+        assert np.array_equal(m, models[h]), (h, np.abs(m - models[h]).max())
+        assert oracle.pnp_ransac_hypothesis(p["xyz"], p["uv"], h)[1] == counts[h]
+
+
 def test_pnp_ransac_too_few_points(vo, synth):
     p = synth.pnp_problem(M=4, seed=1)
     T, inl, n, it = vo.motion_estimation_ransac(p["xyz"], p["uv"], p["T0"])
