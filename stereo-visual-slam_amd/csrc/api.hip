@@ -156,7 +156,7 @@ void vslam_default_params(vslam_params* p) {
 const char* vslam_last_error(void) { return g_err; }
 const char* vslam_version(void) { return "vslam_hip 0.1 (gfx950)"; }
 const char* vslam_kernel_names(void) {
-    return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_blur_kernel orb_describe_kernel match_expand_kernel match_train_nearest_kernel "
+    return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_blur_kernel orb_describe_kernel match_train_nearest_kernel "
            "match_finalize_kernel sgbm_prefilter_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel sgbm_lrcheck_kernel "
            "sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel sgbm_ccl_apply_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel";
 }
@@ -190,8 +190,6 @@ int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** ou
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_blur, B * c->plan.blur_bytes);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_cs, B * (size_t)p->kp_capacity);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->match.d_train_best, B * kMaxRows);
-    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->match.d_q8, B * (size_t)kMaxRows * 256);
-    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->match.d_t8, B * (size_t)kMaxRows * 256);
     if (rc != VSLAM_OK) { vslam_destroy(reinterpret_cast<vslam_ctx*>(c)); return rc; }
     *out = reinterpret_cast<vslam_ctx*>(c);
     return VSLAM_OK;
@@ -207,7 +205,7 @@ void vslam_destroy(vslam_ctx* ctx) {
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->lm.buf) hipFree(c->lm.buf);
     void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs,
-                    c->match.d_train_best, c->match.d_q8, c->match.d_t8, c->d_stage};
+                    c->match.d_train_best, c->d_stage};
     for (void* q : ptrs) if (q) hipFree(q);
     if (c->prof) {
         if (prof_current() == c->prof) prof_set_current(nullptr);
@@ -383,7 +381,7 @@ int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stri
     if (B > c->p.max_batch) { set_error("batch %d exceeds context max_batch %d", B, c->p.max_batch); return VSLAM_ERR_ARG; }
     VS_ENTER(c);
     return launch_match(d_q, q_stride_bytes, d_nq, d_t, t_stride_bytes, d_nt, d_gap, gate, c->p.match_ratio, c->p.match_gap_thr, B, max_rows,
-                        c->match.d_train_best, c->match.d_q8, c->match.d_t8, d_out, out_capacity, d_nout, c->stream);
+                        c->match.d_train_best, d_out, out_capacity, d_nout, c->stream);
 }
 
 int vslam_feature_matching(vslam_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double frame_gap, int gate,
@@ -409,7 +407,7 @@ int vslam_feature_matching(vslam_ctx* ctx, const uint8_t* q, int nq, const uint8
     VS_HIP(hipMemcpyAsync(d_n, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_gap, &frame_gap, sizeof(double), hipMemcpyHostToDevice, c->stream));
     if ((rc = launch_match(d_q, 0, d_n, d_t, 0, d_n + 1, d_gap, gate, c->p.match_ratio, c->p.match_gap_thr, 1, rows, c->match.d_train_best,
-                           c->match.d_q8, c->match.d_t8, d_out, nq, d_n + 2, c->stream))) return rc;
+                           d_out, nq, d_n + 2, c->stream))) return rc;
     int32_t m = 0;
     VS_HIP(hipMemcpyAsync(&m, d_n + 2, sizeof(m), hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));

@@ -10,9 +10,10 @@
 //
 // gfx950 mapping.  The all-pairs Hamming table is the one dense contraction of the pipeline: with the descriptor bits
 // recoded as +-1 bytes, <a, b> = 256 - 2 hamming(a, b), so a 32 x 32 block of distances is eight
-// v_mfma_i32_32x32x32_i8 (exact integer arithmetic).  `match_expand_kernel` writes the +-1 form (256 B per row) once per
-// call; `match_train_nearest_kernel` keeps 64 train columns per wave resident in VGPRs as MFMA B operands, streams
-// 32-row query tiles through LDS (row stride 272 B: conflict-free ds_read_b128) and folds the column minima in the
+// v_mfma_i32_32x32x32_i8 (exact integer arithmetic).  The +-1 form never exists in HBM: `match_train_nearest_kernel` reads the raw
+// 32-B descriptors and expands bits to bytes in registers -- the 64 train columns of a wave once, into the VGPRs that stay resident
+// as MFMA B operands; every 32-row query tile cooperatively (one dword -> 32 bytes per thread) on its way into LDS (row stride
+// 272 B: conflict-free ds_read_b128), shared by the four waves of the workgroup -- and folds the column minima in the
 // accumulator layout (column = lane % 32): per value one v_lshl_add + one v_max on packed keys, with the +256 bias
 // supplied as the MFMA C operand.  The previous v_xor + v_bcnt formulation was bound by v_bcnt_u32_b32 issuing at quarter rate.
 #include "vslam_internal.h"
@@ -22,24 +23,14 @@ namespace vslam {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// ---- descriptors (32 B) -> 256 bytes of +-1 (bit k set -> -1, clear -> +1); one dword (32 output bytes) per thread
-__global__ __launch_bounds__(256) void match_expand_kernel(const uint8_t* __restrict__ d_q, size_t q_stride, const int32_t* __restrict__ d_nq,
-                                                          const uint8_t* __restrict__ d_t, size_t t_stride, const int32_t* __restrict__ d_nt,
-                                                          int max_rows, int8_t* __restrict__ d_q8, int8_t* __restrict__ d_t8) {
-    const int b = blockIdx.z, side = blockIdx.y;
-    const int n = min(side ? d_nt[b] : d_nq[b], max_rows);
-    const int t = blockIdx.x * 256 + threadIdx.x; // (row, dword)
-    if (t >= n * 8) return;
-    const uint32_t word = reinterpret_cast<const uint32_t*>((side ? d_t + (size_t)b * t_stride : d_q + (size_t)b * q_stride))[t];
-    uint32_t o[8];
-#pragma unroll
-    for (int nib = 0; nib < 8; ++nib) {
-        const uint32_t s = __umul24((word >> (4 * nib)) & 0xFu, 0x204081u) & 0x01010101u; // bit k of the nibble -> byte k
-        o[nib] = ((s << 8) - (s << 1)) | 0x01010101u;                                     // 0 -> 0x01 (+1), 1 -> 0xFF (-1)
-    }
-    uint4* dst = reinterpret_cast<uint4*>((side ? d_t8 : d_q8) + ((size_t)b * max_rows) * 256 + (size_t)t * 32);
-    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+// four descriptor bits -> four bytes of +-1 (bit set -> 0xFF = -1, clear -> 0x01 = +1); bit k of the nibble -> byte k
+__device__ inline uint32_t expand_nibble(uint32_t nib) {
+    const uint32_t s = __umul24(nib & 0xFu, 0x204081u) & 0x01010101u;
+    return ((s << 8) - (s << 1)) | 0x01010101u;
+}
+// 16 descriptor bits -> 16 operand bytes
+__device__ inline int4 expand_half(uint32_t bits16) {
+    return make_int4((int)expand_nibble(bits16), (int)expand_nibble(bits16 >> 4), (int)expand_nibble(bits16 >> 8), (int)expand_nibble(bits16 >> 12));
 }
 
 constexpr int kMatchBlock = 256;             // 4 waves
@@ -75,8 +66,8 @@ __device__ inline void fold_tile(const v16i& acc0, const v16i& acc1, int ib, int
 // come first in the grid and spread evenly over the XCDs / CUs, the blocks beyond an item's train rows (capacity padding)
 // sit at the end and exit at once.  (With the item as the slow index the live blocks of every item landed on the same few XCDs.)
 __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
-    const int8_t* __restrict__ d_q8, const int32_t* __restrict__ d_nq, const int8_t* __restrict__ d_t8, const int32_t* __restrict__ d_nt,
-    int max_rows, int qsplit, int B, uint32_t* __restrict__ d_train_best) {
+    const uint8_t* __restrict__ d_q, size_t q_stride, const int32_t* __restrict__ d_nq, const uint8_t* __restrict__ d_t, size_t t_stride,
+    const int32_t* __restrict__ d_nt, int max_rows, int qsplit, int B, uint32_t* __restrict__ d_train_best) {
     const int w = blockIdx.x;
     const int b = w % B, split = (w / B) % qsplit, cb = w / (B * qsplit);
     const int nq = min(d_nq[b], max_rows), nt = min(d_nt[b], max_rows);
@@ -88,26 +79,32 @@ __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
     if (tile0 >= tile1) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     __shared__ alignas(16) int8_t sq[2][kQRows * kQStride];
-    const int8_t* Q8 = d_q8 + (size_t)b * max_rows * 256;
-    const int8_t* T8 = d_t8 + (size_t)b * max_rows * 256;
-    // B operands: this wave's 64 train columns, resident for the whole kernel
+    const uint8_t* Q = d_q + (size_t)b * q_stride;
+    const uint8_t* T = d_t + (size_t)b * t_stride;
+    // B operands: this wave's 64 train columns, expanded once and resident for the whole kernel.  Operand slice s of lane
+    // (r, h) holds k = 32 s + 16 h .. + 15, i.e. halfword 2 s + h of the descriptor.
     v4i breg[2][8];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int j = min(c0 + wave * kColsPerWave + 32 * t + r, nt - 1);
+        const uint4 lo = *reinterpret_cast<const uint4*>(T + (size_t)j * 32), hi = *reinterpret_cast<const uint4*>(T + (size_t)j * 32 + 16);
+        const uint32_t wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int s = 0; s < 8; ++s) breg[t][s] = *reinterpret_cast<const v4i*>(T8 + (size_t)j * 256 + s * 32 + h * 16);
+        for (int s = 0; s < 8; ++s) {
+            const int4 e = expand_half((wd[s] >> (16 * h)) & 0xFFFFu);
+            breg[t][s] = v4i{e.x, e.y, e.z, e.w};
+        }
     }
-    // staging: 512 16-byte chunks per tile, two per thread
-    const int ch0 = threadIdx.x, ch1 = threadIdx.x + kMatchBlock;
-    auto gload = [&](int tile, uint4& x0, uint4& x1) {
-        const int r0 = min(tile * kQRows + (ch0 >> 4), nq - 1), r1 = min(tile * kQRows + (ch1 >> 4), nq - 1);
-        x0 = *reinterpret_cast<const uint4*>(Q8 + (size_t)r0 * 256 + (ch0 & 15) * 16);
-        x1 = *reinterpret_cast<const uint4*>(Q8 + (size_t)r1 * 256 + (ch1 & 15) * 16);
+    // staging: a tile is 32 rows x 8 dwords of raw descriptor = one dword per thread, expanded to 32 operand bytes into LDS
+    const int srow = threadIdx.x >> 3, sword = threadIdx.x & 7;
+    auto gload = [&](int tile, uint32_t& x) {
+        const int r0 = min(tile * kQRows + srow, nq - 1);
+        x = reinterpret_cast<const uint32_t*>(Q + (size_t)r0 * 32)[sword];
     };
-    auto sstore = [&](int buf, const uint4& x0, const uint4& x1) {
-        *reinterpret_cast<uint4*>(&sq[buf][(ch0 >> 4) * kQStride + (ch0 & 15) * 16]) = x0;
-        *reinterpret_cast<uint4*>(&sq[buf][(ch1 >> 4) * kQStride + (ch1 & 15) * 16]) = x1;
+    auto sstore = [&](int buf, uint32_t x) {
+        const int4 e0 = expand_half(x & 0xFFFFu), e1 = expand_half(x >> 16);
+        int4* dst = reinterpret_cast<int4*>(&sq[buf][srow * kQStride + sword * 32]);
+        dst[0] = e0; dst[1] = e1;
     };
     auto mma_tile = [&](int buf, v16i& acc0, v16i& acc1) {
         v4i a[8];
@@ -121,10 +118,10 @@ __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], breg[1][s], acc1, 0, 0, 0);
         }
     };
-    uint4 x0, x1;
-    gload(tile0, x0, x1);
-    sstore(0, x0, x1);
-    if (tile0 + 1 < tile1) gload(tile0 + 1, x0, x1);
+    uint32_t x;
+    gload(tile0, x);
+    sstore(0, x);
+    if (tile0 + 1 < tile1) gload(tile0 + 1, x);
     __syncthreads();
     int m0 = INT_MIN, m1 = INT_MIN;
     // software pipeline: the MFMAs of tile t + 1 are issued before the (VALU) epilogue of tile t
@@ -132,13 +129,13 @@ __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
     mma_tile(0, accA0, accA1);
     for (int tile = tile0; tile < tile1; tile += 2) {
         // ---- stage tile + 1 into buffer 1, issue its MFMAs, then fold tile
-        if (tile + 1 < tile1) { sstore(1, x0, x1); if (tile + 2 < tile1) gload(tile + 2, x0, x1); }
+        if (tile + 1 < tile1) { sstore(1, x); if (tile + 2 < tile1) gload(tile + 2, x); }
         __syncthreads();
         if (tile + 1 < tile1) mma_tile(1, accB0, accB1);
         fold_tile(accA0, accA1, tile * kQRows + 4 * h, nq, tile * kQRows + kQRows <= nq, m0, m1);
         if (tile + 1 >= tile1) break;
         // ---- stage tile + 2 into buffer 0, issue its MFMAs, then fold tile + 1
-        if (tile + 2 < tile1) { sstore(0, x0, x1); if (tile + 3 < tile1) gload(tile + 3, x0, x1); }
+        if (tile + 2 < tile1) { sstore(0, x); if (tile + 3 < tile1) gload(tile + 3, x); }
         __syncthreads();
         if (tile + 2 < tile1) mma_tile(0, accA0, accA1);
         fold_tile(accB0, accB1, (tile + 1) * kQRows + 4 * h, nq, (tile + 1) * kQRows + kQRows <= nq, m0, m1);
@@ -234,14 +231,9 @@ __global__ __launch_bounds__(kFinBlock) void match_finalize_kernel(
 
 int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const uint8_t* d_t, size_t t_stride,
                  const int32_t* d_nt, const double* d_gap, int gate, double ratio, double gap_thr, int B, int max_rows,
-                 uint32_t* d_train_best, int8_t* d_q8, int8_t* d_t8, vslam_dmatch* d_out, int out_capacity, int32_t* d_nout, hipStream_t stream) {
+                 uint32_t* d_train_best, vslam_dmatch* d_out, int out_capacity, int32_t* d_nout, hipStream_t stream) {
     if (B <= 0) return VSLAM_OK;
     if (max_rows > kMaxRows || max_rows <= 0) { set_error("matcher: max_rows %d out of range (<= %d)", max_rows, kMaxRows); return VSLAM_ERR_ARG; }
-    {
-        ProfScope prof__(stream, "match_expand_kernel");
-        hipLaunchKernelGGL(match_expand_kernel, dim3((max_rows * 8 + 255) / 256, 2, B), dim3(256), 0, stream, d_q, q_stride, d_nq, d_t, t_stride,
-                           d_nt, max_rows, d_q8, d_t8);
-    }
     // fill the chip: ~>= 1024 workgroups.  Split the query range when the batch is small.
     const int tblocks = (max_rows + kColsPerBlock - 1) / kColsPerBlock;
     int qsplit = 1;
@@ -250,8 +242,8 @@ int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const
     if (qsplit > 1) VS_HIP(hipMemsetAsync(d_train_best, 0xFF, (size_t)B * max_rows * sizeof(uint32_t), stream));
     {
         ProfScope prof__(stream, "match_train_nearest_kernel");
-        hipLaunchKernelGGL(match_train_nearest_kernel, dim3(tblocks * qsplit * B), dim3(kMatchBlock), 0, stream, d_q8, d_nq, d_t8, d_nt, max_rows,
-                           qsplit, B, d_train_best);
+        hipLaunchKernelGGL(match_train_nearest_kernel, dim3(tblocks * qsplit * B), dim3(kMatchBlock), 0, stream, d_q, q_stride, d_nq, d_t, t_stride,
+                           d_nt, max_rows, qsplit, B, d_train_best);
     }
     ProfScope prof__(stream, "match_finalize_kernel");
     hipLaunchKernelGGL(match_finalize_kernel, dim3(B), dim3(kFinBlock), 0, stream, d_nq, d_nt, d_gap, gate, ratio, gap_thr,

@@ -118,12 +118,10 @@ int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_b
 // ----------------------------------------------------------------------------------------------- matcher
 struct MatchBuffers {
     uint32_t* d_train_best; // B x max_rows : (dist << 16 | query index) per train row
-    int8_t* d_q8;           // B x kMaxRows x 256 : query descriptors as +-1 bytes (MFMA operands)
-    int8_t* d_t8;           // same for the train side
 };
 int launch_match(const uint8_t* d_q, size_t q_stride, const int32_t* d_nq, const uint8_t* d_t, size_t t_stride,
                  const int32_t* d_nt, const double* d_gap, int gate, double ratio, double gap_thr, int B, int max_rows,
-                 uint32_t* d_train_best, int8_t* d_q8, int8_t* d_t8, vslam_dmatch* d_out, int out_capacity, int32_t* d_nout, hipStream_t stream);
+                 uint32_t* d_train_best, vslam_dmatch* d_out, int out_capacity, int32_t* d_nout, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- geometry
 struct CamParams { double fx, fy, cx, cy, b, dmin, dmax, drel, row_tol; };
