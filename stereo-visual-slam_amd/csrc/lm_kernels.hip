@@ -206,14 +206,6 @@ __device__ inline void huber(double e, double delta, double& rho, double& w) {
     else { const double r = rsqrt_nr(e), s = e * r; rho = 2 * s * delta - dsqr; w = delta * r; }
 }
 
-// 2x6 pose Jacobian of the reprojection error from (X, Y, 1/Z).  EdgeProjection uses 1/(Z+1e-18) (optimization.cpp:66),
-// PoseOnlyEdgeProjection divides by Z (:96-100); the caller passes the matching reciprocal.
-__device__ inline void jac_pose(const double* K, double X, double Y, double Zi, double A[12]) {
-    const double fx = K[0], fy = K[1];
-    const double Zi2 = Zi * Zi;
-    A[0] = -fx * Zi; A[1] = 0; A[2] = fx * X * Zi2; A[3] = fx * X * Y * Zi2; A[4] = -fx - fx * X * X * Zi2; A[5] = fx * Y * Zi;
-    A[6] = 0; A[7] = -fy * Zi; A[8] = fy * Y * Zi2; A[9] = fy + fy * Y * Y * Zi2; A[10] = -fy * X * Y * Zi2; A[11] = -fy * X * Zi;
-}
 // The pose Jacobian has two structural zeros, A[1] = A[6] = 0.  Without fast-math the compiler must keep 0 * x (NaN / signed-zero
 // semantics), so the hot loops spell the sparsity out: the helpers below are called with loop indices that are constants after
 // unrolling, and the branches fold away.  (Dropping an exact 0 * finite term does not change any sum.)
@@ -235,15 +227,6 @@ __device__ inline double a_fma_pair(const double* U, int r, const double* V, int
     if (r != 1 && c != 1) acc = fma(U[r], V[c], acc);
     return acc;
 }
-// 2x3 landmark Jacobian = A[:, 0:3] * R
-__device__ inline void jac_point(const double A[12], const double* R, double B[6]) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        B[c] = A[0] * R[c] + A[2] * R[6 + c];
-        B[3 + c] = A[7] * R[3 + c] + A[8] * R[6 + c];
-    }
-}
-
 template <bool FAST = false>
 __device__ inline void project_err(const double* Rt, const double* K, double px, double py, double pz, float u, float v, double& X,
                                    double& Y, double& Z, double& ex, double& ey, double* rz_out = nullptr) {
@@ -256,28 +239,47 @@ __device__ inline void project_err(const double* Rt, const double* K, double px,
     if (rz_out) *rz_out = rz;
 }
 
-// linearisation record of one observation at (pose Rt, point p): camera-frame X, Y, the reciprocal depth the Jacobians use,
-// the Huber weight and the error.  Shared by the evaluation pass (which stores it keyframe-major for the pose-wise and Schur
-// phases) and by the landmark-wise phases, which recompute it from the landmark position instead of gathering it.
-__device__ inline void lin_record(const double* Rt, const double* K, double px, double py, double pz, float2 z, double delta, bool with_lm,
-                                  double& X, double& Y, double& Zi, double& wgt, double& ex, double& ey, double& chi, double& rho) {
-    double Z, rz;
-    project_err<true>(Rt, K, px, py, pz, z.x, z.y, X, Y, Z, ex, ey, &rz);
-    chi = ex * ex + ey * ey;
-    huber(chi, delta, rho, wgt);
-    // optimization.cpp:66 uses 1/(Z + 1e-18), :96-100 1/Z.  Z + 1e-18 rounds to Z for every Z > 0.01: same reciprocal.
-    Zi = rz;
-    if (with_lm) { const double Zc = Z + 1e-18; if (Zc != Z) Zi = rcp_nr(Zc); }
+// ---- linearisation in NORMALISED image coordinates.  With the camera-frame point (X, Y, Z): rho = 1/Z, x = X rho, y = Y rho.  The 2x6
+// pose Jacobian of the reprojection error (optimization.cpp:52-72, :84-100) factors as  A = diag(fx, fy) At  with
+//   At = [ -rho   0    x rho   x y      -(1 + x^2)   y ]
+//        [  0    -rho  y rho   1 + y^2  -x y        -x ]
+// (7 flops from x, y, rho instead of 18 for A), the landmark Jacobian as  B = diag(fx, fy) Bt,  Bt = At[:, 0:3] R, and the
+// error as  e = diag(fx, fy) en,  en = (z - c) / f - (x, y).  Every block of the normal equations then carries the focal lengths
+// only through the two per-edge weights  l0 = w fx^2, l1 = w fy^2  (w = Huber weight):
+//   H_pp = At^T L At,  b_p = -At^T L en,  H_ll = Bt^T L Bt,  b_l = -Bt^T L en,  W = At^T L Bt      (L = diag(l0, l1)).
+// EdgeProjection uses 1/(Z + 1e-18) (optimization.cpp:66), PoseOnlyEdgeProjection 1/Z (:96-100): the two differ by less than one
+// ulp for every Z > 0.01 m and by a relative 1e-16 / Z below that -- one reciprocal serves both.
+struct CamK { double fx, fy, ifx, ify, kx, ky, fx2, fy2; }; // kx = -cx / fx, ky = -cy / fy
+__device__ inline CamK make_camk(const double* K) {
+    CamK c;
+    c.fx = K[0]; c.fy = K[1]; c.ifx = 1.0 / K[0]; c.ify = 1.0 / K[1]; c.kx = -K[2] * c.ifx; c.ky = -K[3] * c.ify; c.fx2 = K[0] * K[0]; c.fy2 = K[1] * K[1];
+    return c;
 }
-
-// camera-frame part of the record only (the Schur phases take the Huber weight from the evaluation pass): X, Y and the
-// reciprocal depth EdgeProjection's Jacobians use (optimization.cpp:66)
-__device__ inline void cam_point(const double* Rt, double px, double py, double pz, double& X, double& Y, double& Zi) {
-    X = Rt[0] * px + Rt[1] * py + Rt[2] * pz + Rt[9];
-    Y = Rt[3] * px + Rt[4] * py + Rt[5] * pz + Rt[10];
+__device__ inline void cam_norm(const double* Rt, double px, double py, double pz, double& x, double& y, double& rho) {
+    const double X = Rt[0] * px + Rt[1] * py + Rt[2] * pz + Rt[9];
+    const double Y = Rt[3] * px + Rt[4] * py + Rt[5] * pz + Rt[10];
     const double Z = Rt[6] * px + Rt[7] * py + Rt[8] * pz + Rt[11];
-    const double Zc = Z + 1e-18;
-    Zi = rcp_nr(Zc == Z ? Z : Zc);
+    rho = rcp_nr(Z);
+    x = X * rho; y = Y * rho;
+}
+__device__ inline void jac_norm(double x, double y, double rho, double A[12]) {
+    A[0] = -rho; A[1] = 0; A[2] = x * rho; A[3] = x * y; A[4] = -fma(x, x, 1.0); A[5] = y;
+    A[6] = 0; A[7] = -rho; A[8] = y * rho; A[9] = fma(y, y, 1.0); A[10] = -A[3]; A[11] = -x;
+}
+// Bt = At[:, 0:3] R = rho (x R2 - R0 ; y R2 - R1)   (R0, R1, R2: rows of the rotation)
+__device__ inline void jac_point_norm(double x, double y, double rho, const double* R, double B[6]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        B[c] = rho * fma(x, R[6 + c], -R[c]);
+        B[3 + c] = rho * fma(y, R[6 + c], -R[3 + c]);
+    }
+}
+// evaluation of one observation: normalised error en, pixel chi2, robust rho, Huber weight
+__device__ inline void eval_obs(const CamK& ck, double x, double y, float2 z, double delta, double& enx, double& eny, double& chi, double& rob, double& wgt) {
+    enx = fma((double)z.x, ck.ifx, ck.kx) - x;
+    eny = fma((double)z.y, ck.ify, ck.ky) - y;
+    chi = ck.fx2 * enx * enx + ck.fy2 * eny * eny;
+    huber(chi, delta, rob, wgt);
 }
 
 __device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double Di[6]) {
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     int2* hits = reinterpret_cast<int2*>(a.pair_hits) + (size_t)e0 * kHitsPerEdge; // off-diagonal pairs only: {pos1 | pos2 << 16, landmark}
     uint8_t* act = ka.act + lm0;
     const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
+    const CamK ck = make_camk(K);
     const double delta = a.huber_delta;
     const bool with_lm = (mode == 0);
     const int npairs = nk * (nk + 1) / 2;
@@ -734,13 +737,15 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 }
                 const int j = cur.j + lane;
                 if (j < cur.jend) {
-                    double X, Y, Zi, wgt, ex, ey, c, rho, A[12], wA[12];
-                    lin_record(Rk, K, px, py, pz, z1, delta, with_lm, X, Y, Zi, wgt, ex, ey, c, rho);
+                    double x, y, ri, wgt, ex, ey, c, rho, A[12], wA[12];
+                    cam_norm(Rk, px, py, pz, x, y, ri);
+                    eval_obs(ck, x, y, z1, delta, ex, ey, c, rho, wgt); // (ex, ey: normalised error)
                     part += rho;
-                    if (with_lm) dstW[j] = wgt; // the Schur passes re-derive X, Y, 1/Z from the landmark; only the weight is kept
-                    jac_pose(K, X, Y, Zi, A);
+                    if (with_lm) dstW[j] = wgt; // the Schur passes re-derive x, y, 1/Z from the landmark; only the weight is kept
+                    jac_norm(x, y, ri, A);
+                    const double l0 = wgt * ck.fx2, l1 = wgt * ck.fy2;
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) wA[i] = wgt * A[i];
+                    for (int i = 0; i < 6; ++i) { wA[i] = l0 * A[i]; wA[6 + i] = l1 * A[6 + i]; }
                     int idx = 0;
 #pragma unroll
                     for (int r = 0; r < 6; ++r)
@@ -843,13 +848,16 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     const int l = l0 + u * kLmBlock;
                     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
                     auto add_edge = [&](int k, float2 z) {
-                        double X, Y, Zi, wg, ex, ey, c, rho, A[12], B[6];
-                        lin_record(&sm.Rt[12 * k], K, px[u], py[u], pz[u], z, delta, true, X, Y, Zi, wg, ex, ey, c, rho);
-                        jac_pose(K, X, Y, Zi, A);
-                        jac_point(A, &sm.Rt[12 * k], B);
-                        h[0] += wg * (B[0] * B[0] + B[3] * B[3]); h[1] += wg * (B[0] * B[1] + B[3] * B[4]); h[2] += wg * (B[0] * B[2] + B[3] * B[5]);
-                        h[3] += wg * (B[1] * B[1] + B[4] * B[4]); h[4] += wg * (B[1] * B[2] + B[4] * B[5]); h[5] += wg * (B[2] * B[2] + B[5] * B[5]);
-                        g[0] -= wg * (B[0] * ex + B[3] * ey); g[1] -= wg * (B[1] * ex + B[4] * ey); g[2] -= wg * (B[2] * ex + B[5] * ey);
+                        double x, y, ri, wg, ex, ey, c, rho, B[6], Bs[6];
+                        cam_norm(&sm.Rt[12 * k], px[u], py[u], pz[u], x, y, ri);
+                        eval_obs(ck, x, y, z, delta, ex, ey, c, rho, wg);
+                        jac_point_norm(x, y, ri, &sm.Rt[12 * k], B);
+                        const double l0 = wg * ck.fx2, l1 = wg * ck.fy2;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { Bs[i] = l0 * B[i]; Bs[3 + i] = l1 * B[3 + i]; }
+                        h[0] += Bs[0] * B[0] + Bs[3] * B[3]; h[1] += Bs[0] * B[1] + Bs[3] * B[4]; h[2] += Bs[0] * B[2] + Bs[3] * B[5];
+                        h[3] += Bs[1] * B[1] + Bs[4] * B[4]; h[4] += Bs[1] * B[2] + Bs[4] * B[5]; h[5] += Bs[2] * B[2] + Bs[5] * B[5];
+                        g[0] -= Bs[0] * ex + Bs[3] * ey; g[1] -= Bs[1] * ex + Bs[4] * ey; g[2] -= Bs[2] * ex + Bs[5] * ey;
                     };
 #pragma unroll
                     for (int q = 0; q < kLmE; ++q) if (b0[u] + q < b1[u]) add_edge(kk[u][q], zz[u][q]);
@@ -928,10 +936,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             loadD(lnn, Dan, Dbn, Dcn);
                             const double g0n = PC(bl, 0, lnn), g1n = PC(bl, 1, lnn), g2n = PC(bl, 2, lnn);
                             double A1[12], B1[6];
-                            double4 ra; // the linearisation record {X, Y, 1/Z, w}: camera-frame part recomputed from the landmark
-                            cam_point(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
-                            jac_pose(K, ra.x, ra.y, ra.z, A1);
-                            jac_point(A1, R1, B1);
+                            double4 ra; // the linearisation record {x, y, 1/Z, w}: camera-frame part recomputed from the landmark
+                            cam_norm(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
+                            jac_norm(ra.x, ra.y, ra.z, A1);
+                            jac_point_norm(ra.x, ra.y, ra.z, R1, B1);
+                            const double l0 = ra.w * ck.fx2, l1 = ra.w * ck.fy2;
                             double BD[6];
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
@@ -940,14 +949,13 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 BD[3 * r + 2] = B1[3 * r] * Db.x + B1[3 * r + 1] * Dc.x + B1[3 * r + 2] * Dc.y;
                             }
                             {
-                                const double m0 = ra.w * (BD[0] * g0 + BD[1] * g1 + BD[2] * g2), m1 = ra.w * (BD[3] * g0 + BD[4] * g1 + BD[5] * g2);
+                                const double m0 = l0 * (BD[0] * g0 + BD[1] * g1 + BD[2] * g2), m1 = l1 * (BD[3] * g0 + BD[4] * g1 + BD[5] * g2);
 #pragma unroll
                                 for (int r = 0; r < 6; ++r) accb[r] = a_fma2(A1, r, m0, m1, accb[r]);
                             }
-                            const double ww = ra.w * ra.w;
-                            const double M00 = ww * (BD[0] * B1[0] + BD[1] * B1[1] + BD[2] * B1[2]);
-                            const double M01 = ww * (BD[0] * B1[3] + BD[1] * B1[4] + BD[2] * B1[5]);
-                            const double M11 = ww * (BD[3] * B1[3] + BD[4] * B1[4] + BD[5] * B1[5]);
+                            const double M00 = l0 * l0 * (BD[0] * B1[0] + BD[1] * B1[1] + BD[2] * B1[2]);
+                            const double M01 = l0 * l1 * (BD[0] * B1[3] + BD[1] * B1[4] + BD[2] * B1[5]);
+                            const double M11 = l1 * l1 * (BD[3] * B1[3] + BD[4] * B1[4] + BD[5] * B1[5]);
 #pragma unroll
                             for (int r = 0; r < 6; ++r) {
                                 const double m0 = a_dot2(A1, r, M00, M01), m1 = a_dot2(A1, r, M01, M11);
@@ -998,12 +1006,12 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             loadD(hn.y, Dan, Dbn, Dcn);
                             double A1[12], A2[12], B1[6], B2[6];
                             double4 ra, rb; // both observations of the landmark: 24 B of landmark + two weights instead of 64 B of records
-                            cam_point(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
-                            cam_point(R2, pax, pay, paz, rb.x, rb.y, rb.z); rb.w = wb;
-                            jac_pose(K, ra.x, ra.y, ra.z, A1);
-                            jac_point(A1, R1, B1);
-                            jac_pose(K, rb.x, rb.y, rb.z, A2);
-                            jac_point(A2, R2, B2);
+                            cam_norm(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
+                            cam_norm(R2, pax, pay, paz, rb.x, rb.y, rb.z); rb.w = wb;
+                            jac_norm(ra.x, ra.y, ra.z, A1);
+                            jac_point_norm(ra.x, ra.y, ra.z, R1, B1);
+                            jac_norm(rb.x, rb.y, rb.z, A2);
+                            jac_point_norm(rb.x, rb.y, rb.z, R2, B2);
                             double BD[6];
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
@@ -1011,12 +1019,13 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 BD[3 * r + 1] = B1[3 * r] * Da.y + B1[3 * r + 1] * Db.y + B1[3 * r + 2] * Dc.x;
                                 BD[3 * r + 2] = B1[3 * r] * Db.x + B1[3 * r + 1] * Dc.x + B1[3 * r + 2] * Dc.y;
                             }
-                            const double ww = ra.w * rb.w;
+                            const double ww = ra.w * rb.w; // M = L1 (Bt1 D Bt2^T) L2 with L = w diag(fx^2, fy^2)
+                            const double lw[4] = {ww * ck.fx2 * ck.fx2, ww * ck.fx2 * ck.fy2, ww * ck.fy2 * ck.fx2, ww * ck.fy2 * ck.fy2};
                             double M[4];
 #pragma unroll
                             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                                for (int c = 0; c < 2; ++c) M[2 * r + c] = ww * (BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]);
+                                for (int c = 0; c < 2; ++c) M[2 * r + c] = lw[2 * r + c] * (BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]);
 #pragma unroll
                             for (int r = 0; r < 6; ++r) {
                                 const double m0 = a_dot2(A1, r, M[0], M[2]), m1 = a_dot2(A1, r, M[1], M[3]);
@@ -1213,10 +1222,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         if (!on[u]) { PC(Pt, 0, l) = px[u]; PC(Pt, 1, l) = py[u]; PC(Pt, 2, l) = pz[u]; continue; }
                         double c0 = g0[u], c1 = g1[u], c2 = g2[u];
                         auto sub_edge = [&](int k, float2 z) {
-                            double X, Y, Zi, wg, ex, ey, c, rho, A[12], B[6];
-                            lin_record(&sm.Rt[12 * k], K, px[u], py[u], pz[u], z, delta, true, X, Y, Zi, wg, ex, ey, c, rho);
-                            jac_pose(K, X, Y, Zi, A);
-                            jac_point(A, &sm.Rt[12 * k], B);
+                            double x, y, ri, wg, ex, ey, c, rho, A[12], B[6];
+                            cam_norm(&sm.Rt[12 * k], px[u], py[u], pz[u], x, y, ri);
+                            eval_obs(ck, x, y, z, delta, ex, ey, c, rho, wg);
+                            jac_norm(x, y, ri, A);
+                            jac_point_norm(x, y, ri, &sm.Rt[12 * k], B);
                             // W^T xp = w B^T (A xp_k)
                             double a0 = 0, a1 = 0;
 #pragma unroll
@@ -1225,7 +1235,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 if (r != 1) a0 = fma(A[r], xr, a0);
                                 if (r != 0) a1 = fma(A[6 + r], xr, a1);
                             }
-                            a0 *= wg; a1 *= wg;
+                            a0 *= wg * ck.fx2; a1 *= wg * ck.fy2;
                             c0 -= B[0] * a0 + B[3] * a1; c1 -= B[1] * a0 + B[4] * a1; c2 -= B[2] * a0 + B[5] * a1;
                         };
 #pragma unroll
