@@ -833,10 +833,12 @@ int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
     LevelTable T;
     fill_level_table(plan, &T);
     const size_t smem = (size_t)kCandCap * 8 * 2 + 272 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {false}; // per device
+    int dev = 0;
+    VS_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     ProfScope prof__(stream, "orb_select_kernel");
     hipLaunchKernelGGL(orb_select_kernel, dim3(B, kNLevels), dim3(kSelBlock), smem, stream, T, d_imgs, img_bytes, pitch, d_pyr,
@@ -867,20 +869,31 @@ __device__ inline int block_rank_1024(bool flag, int* s_wave_tot, int& total) {
 }
 
 // Input: either 8 per-level lists (d_sel, d_sel_cnt; in_capacity = sel_cap) or one flat list (levels = 1).
-__global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoint* __restrict__ d_in, const int32_t* __restrict__ d_nin,
+// CAP = keypoints the workgroup can hold.  LDS per workgroup = 32 KB sort buffer (4096 u64, also the home of the grid lists) +
+// CAP x (8 B position + 4 B response + 2 B source index): 77.6 KB at CAP = 3328, so TWO workgroups share a CU (and the register
+// budget is held to 64 VGPRs for the same reason) -- the phases of this kernel are chains of barriers and LDS round trips that
+// leave the CU idle most of the time, and a second image fills the gaps.  The f64 radii live in global memory (written once, read
+// twice, coalesced); the output-order list reuses the response array, which is dead by then.
+constexpr size_t anms_lds_bytes(int cap) { return (size_t)kMaxRows * 8 + (size_t)cap * (8 + 4 + 2) + 16 + 4 * (kAnmsBlock / 64 + kNLevels + 1 + 3); }
+constexpr int kAnmsCapPipe = 3328; // the detector emits at most nfeatures = 3000 keypoints plus ties at the per-level cuts
+static_assert(2 * anms_lds_bytes(kAnmsCapPipe) <= 160 * 1024, "two ANMS workgroups must fit one CU's LDS");
+
+template <int CAP>
+__global__ __launch_bounds__(kAnmsBlock, 8) void orb_anms_kernel(const vslam_keypoint* __restrict__ d_in, const int32_t* __restrict__ d_nin,
                                                              int nlists, int in_capacity, int anms_num, int regroup, int img_w,
                                                              int img_h, vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, int kp_capacity,
-                                                             int32_t* __restrict__ d_count, int32_t* __restrict__ d_status) {
+                                                             int32_t* __restrict__ d_count, int32_t* __restrict__ d_status, double* __restrict__ d_rad) {
     const int b = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem);                  // kMaxRows u64
-    float2* sxy = reinterpret_cast<float2*>(smem + (size_t)kMaxRows * 8);                    // kMaxRows (x, y) pairs: one broadcast read per candidate
-    float* sr = reinterpret_cast<float*>(sxy + kMaxRows);
-    double* srad = reinterpret_cast<double*>(smem + (size_t)kMaxRows * 8 + (size_t)kMaxRows * 12); // kMaxRows
-    uint16_t* sidx = reinterpret_cast<uint16_t*>(smem + (size_t)kMaxRows * 28);              // kMaxRows : source index per rank
-    uint16_t* sord = sidx + kMaxRows;                                                        // kMaxRows : output order
-    unsigned long long& s_final = *reinterpret_cast<unsigned long long*>(smem + (size_t)kMaxRows * 32);
-    int* s_wave_tot = reinterpret_cast<int*>(smem + (size_t)kMaxRows * 32 + 16);             // kAnmsBlock / 64
+    unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem);                  // kMaxRows u64 (sort buffer; grid lists during the radius phase)
+    float2* sxy = reinterpret_cast<float2*>(smem + (size_t)kMaxRows * 8);                    // CAP (x, y) pairs: one broadcast read per candidate
+    float* sr = reinterpret_cast<float*>(sxy + CAP);                                         // CAP responses (radius phase only)
+    uint16_t* sord = reinterpret_cast<uint16_t*>(sr);                                        // CAP : output order (after the radius phase)
+    uint16_t* sidx = reinterpret_cast<uint16_t*>(sr + CAP);                                  // CAP : source index per rank
+    double* srad = d_rad + (size_t)b * kMaxRows;                                             // radii, global
+    unsigned char* tail = reinterpret_cast<unsigned char*>(sidx + CAP);
+    unsigned long long& s_final = *reinterpret_cast<unsigned long long*>(tail);
+    int* s_wave_tot = reinterpret_cast<int*>(tail + 16);                                     // kAnmsBlock / 64
     int* s_off = s_wave_tot + kAnmsBlock / 64;                                               // kNLevels + 1
 
     OPH_INIT();
@@ -892,7 +905,7 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
     }
     __syncthreads();
     int N = s_off[nlists];
-    if (N > kMaxRows) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStAnmsOverflow); N = kMaxRows; }
+    if (N > CAP) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStAnmsOverflow); N = CAP; }
     const vslam_keypoint* in = d_in + (size_t)b * nlists * in_capacity;
     auto src_ptr = [&](int g) -> const vslam_keypoint* {
         int k = 0;
@@ -1088,31 +1101,37 @@ __global__ __launch_bounds__(kAnmsBlock) void orb_anms_kernel(const vslam_keypoi
     }
 }
 
-static int launch_anms_common(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int nlists, int in_capacity, int anms_num,
-                              int regroup, int img_w, int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count,
-                              int32_t* d_status, hipStream_t stream) {
-    const size_t smem = (size_t)kMaxRows * (8 + 12 + 8 + 2 + 2) + 16 + 4 * (kAnmsBlock / 64 + kNLevels + 1 + 3);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_anms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+template <int CAP>
+static int launch_anms_t(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int nlists, int in_capacity, int anms_num,
+                         int regroup, int img_w, int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count,
+                         int32_t* d_status, double* d_rad, hipStream_t stream) {
+    constexpr size_t smem = anms_lds_bytes(CAP);
+    static bool attr_set[16] = {false}; // per device: the > 64 KB dynamic-LDS opt-in is a per-device function attribute
+    int dev = 0;
+    VS_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_anms_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     ProfScope prof__(stream, "orb_anms_kernel");
-    hipLaunchKernelGGL(orb_anms_kernel, dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
-                       img_w, img_h, d_kps, d_cs, kp_capacity, d_count, d_status);
+    hipLaunchKernelGGL(orb_anms_kernel<CAP>, dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
+                       img_w, img_h, d_kps, d_cs, kp_capacity, d_count, d_status, d_rad);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
 
 int launch_orb_anms(const OrbPlan& plan, int B, const vslam_keypoint* d_sel, const int32_t* d_sel_cnt, int sel_cap, int anms_num,
-                    int regroup, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status, hipStream_t stream) {
-    return launch_anms_common(B, d_sel, d_sel_cnt, kNLevels, sel_cap, anms_num, regroup, plan.w, plan.h, d_kps, d_cs, kp_capacity, d_count,
-                              d_status, stream);
+                    int regroup, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status, double* d_rad,
+                    hipStream_t stream) {
+    return launch_anms_t<kAnmsCapPipe>(B, d_sel, d_sel_cnt, kNLevels, sel_cap, anms_num, regroup, plan.w, plan.h, d_kps, d_cs, kp_capacity, d_count,
+                                       d_status, d_rad, stream);
 }
 
 int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int in_capacity, int anms_num, int regroup, int img_w,
-                     int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status, hipStream_t stream) {
-    return launch_anms_common(B, d_in, d_nin, 1, in_capacity, anms_num, regroup, img_w, img_h, d_kps, d_cs, kp_capacity, d_count, d_status, stream);
+                     int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status, double* d_rad,
+                     hipStream_t stream) {
+    return launch_anms_t<kMaxRows>(B, d_in, d_nin, 1, in_capacity, anms_num, regroup, img_w, img_h, d_kps, d_cs, kp_capacity, d_count, d_status, d_rad,
+                                   stream);
 }
 
 // ------------------------------------------------------------------------------------------- K6 blur + rBRIEF
