@@ -220,11 +220,16 @@ int launch_gather_uv(const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT,
 // ---- measurement aid: what a plain streaming copy reaches on this box (the achievable HBM ceiling next to the 8 TB/s spec)
 __global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) { // four independent 16-B loads in flight per lane before the first store
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 int launch_hbm_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t stream) {
     const size_t n = bytes / 16;
-    hipLaunchKernelGGL(hbm_copy_probe_kernel, dim3(256 * 16), dim3(256), 0, stream, (const float4*)src, (float4*)dst, n);
+    hipLaunchKernelGGL(hbm_copy_probe_kernel, dim3(256 * 8), dim3(256), 0, stream, (const float4*)src, (float4*)dst, n);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
