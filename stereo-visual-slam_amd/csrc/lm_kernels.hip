@@ -65,6 +65,7 @@ constexpr int kLin = 2;        // doubles per edge of linearisation scratch: the
 constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
 constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
 constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work items (keyframe pairs) per wave
+constexpr int kLmSlots = 4;    // observations per landmark kept in the slot table (the rest is reached through the CSR)
 
 size_t lm_hits_per_edge() { return kHitsPerEdge; }
 
@@ -101,6 +102,9 @@ struct LmKernelArgs {
     float* uvk;       // 2 x total_edge: observations in keyframe-major order
     int32_t* status;  // n_windows
     long long* dbg_cycles; // tuning aid (VSLAM_LM_PROFILE=1): 16 phase cycle counters per window, thread 0
+    float* slot_uv;   // kLmSlots x total_lm float2: observation q of landmark l at [q * nl + l] (window-local), landmark-wise phases
+    uint8_t* slot_kf; // kLmSlots x total_lm: its keyframe
+    uint8_t* lcnt;    // total_lm: observations of an ACTIVE landmark, 0 = not in the graph
     int dinv_lds;     // landmarks per window whose Dinv is kept in dynamic LDS (0 = none)
     int want_chi2;    // the caller passed a chi2 output array: scatter chi2 back to its edge order at the end
 };
@@ -397,6 +401,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     int32_t* pair_ptr = a.pair_ptr + (size_t)w * (kMaxPairs + 1);
     int2* hits = reinterpret_cast<int2*>(a.pair_hits) + (size_t)e0 * kHitsPerEdge; // off-diagonal pairs only: {pos1 | pos2 << 16, landmark}
     uint8_t* act = ka.act + lm0;
+    uint8_t* lcnt = ka.lcnt + lm0;
+    float2* suv = reinterpret_cast<float2*>(ka.slot_uv) + (size_t)kLmSlots * lm0; // [q * nl + l]
+    uint8_t* skf = ka.slot_kf + (size_t)kLmSlots * lm0;
     const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
     const CamK ck = make_camk(K);
     const double delta = a.huber_delta;
@@ -474,17 +481,37 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     }
     for (int l0 = tid; l0 < nl; l0 += 3 * kLmBlock) {
         bool on[3];
+        int cn[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int l = min(l0 + u * kLmBlock, nl - 1);
-            on[u] = true;
+            on[u] = true; cn[u] = 1;
             if (!IMPL) {
-                on[u] = lm_ptr[l + 1] > lm_ptr[l] && a.lm_inlier[lm0 + l] != 0;
+                cn[u] = lm_ptr[l + 1] - lm_ptr[l];
+                on[u] = cn[u] > 0 && a.lm_inlier[lm0 + l] != 0;
                 if (with_lm && a.reliable) on[u] = on[u] && a.reliable[lm0 + l] != 0;
             }
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u) if (l0 + u * kLmBlock < nl) act[l0 + u * kLmBlock] = on[u];
+        for (int u = 0; u < 3; ++u)
+            if (l0 + u * kLmBlock < nl) { act[l0 + u * kLmBlock] = on[u]; if (!IMPL) lcnt[l0 + u * kLmBlock] = on[u] ? (uint8_t)min(cn[u], 255) : 0; }
+    }
+    // Slot table of the landmark-wise phases: observation q < kLmSlots of landmark l at [q * nl + l].  A lane that owns landmark l
+    // fetches its position, its count and its first observations in ONE round trip, coalesced across the lanes (through the CSR it
+    // was lm_ptr -> edge list -> data: two dependent trips, the second one scattered).  The edges do not change inside a schedule.
+    if (!IMPL && !reuse_csr && with_lm) {
+        for (int eb = tid; eb < ne; eb += 4 * kLmBlock) {
+            int lv[4], kv[4], bv[4]; float2 zv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = min(eb + u * kLmBlock, ne - 1); lv[u] = lmi[e]; kv[u] = kfi[e]; zv[u] = reinterpret_cast<const float2*>(uv)[e]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bv[u] = lm_ptr[lv[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + u * kLmBlock, q = e - bv[u];
+                if (e < ne && q < kLmSlots) { suv[(size_t)q * nl + lv[u]] = zv[u]; skf[(size_t)q * nl + lv[u]] = (uint8_t)kv[u]; }
+            }
+        }
     }
     __syncthreads();
     if (!IMPL) {
@@ -658,7 +685,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // then the arithmetic -- the per-thread summation order is unchanged.
     const float2* uv2 = reinterpret_cast<const float2*>(uv);
     constexpr int kEvalU = 4;
-    constexpr int kLmU = 3, kLmE = 4; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
+    constexpr int kLmU = 3, kLmE = kLmSlots; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
     // Evaluation + linearisation at (Rt, Pcur) in one keyframe-major pass.  The keyframe-major edge lists are cut into rows
     // of 64 edges (a row never straddles two keyframes); every wave owns a contiguous range of rows and streams it through
     // a register queue (landmark ids and observations four rows ahead, landmark positions two rows ahead: the lists come from
@@ -827,21 +854,21 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         double maxdiag = 0;
         if (with_lm && !boot) {
             for (int l0 = tid; l0 < nl; l0 += kLmU * kLmBlock) {
-                int b0[kLmU], b1[kLmU];
+                int cn[kLmU];
                 double px[kLmU], py[kLmU], pz[kLmU];
                 bool on[kLmU];
+                int kk[kLmU][kLmE]; float2 zz[kLmU][kLmE];
+                // one round trip: count, position and the first kLmE observations of the lane's landmarks (slot table)
 #pragma unroll
                 for (int u = 0; u < kLmU; ++u) {
                     const int l = min(l0 + u * kLmBlock, nl - 1);
-                    on[u] = act[l] != 0 && l0 + u * kLmBlock < nl;
-                    b0[u] = lm_ptr[l]; b1[u] = lm_ptr[l + 1];
+                    cn[u] = lcnt[l];
                     px[u] = PC(P, 0, l); py[u] = PC(P, 1, l); pz[u] = PC(P, 2, l);
+#pragma unroll
+                    for (int q = 0; q < kLmE; ++q) { kk[u][q] = skf[(size_t)q * nl + l]; zz[u][q] = suv[(size_t)q * nl + l]; }
                 }
-                int kk[kLmU][kLmE]; float2 zz[kLmU][kLmE];
 #pragma unroll
-                for (int u = 0; u < kLmU; ++u)
-#pragma unroll
-                    for (int q = 0; q < kLmE; ++q) { const int e = max(min(b0[u] + q, ne - 1), 0); kk[u][q] = ne > 0 ? kfi[e] : 0; zz[u][q] = ne > 0 ? uv2[e] : make_float2(0.f, 0.f); }
+                for (int u = 0; u < kLmU; ++u) on[u] = cn[u] > 0 && l0 + u * kLmBlock < nl;
 #pragma unroll
                 for (int u = 0; u < kLmU; ++u) {
                     if (!on[u]) continue;
@@ -860,8 +887,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         g[0] -= Bs[0] * ex + Bs[3] * ey; g[1] -= Bs[1] * ex + Bs[4] * ey; g[2] -= Bs[2] * ex + Bs[5] * ey;
                     };
 #pragma unroll
-                    for (int q = 0; q < kLmE; ++q) if (b0[u] + q < b1[u]) add_edge(kk[u][q], zz[u][q]);
-                    for (int e = b0[u] + kLmE; e < b1[u]; ++e) add_edge(kfi[e], uv2[e]); // rare: more than kLmE observations
+                    for (int q = 0; q < kLmE; ++q) if (q < cn[u]) add_edge(kk[u][q], zz[u][q]);
+                    if (cn[u] > kLmE) { // more than kLmE observations: the rest through the CSR
+                        const int b0 = lm_ptr[l];
+                        for (int e = b0 + kLmE; e < b0 + cn[u]; ++e) add_edge(kfi[e], uv2[e]);
+                    }
                     if (!lam_known) {
 #pragma unroll
                         for (int i = 0; i < 6; ++i) PC(Hll, i, l) = h[i];
@@ -1195,26 +1225,25 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             double scale_part = 0;
             if (with_lm) {
                 for (int l0 = tid; l0 < nl; l0 += kLmU * kLmBlock) {
-                    int b0[kLmU], b1[kLmU];
+                    int cn[kLmU];
                     double px[kLmU], py[kLmU], pz[kLmU], g0[kLmU], g1[kLmU], g2[kLmU], Dq[kLmU][6];
                     bool on[kLmU], in[kLmU];
+                    int kk[kLmU][kLmE]; float2 zz[kLmU][kLmE];
 #pragma unroll
                     for (int u = 0; u < kLmU; ++u) {
                         const int l = min(l0 + u * kLmBlock, nl - 1);
                         in[u] = l0 + u * kLmBlock < nl;
-                        on[u] = act[l] != 0 && in[u];
-                        b0[u] = lm_ptr[l]; b1[u] = lm_ptr[l + 1];
+                        cn[u] = lcnt[l];
+#pragma unroll
+                        for (int q = 0; q < kLmE; ++q) { kk[u][q] = skf[(size_t)q * nl + l]; zz[u][q] = suv[(size_t)q * nl + l]; }
                         px[u] = PC(P, 0, l); py[u] = PC(P, 1, l); pz[u] = PC(P, 2, l);
                         g0[u] = PC(bl, 0, l); g1[u] = PC(bl, 1, l); g2[u] = PC(bl, 2, l);
                         double2 da, dbb, dc;
                         loadD(l, da, dbb, dc);
                         Dq[u][0] = da.x; Dq[u][1] = da.y; Dq[u][2] = dbb.x; Dq[u][3] = dbb.y; Dq[u][4] = dc.x; Dq[u][5] = dc.y;
                     }
-                    int kk[kLmU][kLmE]; float2 zz[kLmU][kLmE];
 #pragma unroll
-                    for (int u = 0; u < kLmU; ++u)
-#pragma unroll
-                        for (int q = 0; q < kLmE; ++q) { const int e = max(min(b0[u] + q, ne - 1), 0); kk[u][q] = ne > 0 ? kfi[e] : 0; zz[u][q] = ne > 0 ? uv2[e] : make_float2(0.f, 0.f); }
+                    for (int u = 0; u < kLmU; ++u) on[u] = cn[u] > 0 && in[u];
 #pragma unroll
                     for (int u = 0; u < kLmU; ++u) {
                         if (!in[u]) continue;
@@ -1239,8 +1268,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             c0 -= B[0] * a0 + B[3] * a1; c1 -= B[1] * a0 + B[4] * a1; c2 -= B[2] * a0 + B[5] * a1;
                         };
 #pragma unroll
-                        for (int q = 0; q < kLmE; ++q) if (b0[u] + q < b1[u]) sub_edge(kk[u][q], zz[u][q]);
-                        for (int e = b0[u] + kLmE; e < b1[u]; ++e) sub_edge(kfi[e], uv2[e]);
+                        for (int q = 0; q < kLmE; ++q) if (q < cn[u]) sub_edge(kk[u][q], zz[u][q]);
+                        if (cn[u] > kLmE) {
+                            const int b0 = lm_ptr[l];
+                            for (int e = b0 + kLmE; e < b0 + cn[u]; ++e) sub_edge(kfi[e], uv2[e]);
+                        }
                         const double x0 = Dq[u][0] * c0 + Dq[u][1] * c1 + Dq[u][2] * c2;
                         const double x1 = Dq[u][1] * c0 + Dq[u][3] * c1 + Dq[u][4] * c2;
                         const double x2 = Dq[u][2] * c0 + Dq[u][4] * c1 + Dq[u][5] * c2;
@@ -1386,6 +1418,9 @@ static int carve(LmScratch& g_lm, LmKernelArgs& ka, size_t total_lm, size_t tota
     const size_t o_chi = need; need += al(total_edge * 8);
     const size_t o_chik = need; need += al(total_edge * 8);
     const size_t o_uvk = need; need += al(total_edge * 8);
+    const size_t o_suv = need; need += with_lm ? al(total_lm * kLmSlots * 8) : 256;
+    const size_t o_skf = need; need += with_lm ? al(total_lm * kLmSlots) : 256;
+    const size_t o_lcnt = need; need += al(total_lm);
     // hipFree/hipMalloc are synchronising; growth only happens on the first call of a given size
     if (g_lm.bytes < need) { hipStreamSynchronize(stream); int rc = ensure(&g_lm.buf, &g_lm.bytes, need); if (rc) return rc; }
     uint8_t* base = (uint8_t*)g_lm.buf;
@@ -1397,6 +1432,7 @@ static int carve(LmScratch& g_lm, LmKernelArgs& ka, size_t total_lm, size_t tota
     g_lm.status = ka.status; g_lm.status_n = n_windows;
     if (!ka.a.chi2) ka.a.chi2 = (double*)(base + o_chi);
     ka.chi2k = (double*)(base + o_chik); ka.uvk = (float*)(base + o_uvk);
+    ka.slot_uv = (float*)(base + o_suv); ka.slot_kf = base + o_skf; ka.lcnt = base + o_lcnt;
     return VSLAM_OK;
 }
 
