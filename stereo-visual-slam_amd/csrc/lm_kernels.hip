@@ -716,7 +716,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             RowIt ahead = cur;
             int lq[4];
             float2 zq[4];
-            double pq[2][3];
+#ifndef VSLAM_LM_EVAL_PD
+#define VSLAM_LM_EVAL_PD 2
+#endif
+            constexpr int kPD = VSLAM_LM_EVAL_PD; // rows of landmark positions in flight (ids are 4 rows ahead)
+            double pq[kPD][3];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int jj = min(ahead.j + lane, ahead.jend - 1);
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 row_next(ahead);
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < kPD; ++q)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) pq[q][c] = PC(Pcur, c, lq[q]);
             double acc[27];
@@ -760,7 +764,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     zq[0] = zq[1]; zq[1] = zq[2]; zq[2] = zq[3]; zq[3] = uvk2[jj];
                     row_next(ahead);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { pq[0][c] = pq[1][c]; pq[1][c] = PC(Pcur, c, lq[1]); }
+                    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                        for (int q = 0; q + 1 < kPD; ++q) pq[q][c] = pq[q + 1][c];
+                        pq[kPD - 1][c] = PC(Pcur, c, lq[kPD - 1]);
+                    }
                 }
                 const int j = cur.j + lane;
                 if (j < cur.jend) {

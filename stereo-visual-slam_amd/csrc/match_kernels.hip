@@ -33,30 +33,34 @@ __device__ inline int4 expand_half(uint32_t bits16) {
     return make_int4((int)expand_nibble(bits16), (int)expand_nibble(bits16 >> 4), (int)expand_nibble(bits16 >> 8), (int)expand_nibble(bits16 >> 12));
 }
 
+#ifndef VSLAM_MATCH_CT
+#define VSLAM_MATCH_CT 2
+#endif
 constexpr int kMatchBlock = 256;             // 4 waves
-constexpr int kColsPerWave = 64;             // two 32-column MFMA tiles held in registers
+constexpr int kColTiles = VSLAM_MATCH_CT;    // 32-column MFMA tiles per wave held in registers (2: accumulators double-buffered; 4: one A read feeds four tiles)
+constexpr int kColsPerWave = 32 * kColTiles;
 constexpr int kColsPerBlock = (kMatchBlock / 64) * kColsPerWave;
 constexpr int kQRows = 32;                   // query rows per LDS tile
 constexpr int kQStride = 272;                // bytes per staged query row (256 + 16: conflict-free 16-B reads)
 
-// epilogue of one 32 x 32 tile: fold the 16 accumulator slots of this lane into the running maximum of
+// epilogue of one 32-row query tile: fold the 16 accumulator slots of this lane (per column tile) into the running maximum of
 // dot << 16 | (0xFFFF - row) (signed compare: largest dot = smallest distance, then smallest row)
-__device__ inline void fold_tile(const v16i& acc0, const v16i& acc1, int ib, int nq, bool full, int& m0, int& m1) {
+__device__ inline void fold_tile(const v16i (&acc)[kColTiles], int ib, int nq, bool full, int (&m)[kColTiles]) {
     const int inv = 0xFFFF - ib;
     if (full) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int iv = inv - (8 * (v / 4) + (v % 4));
-            m0 = max(m0, (acc0[v] << 16) + iv);
-            m1 = max(m1, (acc1[v] << 16) + iv);
+#pragma unroll
+            for (int t = 0; t < kColTiles; ++t) m[t] = max(m[t], (acc[t][v] << 16) + iv);
         }
     } else { // last, partial tile: rows >= nq must not compete
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int off = 8 * (v / 4) + (v % 4);
             if (ib + off < nq) {
-                m0 = max(m0, (acc0[v] << 16) + inv - off);
-                m1 = max(m1, (acc1[v] << 16) + inv - off);
+#pragma unroll
+                for (int t = 0; t < kColTiles; ++t) m[t] = max(m[t], (acc[t][v] << 16) + inv - off);
             }
         }
     }
@@ -79,13 +83,18 @@ __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
     if (tile0 >= tile1) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     __shared__ alignas(16) int8_t sq[2][kQRows * kQStride];
+    __shared__ uint2 lut[256]; // descriptor byte -> its eight +-1 operand bytes
+    {
+        const uint32_t v = threadIdx.x;
+        lut[v] = make_uint2(expand_nibble(v), expand_nibble(v >> 4));
+    }
     const uint8_t* Q = d_q + (size_t)b * q_stride;
     const uint8_t* T = d_t + (size_t)b * t_stride;
     // B operands: this wave's 64 train columns, expanded once and resident for the whole kernel.  Operand slice s of lane
     // (r, h) holds k = 32 s + 16 h .. + 15, i.e. halfword 2 s + h of the descriptor.
-    v4i breg[2][8];
+    v4i breg[kColTiles][8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < kColTiles; ++t) {
         const int j = min(c0 + wave * kColsPerWave + 32 * t + r, nt - 1);
         const uint4 lo = *reinterpret_cast<const uint4*>(T + (size_t)j * 32), hi = *reinterpret_cast<const uint4*>(T + (size_t)j * 32 + 16);
         const uint32_t wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -102,53 +111,69 @@ __global__ __launch_bounds__(kMatchBlock) void match_train_nearest_kernel(
         x = reinterpret_cast<const uint32_t*>(Q + (size_t)r0 * 32)[sword];
     };
     auto sstore = [&](int buf, uint32_t x) {
-        const int4 e0 = expand_half(x & 0xFFFFu), e1 = expand_half(x >> 16);
+        const uint2 b0 = lut[x & 0xFFu], b1 = lut[(x >> 8) & 0xFFu], b2 = lut[(x >> 16) & 0xFFu], b3 = lut[x >> 24];
         int4* dst = reinterpret_cast<int4*>(&sq[buf][srow * kQStride + sword * 32]);
-        dst[0] = e0; dst[1] = e1;
+        dst[0] = make_int4((int)b0.x, (int)b0.y, (int)b1.x, (int)b1.y); dst[1] = make_int4((int)b2.x, (int)b2.y, (int)b3.x, (int)b3.y);
     };
-    auto mma_tile = [&](int buf, v16i& acc0, v16i& acc1) {
+    auto mma_tile = [&](int buf, v16i (&acc)[kColTiles]) {
         v4i a[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const v4i*>(&sq[buf][r * kQStride + s * 32 + h * 16]);
+        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // (the first MFMA of a tile reads C = 0 as an inline constant: no accumulator clears)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) { acc0[v] = 0; acc1[v] = 0; }
+        for (int t = 0; t < kColTiles; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], breg[t][0], zero, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], breg[0][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], breg[1][s], acc1, 0, 0, 0);
-        }
+        for (int s = 1; s < 8; ++s)
+#pragma unroll
+            for (int t = 0; t < kColTiles; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], breg[t][s], acc[t], 0, 0, 0);
     };
     uint32_t x;
     gload(tile0, x);
+    __syncthreads(); // the expansion table is complete
     sstore(0, x);
     if (tile0 + 1 < tile1) gload(tile0 + 1, x);
     __syncthreads();
-    int m0 = INT_MIN, m1 = INT_MIN;
-    // software pipeline: the MFMAs of tile t + 1 are issued before the (VALU) epilogue of tile t
-    v16i accA0, accA1, accB0, accB1;
-    mma_tile(0, accA0, accA1);
-    for (int tile = tile0; tile < tile1; tile += 2) {
-        // ---- stage tile + 1 into buffer 1, issue its MFMAs, then fold tile
-        if (tile + 1 < tile1) { sstore(1, x); if (tile + 2 < tile1) gload(tile + 2, x); }
-        __syncthreads();
-        if (tile + 1 < tile1) mma_tile(1, accB0, accB1);
-        fold_tile(accA0, accA1, tile * kQRows + 4 * h, nq, tile * kQRows + kQRows <= nq, m0, m1);
-        if (tile + 1 >= tile1) break;
-        // ---- stage tile + 2 into buffer 0, issue its MFMAs, then fold tile + 1
-        if (tile + 2 < tile1) { sstore(0, x); if (tile + 3 < tile1) gload(tile + 3, x); }
-        __syncthreads();
-        if (tile + 2 < tile1) mma_tile(0, accA0, accA1);
-        fold_tile(accB0, accB1, (tile + 1) * kQRows + 4 * h, nq, (tile + 1) * kQRows + kQRows <= nq, m0, m1);
+    int m[kColTiles];
+#pragma unroll
+    for (int t = 0; t < kColTiles; ++t) m[t] = INT_MIN;
+    if constexpr (kColTiles <= 2) {
+        // software pipeline: the MFMAs of tile t + 1 are issued before the (VALU) epilogue of tile t (two accumulator sets)
+        v16i accA[kColTiles], accB[kColTiles];
+        mma_tile(0, accA);
+        for (int tile = tile0; tile < tile1; tile += 2) {
+            // ---- stage tile + 1 into buffer 1, issue its MFMAs, then fold tile
+            if (tile + 1 < tile1) { sstore(1, x); if (tile + 2 < tile1) gload(tile + 2, x); }
+            __syncthreads();
+            if (tile + 1 < tile1) mma_tile(1, accB);
+            fold_tile(accA, tile * kQRows + 4 * h, nq, tile * kQRows + kQRows <= nq, m);
+            if (tile + 1 >= tile1) break;
+            // ---- stage tile + 2 into buffer 0, issue its MFMAs, then fold tile + 1
+            if (tile + 2 < tile1) { sstore(0, x); if (tile + 3 < tile1) gload(tile + 3, x); }
+            __syncthreads();
+            if (tile + 2 < tile1) mma_tile(0, accA);
+            fold_tile(accB, (tile + 1) * kQRows + 4 * h, nq, (tile + 1) * kQRows + kQRows <= nq, m);
+        }
+    } else {
+        // four column tiles per wave: one set of accumulators; a query tile read from LDS once feeds 32 MFMAs (half the LDS
+        // traffic per MAC); the other wave of the SIMD fills the MFMA pipe while this one folds
+        v16i acc[kColTiles];
+        for (int tile = tile0; tile < tile1; ++tile) {
+            const int buf = (tile - tile0) & 1;
+            if (tile + 1 < tile1) { sstore(buf ^ 1, x); if (tile + 2 < tile1) gload(tile + 2, x); } // (buffer buf ^ 1 was released by the barrier below)
+            mma_tile(buf, acc);
+            fold_tile(acc, tile * kQRows + 4 * h, nq, tile * kQRows + kQRows <= nq, m);
+            __syncthreads();
+        }
     }
-    m0 = max(m0, __shfl_xor(m0, 32));
-    m1 = max(m1, __shfl_xor(m1, 32));
+#pragma unroll
+    for (int t = 0; t < kColTiles; ++t) m[t] = max(m[t], __shfl_xor(m[t], 32));
     if (h == 0) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int m = t ? m1 : m0;
+        for (int t = 0; t < kColTiles; ++t) {
+            const int mm = m[t];
             const int j = c0 + wave * kColsPerWave + 32 * t + r;
-            if (j < nt && m != INT_MIN) {
-                const uint32_t d = (uint32_t)(256 - (m >> 16)) >> 1, i = 0xFFFFu - ((uint32_t)m & 0xFFFFu);
+            if (j < nt && mm != INT_MIN) {
+                const uint32_t d = (uint32_t)(256 - (mm >> 16)) >> 1, i = 0xFFFFu - ((uint32_t)mm & 0xFFFFu);
                 const uint32_t key = (d << 16) | i;
                 if (qsplit == 1) d_train_best[(size_t)b * max_rows + j] = key;
                 else atomicMin(&d_train_best[(size_t)b * max_rows + j], key);
