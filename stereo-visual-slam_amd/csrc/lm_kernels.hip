@@ -65,7 +65,10 @@ constexpr int kLin = 2;        // doubles per edge of linearisation scratch: the
 constexpr int kPoseParts = 3;  // a pose's by-pose edge list is summed by this many waves (parts added in a fixed order)
 constexpr int kCntStride = 80; // per-wave counter row (>= kMaxPairs)
 constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work items (keyframe pairs) per wave
-constexpr int kLmSlots = 4;    // observations per landmark kept in the slot table (the rest is reached through the CSR)
+#ifndef VSLAM_LM_SLOTS
+#define VSLAM_LM_SLOTS 5
+#endif
+constexpr int kLmSlots = VSLAM_LM_SLOTS;    // observations per landmark kept in the slot table (the rest is reached through the CSR)
 
 size_t lm_hits_per_edge() { return kHitsPerEdge; }
 
@@ -685,7 +688,10 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // then the arithmetic -- the per-thread summation order is unchanged.
     const float2* uv2 = reinterpret_cast<const float2*>(uv);
     constexpr int kEvalU = 4;
-    constexpr int kLmU = 3, kLmE = kLmSlots; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
+#ifndef VSLAM_LM_U
+#define VSLAM_LM_U 2
+#endif
+    constexpr int kLmU = VSLAM_LM_U, kLmE = kLmSlots; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
     // Evaluation + linearisation at (Rt, Pcur) in one keyframe-major pass.  The keyframe-major edge lists are cut into rows
     // of 64 edges (a row never straddles two keyframes); every wave owns a contiguous range of rows and streams it through
     // a register queue (landmark ids and observations four rows ahead, landmark positions two rows ahead: the lists come from
