@@ -110,11 +110,15 @@ __device__ inline void load_tile_u8(uint8_t* lds, int lds_pitch, const uint8_t* 
             const int r = i / tw4, c4 = (i - r * tw4) << 2;
             const int y = REFLECT ? reflect101(y0 + r, H) : min(max(y0 + r, 0), H - 1);
             const uint8_t* row = src + (size_t)y * spitch;
+            const int xa = x0 + c4;
             uint32_t v = 0;
+            if (xa >= 0 && xa + 4 <= W) __builtin_memcpy(&v, row + xa, 4); // only the dwords that straddle the edge go byte by byte
+            else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int x = REFLECT ? reflect101(x0 + c4 + k, W) : min(max(x0 + c4 + k, 0), W - 1);
-                v |= (uint32_t)row[x] << (8 * k);
+                for (int k = 0; k < 4; ++k) {
+                    const int x = REFLECT ? reflect101(xa + k, W) : min(max(xa + k, 0), W - 1);
+                    v |= (uint32_t)row[x] << (8 * k);
+                }
             }
             *reinterpret_cast<uint32_t*>(lds + r * lds_pitch + c4) = v;
         }
@@ -303,6 +307,11 @@ constexpr int kPixW = kTileW + 8, kPixH = kTileH + 8;  // 72 x 24 pixel tile (ha
 constexpr int kScW = kTileW + 2, kScH = kTileH + 2;    // 66 x 18 score tile (halo 1)
 constexpr int kPixPitch = kPixW + 4;                    // LDS row pitch (bytes)
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ inline s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ inline s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ inline s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
 __device__ inline bool ring9(uint32_t m) {
     const uint32_t x = m | (m << 16);
     const uint32_t a = x & (x >> 1);
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
     const int ox = kEdge + tx * kTileW, oy = kEdge + ty * kTileH; // first emitted pixel of this tile
 
     __shared__ __attribute__((aligned(16))) uint8_t pix[kPixH * kPixPitch];
-    __shared__ uint8_t sc[kScH * kScW];
+    __shared__ __attribute__((aligned(4))) uint8_t sc[(kScH * kScW + 3) / 4 * 4];
     __shared__ uint16_t queue[kScH * kScW];   // positions that pass the compass pre-test
     __shared__ uint16_t cqueue[kScH * kScW];  // corners
     __shared__ uint32_t outq[kTileW * kTileH / 4];
@@ -363,24 +372,51 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
     OPH_INIT();
     if (threadIdx.x == 0) { qcount = 0; ccount = 0; ocount = 0; }
     load_tile_u8<false, 256>(pix, kPixPitch, V.ptr, V.pitch, V.w, V.h, ox - 4, oy - 4, kPixW, kPixH);
-    for (int i = threadIdx.x; i < kScH * kScW; i += 256) sc[i] = 0;
+    for (int i = threadIdx.x; i < (kScH * kScW + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
     __syncthreads();
     OPH(16);
 
-    // (a) compass pre-test on the 66 x 18 score region: a 9-arc always contains two ADJACENT compass pixels (ring
+    // (a) compass pre-test on the score region (tile + halo 1): a 9-arc always contains two ADJACENT compass pixels (ring
     // positions 0, 4, 8, 12), so a corner needs two adjacent compass pixels all brighter or all darker.  Cheap, and it
-    // thins the candidates before the full 16-pixel test runs with all lanes busy.
-    for (int i = threadIdx.x; i < kScH * kScW; i += 256) {
-        const int sy = i / kScW, sx = i - sy * kScW;
-        const int x = ox - 1 + sx, y = oy - 1 + sy;
-        if (x >= V.w - 3 || y >= V.h - 3) continue; // outside cv::FAST's own range (left/top are always >= 30)
-        const uint8_t* p = &pix[(sy + 3) * kPixPitch + sx + 3];
-        const int v = p[0], hi = v + thr, lo = v - thr;
-        const int c0 = p[3 * kPixPitch], c4 = p[3], c8 = p[-3 * kPixPitch], c12 = p[-3];
-        const bool b0 = c0 > hi, b4 = c4 > hi, b8 = c8 > hi, b12 = c12 > hi;
-        const bool d0 = c0 < lo, d4 = c4 < lo, d8 = c8 < lo, d12 = c12 < lo;
-        const bool pass = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (d0 & d4) | (d4 & d8) | (d8 & d12) | (d12 & d0);
-        if (pass) queue[atomicAdd(&qcount, 1)] = (uint16_t)i;
+    // thins the candidates before the full 16-pixel test runs with all lanes busy.  One lane tests the four pixels of an aligned
+    // dword of the pixel tile: five dword LDS reads, the bytes widened to packed i16 pairs (v_perm), "brighter" / "darker" as
+    // signed differences (c - (v + t) > 0, (v - t) - c > 0), AND = packed min, OR = packed max.
+    {
+        constexpr int kGroups = (kScW + 3 + 3) / 4; // pixel-tile columns 3 .. kScW + 2 in dwords of four
+        const s16x2 vthr = {(short)thr, (short)thr};
+        for (int i = threadIdx.x; i < kScH * kGroups; i += 256) {
+            const int sy = i / kGroups, g = i - sy * kGroups;
+            const int y = oy - 1 + sy;
+            if (y >= V.h - 3) continue; // outside cv::FAST's own range (left/top are always >= 30)
+            const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&pix[(sy + 3) * kPixPitch]);
+            const uint32_t D0 = g > 0 ? rowc[g - 1] : 0u, D1 = rowc[g], D2 = rowc[g + 1];
+            const uint32_t U = reinterpret_cast<const uint32_t*>(&pix[sy * kPixPitch])[g];       // row - 3 (ring position 8)
+            const uint32_t L = reinterpret_cast<const uint32_t*>(&pix[(sy + 6) * kPixPitch])[g]; // row + 3 (ring position 0)
+            uint32_t mask = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { // pixels (4 g + 2 h, 4 g + 2 h + 1) of the pixel tile
+                const s16x2 v = as_s16x2(__builtin_amdgcn_perm(0u, D1, h ? 0x0c030c02u : 0x0c010c00u));
+                const s16x2 c0 = as_s16x2(__builtin_amdgcn_perm(0u, L, h ? 0x0c030c02u : 0x0c010c00u));
+                const s16x2 c8 = as_s16x2(__builtin_amdgcn_perm(0u, U, h ? 0x0c030c02u : 0x0c010c00u));
+                const s16x2 c4 = as_s16x2(h ? __builtin_amdgcn_perm(0u, D2, 0x0c020c01u) : __builtin_amdgcn_perm(D2, D1, 0x0c040c03u));   // x + 3
+                const s16x2 c12 = as_s16x2(h ? __builtin_amdgcn_perm(D1, D0, 0x0c040c03u) : __builtin_amdgcn_perm(0u, D0, 0x0c020c01u)); // x - 3
+                const s16x2 hi = v + vthr, lo = v - vthr;
+                const s16x2 b0 = c0 - hi, b4 = c4 - hi, b8 = c8 - hi, b12 = c12 - hi;
+                const s16x2 d0 = lo - c0, d4 = lo - c4, d8 = lo - c8, d12 = lo - c12;
+                s16x2 m = pk_max(pk_max(pk_min(b0, b4), pk_min(b4, b8)), pk_max(pk_min(b8, b12), pk_min(b12, b0)));
+                m = pk_max(m, pk_max(pk_max(pk_min(d0, d4), pk_min(d4, d8)), pk_max(pk_min(d8, d12), pk_min(d12, d0))));
+                mask |= (uint32_t)(m.x > 0) << (2 * h) | (uint32_t)(m.y > 0) << (2 * h + 1);
+            }
+            // valid score columns: sx = 4 g - 3 + k in [0, kScW), image column x = ox - 1 + sx < V.w - 3
+            const int sx0 = 4 * g - 3;
+            const int kmin = max(0, -sx0), kmax = min(4, min(kScW - sx0, V.w - 3 - (ox - 1 + sx0)));
+            mask &= kmax > kmin ? ((1u << kmax) - 1u) & ~((1u << kmin) - 1u) : 0u;
+            while (mask) {
+                const int k = __builtin_ctz(mask);
+                mask &= mask - 1;
+                queue[atomicAdd(&qcount, 1)] = (uint16_t)(sy * kScW + sx0 + k);
+            }
+        }
     }
     __syncthreads();
     // (b) full FAST-9/16 test on the survivors
