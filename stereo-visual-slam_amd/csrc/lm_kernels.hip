@@ -694,7 +694,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     constexpr int kLmU = VSLAM_LM_U, kLmE = kLmSlots; // landmark-wise phases: landmarks per batch, observations preloaded per landmark
     // Evaluation + linearisation at (Rt, Pcur) in one keyframe-major pass.  The keyframe-major edge lists are cut into rows
     // of 64 edges (a row never straddles two keyframes); every wave owns a contiguous range of rows and streams it through
-    // a register queue (landmark ids and observations four rows ahead, landmark positions two rows ahead: the lists come from
+    // a register queue (landmark ids and observations two rows ahead, landmark positions one row ahead -- a row is ~2000 cycles of issue, deeper queues only cost register moves: the lists come from
     // HBM / Infinity Cache at ~1 us per dependent access, a row is ~0.5 us of arithmetic).  It writes the Huber
     // weight of every edge for the Schur phase and accumulates the pose blocks (H_pp upper triangle, b_p) on the fly, so the errors
     // never have to be stored; when the keyframe changes the 27 sums are folded (butterfly) into slot (keyframe + wave) --
@@ -720,15 +720,20 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 cur.k = k; cur.j = sm.kfp[k] + 64 * (ra - sm.rowp[k]); cur.jend = sm.kfp[k + 1];
             }
             RowIt ahead = cur;
-            int lq[4];
-            float2 zq[4];
 #ifndef VSLAM_LM_EVAL_PD
-#define VSLAM_LM_EVAL_PD 2
+#define VSLAM_LM_EVAL_PD 1
 #endif
-            constexpr int kPD = VSLAM_LM_EVAL_PD; // rows of landmark positions in flight (ids are 4 rows ahead)
+#ifndef VSLAM_LM_EVAL_QD
+#define VSLAM_LM_EVAL_QD 2
+#endif
+            constexpr int kPD = VSLAM_LM_EVAL_PD; // rows of landmark positions in flight
+            constexpr int kQD = VSLAM_LM_EVAL_QD; // rows of landmark ids / observations in flight (>= kPD)
+            static_assert(kQD >= kPD && kPD >= 1, "queue depths");
+            int lq[kQD];
+            float2 zq[kQD];
             double pq[kPD][3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < kQD; ++q) {
                 const int jj = min(ahead.j + lane, ahead.jend - 1);
                 lq[q] = LMJ(jj); zq[q] = uvk2[jj];
                 row_next(ahead);
@@ -764,10 +769,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 }
                 const float2 z1 = zq[0];
                 const double px = pq[0][0], py = pq[0][1], pz = pq[0][2];
-                { // rotate the queues and refill their tails: ids of row + 4, positions of row + 2
+                { // rotate the queues and refill their tails: ids of row + kQD, positions of row + kPD
                     const int jj = min(ahead.j + lane, ahead.jend - 1);
-                    lq[0] = lq[1]; lq[1] = lq[2]; lq[2] = lq[3]; lq[3] = LMJ(jj);
-                    zq[0] = zq[1]; zq[1] = zq[2]; zq[2] = zq[3]; zq[3] = uvk2[jj];
+#pragma unroll
+                    for (int q = 0; q + 1 < kQD; ++q) { lq[q] = lq[q + 1]; zq[q] = zq[q + 1]; }
+                    lq[kQD - 1] = LMJ(jj); zq[kQD - 1] = uvk2[jj];
                     row_next(ahead);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
