@@ -123,6 +123,25 @@ __device__ inline double wave_max(double v) {
 // Sum N per-lane values over the 64 lanes of a wave with a halving butterfly: at every step a lane sends one half of its
 // values to its partner and keeps (and accumulates) the other half, so N values cost about N shuffles instead of 6 N.
 // On return v[0] holds the wave-wide sum of value wave_slot<N>(lane) (a fixed tree: deterministic).
+// The two widest steps (partner lane ^ 32, lane ^ 16) are the gfx950 half-wave / row swaps: with X = a, Y = b,
+// v_permlane32_swap leaves {keep, received} in {X, Y} of the lower lanes and {received, keep} in the upper ones, so the step is
+// two swaps (one per dword) and the add -- no select, no LDS crossbar; same pairs, same sums as the generic step.
+template <int M>
+__device__ inline double swap_add(double a, double b) {
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    unsigned xl, yl, xh, yh;
+    if constexpr (M == 32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+        xl = lo[0]; yl = lo[1]; xh = hi[0]; yh = hi[1];
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+        xl = lo[0]; yl = lo[1]; xh = hi[0]; yh = hi[1];
+    }
+    return __builtin_bit_cast(double, (unsigned long long)xl | ((unsigned long long)xh << 32)) +
+           __builtin_bit_cast(double, (unsigned long long)yl | ((unsigned long long)yh << 32));
+}
 template <int N>
 __device__ inline void wave_reduce_scatter(double (&v)[N], int lane) {
     int n = N;
@@ -133,8 +152,12 @@ __device__ inline void wave_reduce_scatter(double (&v)[N], int lane) {
 #pragma unroll
         for (int i = 0; i < h; ++i) {
             const double a = v[i], b = (i + h < n) ? v[i + h] : 0.0;
-            const double send = upper ? a : b, keep = upper ? b : a;
-            v[i] = keep + __shfl_xor(send, m);
+            if (m == 32) v[i] = swap_add<32>(a, b);
+            else if (m == 16) v[i] = swap_add<16>(a, b);
+            else {
+                const double send = upper ? a : b, keep = upper ? b : a;
+                v[i] = keep + __shfl_xor(send, m);
+            }
         }
         n = h;
     }
