@@ -241,45 +241,59 @@ void orb_tables_free(OrbTables* t) {
 }
 
 // ------------------------------------------------------------------------------------------- K1 pyramid
-// each thread produces 4 consecutive output pixels of one row: per source row ONE unaligned 8-byte load covers the <= 6
-// source pixels they interpolate (scale 1.2), coefficients come as one int4 + one 16-byte load, the result is one dword store
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t udot2_u16(uint32_t a, uint32_t b) { // v_dot2_u32_u16: a.lo * b.lo + a.hi * b.hi
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), 0u, false);
+}
+// Workgroup = 4 waves; a wave owns kResizeRows consecutive output rows (so the row tables and every row base address are scalar)
+// and a lane four consecutive output pixels: the column setup -- source offsets, coefficient words, byte selectors -- is done
+// once and reused for every row.  Per source row ONE unaligned 8-byte load covers the <= 6 source pixels the four outputs
+// interpolate (scale 1.2); v_perm picks source bytes rel, rel + 1 of the window as a u16 pair; the coefficient word already is
+// (a0, a1) as u16 (both in [0, 2048]), so a row's horizontal pass is one v_dot2_u32_u16; the result is one dword store.
+constexpr int kResizeRows = 4;
 __global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t* __restrict__ src_base, size_t src_img_stride, int spitch,
                                                         int sw, int sh, uint8_t* __restrict__ dst_base, size_t dst_img_stride,
                                                         int dpitch, int dw, int dh, const int* __restrict__ xofs,
                                                         const short* __restrict__ ialpha, const int* __restrict__ yofs,
                                                         const short* __restrict__ ibeta) {
     const int b = blockIdx.z;
-    const int quads = (dw + 3) >> 2;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= quads * dh) return;
-    const int dy = idx / quads, dx0 = (idx - dy * quads) << 2;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dx0 = (blockIdx.x * 64 + lane) << 2;
+    const int dyb = (blockIdx.y * 4 + wave) * kResizeRows;
+    if (dx0 >= dw || dyb >= dh) return;
     const uint8_t* src = src_base + (size_t)b * src_img_stride;
     uint8_t* dst = dst_base + (size_t)b * dst_img_stride;
-    const int sy = yofs[dy];
-    const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
-    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
     const int4 xo = *reinterpret_cast<const int4*>(xofs + dx0);
     const uint4 al = *reinterpret_cast<const uint4*>(ialpha + 2 * dx0); // a0,a1 of 4 pixels as 8 shorts
     // window start: xo.x, pulled back if an 8-byte read would leave the row's pitch
     const int wx = min(xo.x, spitch - 8);
-    unsigned long long r0, r1;
-    __builtin_memcpy(&r0, src + (size_t)y0 * spitch + wx, 8);
-    __builtin_memcpy(&r1, src + (size_t)y1 * spitch + wx, 8);
     const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
     const uint32_t alw[4] = {al.x, al.y, al.z, al.w};
-    uint32_t packed = 0;
+    uint32_t sel[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int rel = sxs[k] - wx;              // 0..6 (the +1 neighbour at most 7)
-        const int a0 = (int)(short)(alw[k] & 0xFFFFu), a1 = (int)(short)(alw[k] >> 16);
-        // when sx is the last source column a1 == 0, so whatever byte sits at rel + 1 does not matter
-        const int p00 = (int)((r0 >> (8 * rel)) & 0xFFu), p01 = (int)((r0 >> (8 * min(rel + 1, 7))) & 0xFFu);
-        const int p10 = (int)((r1 >> (8 * rel)) & 0xFFu), p11 = (int)((r1 >> (8 * min(rel + 1, 7))) & 0xFFu);
-        const int h0 = p00 * a0 + p01 * a1, h1 = p10 * a0 + p11 * a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)(v & 0xFF) << (8 * k);
+    for (int k = 0; k < 4; ++k) // when sx is the last source column a1 == 0: whatever the selector rel + 1 (<= 8) yields does not matter
+        sel[k] = 0x0c010c00u + __umul24((uint32_t)(sxs[k] - wx), 0x00010001u); // rel = 0..7
+#pragma unroll
+    for (int r = 0; r < kResizeRows; ++r) {
+        const int dy = dyb + r; // wave-uniform
+        if (dy >= dh) break;
+        const int sy = yofs[dy];
+        const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+        const uint32_t b0 = (uint32_t)(int)ibeta[2 * dy], b1 = (uint32_t)(int)ibeta[2 * dy + 1];
+        unsigned long long r0, r1;
+        __builtin_memcpy(&r0, src + (size_t)y0 * spitch + wx, 8);
+        __builtin_memcpy(&r1, src + (size_t)y1 * spitch + wx, 8);
+        const uint32_t r0l = (uint32_t)r0, r0h = (uint32_t)(r0 >> 32), r1l = (uint32_t)r1, r1h = (uint32_t)(r1 >> 32);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t h0 = udot2_u16(__builtin_amdgcn_perm(r0h, r0l, sel[k]), alw[k]);
+            const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(r1h, r1l, sel[k]), alw[k]);
+            const uint32_t v = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2; // (11-bit x 15-bit products)
+            packed |= (v & 0xFFu) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + dx0) = packed; // dpitch is a multiple of 64; lanes past dw write padding
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + dx0) = packed; // dpitch is a multiple of 64; lanes past dw write padding
 }
 
 int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B,
@@ -292,7 +306,7 @@ int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t*
         const size_t sstride = l == 1 ? img_bytes : (size_t)plan.pyr_bytes;
         const int spitch = l == 1 ? pitch : ((S.w + 63) & ~63);
         const int dpitch = (D.w + 63) & ~63;
-        dim3 grid((((D.w + 3) / 4) * D.h + 255) / 256, 1, B);
+        dim3 grid(((D.w + 3) / 4 + 63) / 64, (D.h + 4 * kResizeRows - 1) / (4 * kResizeRows), B);
         hipLaunchKernelGGL(orb_resize_kernel, grid, dim3(256), 0, stream, src, sstride, spitch, S.w, S.h, d_pyr + D.pyr_off,
                            (size_t)plan.pyr_bytes, dpitch, D.w, D.h, tab.d_xofs + tab.x_off[l], tab.d_ialpha + 2 * tab.x_off[l],
                            tab.d_yofs + tab.y_off[l], tab.d_ibeta + 2 * tab.y_off[l]);
