@@ -94,7 +94,8 @@ __device__ inline LevelView level_view(const LevelTable& T, int l, const uint8_t
 // Stage a tw x th (tw % 4 == 0) pixel tile with origin (x0, y0) into LDS.  Interior tiles take one unaligned dword load
 // per 4 pixels (global memory tolerates unaligned dwords); tiles that cross the image edge fall back to per-byte loads
 // with reflect-101 (REFLECT) or clamped (!REFLECT) coordinates.
-template <bool REFLECT, int NTHREADS>
+// SKIP_FAR: dwords that start more than 3 columns / rows beyond the image (a 7-tap filter never reads them) are left unwritten.
+template <bool REFLECT, int NTHREADS, bool SKIP_FAR = false>
 __device__ inline void load_tile_u8(uint8_t* lds, int lds_pitch, const uint8_t* __restrict__ src, int spitch, int W, int H, int x0, int y0,
                                     int tw, int th) {
     const int tw4 = tw >> 2;
@@ -108,9 +109,10 @@ __device__ inline void load_tile_u8(uint8_t* lds, int lds_pitch, const uint8_t* 
     } else {
         for (int i = threadIdx.x; i < th * tw4; i += NTHREADS) {
             const int r = i / tw4, c4 = (i - r * tw4) << 2;
+            const int xa = x0 + c4;
+            if (SKIP_FAR && (xa >= W + 4 || y0 + r >= H + 3)) continue;
             const int y = REFLECT ? reflect101(y0 + r, H) : min(max(y0 + r, 0), H - 1);
             const uint8_t* row = src + (size_t)y * spitch;
-            const int xa = x0 + c4;
             uint32_t v = 0;
             if (xa >= 0 && xa + 4 <= W) __builtin_memcpy(&v, row + xa, 4); // only the dwords that straddle the edge go byte by byte
             else {
@@ -122,6 +124,47 @@ __device__ inline void load_tile_u8(uint8_t* lds, int lds_pitch, const uint8_t* 
             }
             *reinterpret_cast<uint32_t*>(lds + r * lds_pitch + c4) = v;
         }
+    }
+}
+
+// Wide variant for tiles whose rows are CHUNKS x 16 bytes (lds_pitch = 16 * CHUNKS, 16-byte aligned): every thread first ISSUES
+// all of its 16-byte loads (a tile load is otherwise a chain of dependent round trips, one dword each), then stores them.
+// Chunks that straddle the image border are assembled byte by byte with reflect-101 (REFLECT) or clamped (!REFLECT) coordinates;
+// chunks nobody reads (more than 3 columns / rows beyond the image) are skipped.
+template <int NTHREADS, int CHUNKS, int ROWS, bool REFLECT>
+__device__ inline void load_tile_b128(uint8_t* lds, const uint8_t* __restrict__ src, int spitch, int W, int H, int x0, int y0) {
+    constexpr int kTotal = CHUNKS * ROWS, kIter = (kTotal + NTHREADS - 1) / NTHREADS;
+    uint4 v[kIter];
+    int state[kIter]; // 0: nothing to do, 1: loaded, 2: border chunk (byte path)
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int i = threadIdx.x + it * NTHREADS;
+        const int r = i / CHUNKS, c = i - r * CHUNKS, xa = x0 + 16 * c, ya = y0 + r;
+        state[it] = 0;
+        if (i < kTotal && xa < W + 4 && ya < H + 3) {
+            if (xa >= 0 && xa + 16 <= W) {
+                const int y = REFLECT ? reflect101(ya, H) : min(max(ya, 0), H - 1);
+                __builtin_memcpy(&v[it], src + (size_t)y * spitch + xa, 16);
+                state[it] = 1;
+            } else state[it] = 2;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int i = threadIdx.x + it * NTHREADS;
+        const int r = i / CHUNKS, c = i - r * CHUNKS, xa = x0 + 16 * c;
+        if (state[it] == 2) {
+            const uint8_t* row = src + (size_t)(REFLECT ? reflect101(y0 + r, H) : min(max(y0 + r, 0), H - 1)) * spitch;
+            uint32_t w[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                w[d] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[d] |= (uint32_t)row[REFLECT ? reflect101(xa + 4 * d + k, W) : min(max(xa + 4 * d + k, 0), W - 1)] << (8 * k);
+            }
+            v[it] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        if (state[it] != 0) *reinterpret_cast<uint4*>(lds + (r * CHUNKS + c) * 16) = v[it];
     }
 }
 
@@ -319,7 +362,7 @@ int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t*
 // (kTileW, kTileH are defined next to the host plan, which counts the tiles)
 constexpr int kPixW = kTileW + 8, kPixH = kTileH + 8;  // 72 x 24 pixel tile (halo 4)
 constexpr int kScW = kTileW + 2, kScH = kTileH + 2;    // 66 x 18 score tile (halo 1)
-constexpr int kPixPitch = kPixW + 4;                    // LDS row pitch (bytes)
+constexpr int kPixChunks = (kPixW + 15) / 16, kPixPitch = 16 * kPixChunks; // LDS rows of 5 x 16 bytes
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ inline s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
@@ -385,7 +428,7 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
 
     OPH_INIT();
     if (threadIdx.x == 0) { qcount = 0; ccount = 0; ocount = 0; }
-    load_tile_u8<false, 256>(pix, kPixPitch, V.ptr, V.pitch, V.w, V.h, ox - 4, oy - 4, kPixW, kPixH);
+    load_tile_b128<256, kPixChunks, kPixH, false>(pix, V.ptr, V.pitch, V.w, V.h, ox - 4, oy - 4);
     for (int i = threadIdx.x; i < (kScH * kScW + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
     __syncthreads();
     OPH(16);
@@ -1186,15 +1229,10 @@ int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, in
 
 // ------------------------------------------------------------------------------------------- K6 blur + rBRIEF
 // K6a orb_blur_kernel: GaussianBlur 7x7 sigma 2 (8-bit fixed point, BORDER_REFLECT_101) of every pyramid level into a
-// second pyramid, one launch for all levels.  64x16 output tiles: (70 x 22) raw pixels staged in LDS, separable
-// passes through an int32 LDS tile -- the arithmetic of cv::GaussianBlur's 8U path: taps cvRound(k*256) =
-// {18,34,49,55,49,34,18} per pass, (sum + 2^15) >> 16 after the column pass.
-#ifndef VSLAM_BLUR_TILE_H
-#define VSLAM_BLUR_TILE_H 32
-#endif
-constexpr int kBlurTileW = 64, kBlurTileH = VSLAM_BLUR_TILE_H;
-constexpr int kBlurRawW = kBlurTileW + 8, kBlurRawH = kBlurTileH + 6, kBlurRawPitch = 76; // raw tile starts at x0 - 4 (dword loads)
-constexpr int kBlurTmpPitch = kBlurRawH + 4; // u16 per column of the transposed row-pass tile (even: dword-aligned pairs; +4: bank spread)
+// second pyramid, one launch for all levels.  256 x 64 output tiles: (264 x 70) raw pixels staged in LDS -- the arithmetic of
+// cv::GaussianBlur's 8U path: taps cvRound(k*256) = {18,34,49,55,49,34,18} per pass, (sum + 2^15) >> 16 after the column pass.
+constexpr int kBlurTileW = 256, kBlurTileH = 64, kBlurWaveRows = 16; // workgroup tile; a wave owns 16 output rows of all 256 columns
+constexpr int kBlurRawH = kBlurTileH + 6, kBlurRawChunks = (kBlurTileW + 8 + 15) / 16, kBlurRawPitch = 16 * kBlurRawChunks; // raw tile starts at (x0 - 4, y0 - 3); rows of 17 x 16 B
 
 struct BlurTable {
     int w[kNLevels], h[kNLevels], pitch[kNLevels], pyr_off[kNLevels], blur_off[kNLevels];
@@ -1218,14 +1256,19 @@ __device__ inline uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) { // v_dot2
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
 }
 
+// The raw tile (reflect-101 at the image border) is staged in LDS once; after that everything stays in registers.  A wave streams
+// down its 16 + 6 raw rows; a lane owns four consecutive columns: the row pass is two v_dot4_u32_u8 per output on the three aligned
+// dwords of the lane's 12-byte window, its u16 results are paired with the previous row's (one v_lshl_or per column), and the
+// column pass of output row t - 6 is four v_dot2_u32_u16 on the pairs (t-6,t-5), (t-4,t-3), (t-2,t-1), (t-1,t) -- the last with
+// weights (0, 18) -- seeded with the rounding constant; the high halves of two sums are paired (v_perm), saturated at 255
+// (v_pk_min_u16) and packed into the dword that is stored.  The loop over the 22 rows is unrolled: the six live row pairs rotate by name.
 __global__ __launch_bounds__(256) void orb_blur_kernel(BlurTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes, int pitch0,
                                                       const uint8_t* __restrict__ d_pyr, size_t pyr_bytes, uint8_t* __restrict__ d_blur,
                                                       size_t blur_bytes) {
     const int b = blockIdx.y;
-    // Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2: with the tile index as the fast
-    // grid index, the two tiles that share a 128-B line (and the four that share a halo) always sat on different L2s and each
-    // fetched the line from memory.  The grid is padded to a multiple of 8 and XCD x walks the contiguous tile range
-    // [x * chunk, (x + 1) * chunk) of every image, so neighbours meet in one L2 a few workgroups apart.
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2: the grid is padded to a multiple
+    // of 8 and XCD x walks the contiguous tile range [x * chunk, (x + 1) * chunk) of every image, so tiles that share halo lines
+    // meet in one L2 a few workgroups apart.
     const int chunk = gridDim.x >> 3;
     int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3), l = 0;
     if (tile >= T.tile_off[kNLevels]) return;
@@ -1240,44 +1283,41 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(BlurTable T, const uint8_
     const int ox = (tile % T.tiles_x[l]) * kBlurTileW, oy = (tile / T.tiles_x[l]) * kBlurTileH;
 
     __shared__ __attribute__((aligned(16))) uint8_t raw[kBlurRawH * kBlurRawPitch];
-    // row-pass output, u16 (<= 257 * 255), stored COLUMN-major so that the column pass reads vertical neighbours as packed pairs
-    __shared__ __attribute__((aligned(16))) uint16_t tmpT[kBlurTileW * kBlurTmpPitch];
-    load_tile_u8<true, 256>(raw, kBlurRawPitch, src, spitch, W, H, ox - 4, oy - 3, kBlurRawW, kBlurRawH);
+    load_tile_b128<256, kBlurRawChunks, kBlurRawH, true>(raw, src, spitch, W, H, ox - 4, oy - 3);
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = wave * kBlurWaveRows;                // first output row of this wave inside the tile
+    const int nrows = min(kBlurWaveRows, H - (oy + row0)); // wave-uniform
+    const int x = ox + 4 * lane;
+    if (nrows <= 0) return;
     // taps cvRound(k * 256) = {18, 34, 49, 55, 49, 34, 18}, packed for v_dot4_u32_u8 / v_dot2_u32_u16
     constexpr uint32_t W0 = 18u | 34u << 8 | 49u << 16 | 55u << 24, W1 = 49u | 34u << 8 | 18u << 16;
-    // row pass: one lane = 4 consecutive outputs of one row from three aligned dwords (output column c reads raw columns c+1 .. c+7)
-    for (int i = threadIdx.x; i < kBlurRawH * (kBlurTileW / 4); i += 256) {
-        const int c = (i / kBlurRawH) * 4, r = i - (i / kBlurRawH) * kBlurRawH; // rows fastest: conflict-free raw reads (19-dword pitch) and tmpT writes
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(&raw[r * kBlurRawPitch + c]);
-        const uint32_t A = p[0], B = p[1], C = p[2];
-        uint32_t s[4];
+    constexpr uint32_t V0 = 18u | 34u << 16, V1 = 49u | 55u << 16, V2 = 49u | 34u << 16, V3 = 18u << 16;
+    const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + row0 * kBlurRawPitch) + lane; // window dwords A, B, C of raw row row0 + t
+    uint8_t* out = dst + (size_t)(oy + row0) * dpitch + x;
+    uint32_t P[kBlurWaveRows + 6][4], hprev[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+    for (int t = 0; t < kBlurWaveRows + 6; ++t) {
+        if (t - 6 >= nrows) break; // uniform
+        const uint32_t A = rp[t * (kBlurRawPitch / 4)], B = rp[t * (kBlurRawPitch / 4) + 1], C = rp[t * (kBlurRawPitch / 4) + 2];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { // output column x + o reads window bytes o + 1 .. o + 7
             const uint32_t lo = o == 3 ? B : __builtin_amdgcn_alignbyte(B, A, o + 1), hi = o == 3 ? C : __builtin_amdgcn_alignbyte(C, B, o + 1);
-            s[o] = __builtin_amdgcn_udot4(hi, W1, __builtin_amdgcn_udot4(lo, W0, 0u, false), false);
+            const uint32_t h = __builtin_amdgcn_udot4(hi, W1, __builtin_amdgcn_udot4(lo, W0, 0u, false), false); // <= 255 * 257
+            P[t][o] = hprev[o] | h << 16; // rows (t - 1, t)
+            hprev[o] = h;
         }
+        if (t >= 6) {
+            uint32_t sum[4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) tmpT[(c + o) * kBlurTmpPitch + r] = (uint16_t)s[o];
-    }
-    __syncthreads();
-    // column pass: one lane = 4 consecutive rows of one column; rows come as (even, odd) u16 pairs, odd outputs use shifted weights
-    constexpr uint32_t E0 = 18u | 34u << 16, E1 = 49u | 55u << 16, E2 = 49u | 34u << 16, E3 = 18u;          // taps start on the pair
-    constexpr uint32_t O0 = 18u << 16, O1 = 34u | 49u << 16, O2 = 55u | 49u << 16, O3 = 34u | 18u << 16;    // taps start on its high half
-    for (int i = threadIdx.x; i < (kBlurTileH / 4) * kBlurTileW; i += 256) {
-        const int c = i & (kBlurTileW - 1), r = (i / kBlurTileW) * 4;
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(&tmpT[c * kBlurTmpPitch + r]); // rows r .. r+9 as 5 pairs
-        const uint32_t p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4];
-        uint32_t s[4];
-        s[0] = udot2(p3, E3, udot2(p2, E2, udot2(p1, E1, udot2(p0, E0, 0u))));
-        s[1] = udot2(p3, O3, udot2(p2, O2, udot2(p1, O1, udot2(p0, O0, 0u))));
-        s[2] = udot2(p4, E3, udot2(p3, E2, udot2(p2, E1, udot2(p1, E0, 0u))));
-        s[3] = udot2(p4, O3, udot2(p3, O2, udot2(p2, O1, udot2(p1, O0, 0u))));
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int px = min((int)((s[o] + (1u << 15)) >> 16), 255);
-            const int x = ox + c, y = oy + r + o;
-            if (x < W && y < H) dst[(size_t)y * dpitch + x] = (uint8_t)px;
+            for (int o = 0; o < 4; ++o)
+                sum[o] = udot2(P[t][o], V3, udot2(P[t - 1][o], V2, udot2(P[t - 3][o], V1, udot2(P[t - 5][o], V0, 1u << 15))));
+            // sum >> 16 can reach 257 (the taps add up to 257 per pass): saturate as cv::saturate_cast<uchar> does
+            const us2_t lim = {255, 255};
+            const us2_t p01 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u)), lim);
+            const us2_t p23 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u)), lim);
+            const uint32_t px = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
+            if (x < W) *reinterpret_cast<uint32_t*>(out + (size_t)(t - 6) * dpitch) = px; // (columns past W land in the row's padding)
         }
     }
 }
