@@ -1339,6 +1339,15 @@ int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes
 constexpr int kDescWaves = 4;
 constexpr int kDescR = 19, kDescRows = 2 * kDescR + 1, kDescPitch = 40; // |pattern| <= 13 -> rotated radius <= 18.4; rows of 39 (+1) bytes
 
+// A wave walks keypoints j = wave id, wave id + #waves, ... of its image.  The chain "keypoint record -> 39 x 40 patch -> LDS ->
+// tests" is two memory round trips per keypoint, so it is software-pipelined: while the tests of keypoint j run out of LDS the patch
+// dwords of the next keypoint are already in flight to registers and the record of the one after that is being fetched; the
+// lane's four test pairs stay in registers for the whole walk.
+#ifndef VSLAM_DESC_BLOCKS
+#define VSLAM_DESC_BLOCKS 48
+#endif
+constexpr int kDescBlocksPerImage = VSLAM_DESC_BLOCKS; // x 4 waves = 192 waves per image: eight keypoints per wave at N = 1500 (32 / 48 / 64 / 96 / 144 blocks: 0.373 / 0.365 / 0.373 / 0.390 / 0.409 ms per 512 images)
+constexpr int kDescPatchIters = (kDescRows * (kDescPitch / 4) + 63) / 64;
 __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable T, LevelTable LT, const uint8_t* __restrict__ d_imgs,
                                                                       size_t img_bytes, int pitch0, const uint8_t* __restrict__ d_pyr,
                                                                       size_t pyr_bytes, const uint8_t* __restrict__ d_blur, size_t blur_bytes,
@@ -1346,74 +1355,110 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
                                                                       int kp_capacity, const int32_t* __restrict__ d_count,
                                                                       uint8_t* __restrict__ d_desc) {
     const int b = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * kDescWaves + wave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * kDescWaves;
     const int n = min(d_count[b], kp_capacity);
+    int j = blockIdx.x * kDescWaves + wave; // wave-uniform
     if (j >= n) return; // no block-level barrier below
-    const vslam_keypoint kp = d_kps[(size_t)b * kp_capacity + j];
-    const float2 cs = d_cs[(size_t)b * kp_capacity + j];
-    const int l = min(max(kp.octave, 0), kNLevels - 1);
-    const int W = T.w[l], H = T.h[l], bpitch = T.pitch[l];
-    const uint8_t* blur = d_blur + (size_t)b * blur_bytes + T.blur_off[l];
-    const uint8_t* rawp = l == 0 ? d_imgs + (size_t)b * img_bytes : d_pyr + (size_t)b * pyr_bytes + T.pyr_off[l];
-    const int rpitch = l == 0 ? pitch0 : T.pitch[l];
-    const float inv_scale = __fdiv_rn(1.f, LT.scale[l]);
-    const int cx = __float2int_rn(__fmul_rn(kp.x, inv_scale)), cy = __float2int_rn(__fmul_rn(kp.y, inv_scale));
-    const float ca = cs.x, sa = cs.y;
-    // Fast path (every keypoint the detector emits: edgeThreshold 31 > the rotated pattern radius 19): the wave stages the
-    // 39 x 40 byte neighbourhood of the blurred level in LDS with coalesced unaligned-dword row loads and gathers the 512
-    // samples from there -- scattered byte loads from global memory are bound by the texture-address line rate.
+    const vslam_keypoint* kps = d_kps + (size_t)b * kp_capacity;
+    const float2* css = d_cs + (size_t)b * kp_capacity;
     __shared__ __attribute__((aligned(16))) uint8_t patch[kDescWaves][kDescRows * kDescPitch];
-    const bool inside = cx - kDescR >= 0 && cx + kDescR + 1 < W && cy - kDescR >= 0 && cy + kDescR < H; // uniform per wave
-    if (inside) {
-        uint8_t* pl = patch[wave];
-        const uint8_t* org = blur + (size_t)(cy - kDescR) * bpitch + (cx - kDescR);
-#pragma unroll
-        for (int it = 0; it < (kDescRows * (kDescPitch / 4) + 63) / 64; ++it) {
-            const int i = lane + 64 * it, row = i / (kDescPitch / 4), col = i - row * (kDescPitch / 4);
-            if (row < kDescRows) {
-                uint32_t v;
-                __builtin_memcpy(&v, org + (size_t)row * bpitch + 4 * col, 4);
-                *reinterpret_cast<uint32_t*>(pl + row * kDescPitch + 4 * col) = v;
-            }
-        }
-        __builtin_amdgcn_wave_barrier(); // LDS traffic of one wave is ordered; this only pins the compiler
-        int nibf = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const signed char* q = &c_pattern[(4 * lane + k) * 4];
-            const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
-            const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
-            const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
-            const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
-            const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-            const int t0 = pl[(iy0 + kDescR) * kDescPitch + ix0 + kDescR], t1 = pl[(iy1 + kDescR) * kDescPitch + ix1 + kDescR];
-            nibf |= (t0 < t1) << k;
-        }
-        const int hif = __shfl_down(nibf, 1);
-        if ((lane & 1) == 0) d_desc[((size_t)b * kp_capacity + j) * 32 + (lane >> 1)] = (uint8_t)(nibf | (hif << 4));
-        return;
-    }
-    auto sample = [&](int ix, int iy) -> int {
-        const int x = cx + ix, y = cy + iy;
-        if (x >= 0 && x < W && y >= 0 && y < H) return blur[(size_t)y * bpitch + x];
-        // outside the level the reference reads the UNBLURRED reflect-101 border of its pyramid buffer
-        return rawp[(size_t)reflect101(y, H) * rpitch + reflect101(x, W)];
-    };
-    int nib = 0;
+    uint8_t* pl = patch[wave];
+    float px0[4], py0[4], px1[4], py1[4]; // this lane's four test pairs
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const signed char* q = &c_pattern[(4 * lane + k) * 4];
-        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
-        const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
-        const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
-        const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
-        const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-        const int t0 = sample(ix0, iy0), t1 = sample(ix1, iy1);
-        nib |= (t0 < t1) << k;
+        px0[k] = (float)q[0]; py0[k] = (float)q[1]; px1[k] = (float)q[2]; py1[k] = (float)q[3];
     }
-    const int hi = __shfl_down(nib, 1);
-    if ((lane & 1) == 0) d_desc[((size_t)b * kp_capacity + j) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    // position of this lane's patch dwords (same for every keypoint)
+    int prow[kDescPatchIters], pcol[kDescPatchIters];
+#pragma unroll
+    for (int it = 0; it < kDescPatchIters; ++it) {
+        const int i = lane + 64 * it;
+        prow[it] = i / (kDescPitch / 4); pcol[it] = 4 * (i - prow[it] * (kDescPitch / 4));
+    }
+    struct Geo { int cx, cy, l, W, H, bpitch; bool inside; const uint8_t* blur; };
+    auto geometry = [&](const vslam_keypoint& kp) -> Geo {
+        Geo g;
+        g.l = min(max(kp.octave, 0), kNLevels - 1);
+        g.W = T.w[g.l]; g.H = T.h[g.l]; g.bpitch = T.pitch[g.l];
+        g.blur = d_blur + (size_t)b * blur_bytes + T.blur_off[g.l];
+        const float inv_scale = __fdiv_rn(1.f, LT.scale[g.l]);
+        g.cx = __float2int_rn(__fmul_rn(kp.x, inv_scale)); g.cy = __float2int_rn(__fmul_rn(kp.y, inv_scale));
+        // Fast path (every keypoint the detector emits: edgeThreshold 31 > the rotated pattern radius 19): the wave stages the
+        // 39 x 40 byte neighbourhood of the blurred level in LDS with coalesced unaligned-dword row loads and gathers the 512
+        // samples from there -- scattered byte loads from global memory are bound by the texture-address line rate.
+        g.inside = g.cx - kDescR >= 0 && g.cx + kDescR + 1 < g.W && g.cy - kDescR >= 0 && g.cy + kDescR < g.H; // uniform per wave
+        return g;
+    };
+    auto patch_fetch = [&](const Geo& g, uint32_t (&pv)[kDescPatchIters]) {
+        if (!g.inside) return;
+        const uint8_t* org = g.blur + (size_t)(g.cy - kDescR) * g.bpitch + (g.cx - kDescR);
+#pragma unroll
+        for (int it = 0; it < kDescPatchIters; ++it)
+            if (prow[it] < kDescRows) __builtin_memcpy(&pv[it], org + (size_t)prow[it] * g.bpitch + pcol[it], 4);
+    };
+    vslam_keypoint kp = kps[j];
+    float2 cs = css[j];
+    Geo g = geometry(kp);
+    uint32_t pv[kDescPatchIters];
+    patch_fetch(g, pv);
+    int j1 = j + nwaves;                           // next keypoint: record in flight
+    vslam_keypoint kp1 = kps[min(j1, n - 1)];
+    float2 cs1 = css[min(j1, n - 1)];
+    for (;;) {
+        // patch of keypoint j: registers -> LDS
+        if (g.inside) {
+#pragma unroll
+            for (int it = 0; it < kDescPatchIters; ++it)
+                if (prow[it] < kDescRows) *reinterpret_cast<uint32_t*>(pl + prow[it] * kDescPitch + pcol[it]) = pv[it];
+        }
+        // keypoint j1: its patch goes in flight now; keypoint j2: its record
+        const Geo g1 = geometry(kp1);
+        uint32_t pv1[kDescPatchIters];
+        if (j1 < n) patch_fetch(g1, pv1);
+        const int j2 = j1 + nwaves;
+        const vslam_keypoint kp2 = kps[min(j2, n - 1)];
+        const float2 cs2 = css[min(j2, n - 1)];
+        __builtin_amdgcn_wave_barrier(); // LDS traffic of one wave is ordered; this only pins the compiler
+        const float ca = cs.x, sa = cs.y;
+        int nib = 0;
+        if (g.inside) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[k], ca), __fmul_rn(py0[k], sa)));
+                const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[k], sa), __fmul_rn(py0[k], ca)));
+                const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[k], ca), __fmul_rn(py1[k], sa)));
+                const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[k], sa), __fmul_rn(py1[k], ca)));
+                const int t0 = pl[(iy0 + kDescR) * kDescPitch + ix0 + kDescR], t1 = pl[(iy1 + kDescR) * kDescPitch + ix1 + kDescR];
+                nib |= (t0 < t1) << k;
+            }
+        } else {
+            const uint8_t* rawp = g.l == 0 ? d_imgs + (size_t)b * img_bytes : d_pyr + (size_t)b * pyr_bytes + T.pyr_off[g.l];
+            const int rpitch = g.l == 0 ? pitch0 : T.pitch[g.l];
+            auto sample = [&](int ix, int iy) -> int {
+                const int x = g.cx + ix, y = g.cy + iy;
+                if (x >= 0 && x < g.W && y >= 0 && y < g.H) return g.blur[(size_t)y * g.bpitch + x];
+                // outside the level the reference reads the UNBLURRED reflect-101 border of its pyramid buffer
+                return rawp[(size_t)reflect101(y, g.H) * rpitch + reflect101(x, g.W)];
+            };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[k], ca), __fmul_rn(py0[k], sa)));
+                const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[k], sa), __fmul_rn(py0[k], ca)));
+                const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[k], ca), __fmul_rn(py1[k], sa)));
+                const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[k], sa), __fmul_rn(py1[k], ca)));
+                nib |= (sample(ix0, iy0) < sample(ix1, iy1)) << k;
+            }
+        }
+        const int hi = __shfl_down(nib, 1);
+        if ((lane & 1) == 0) d_desc[((size_t)b * kp_capacity + j) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+        if (j1 >= n) break;
+        __builtin_amdgcn_wave_barrier(); // the tests above have read the patch before the next one overwrites it
+        j = j1; j1 = j2; g = g1; cs = cs1; kp1 = kp2; cs1 = cs2;
+#pragma unroll
+        for (int it = 0; it < kDescPatchIters; ++it) pv[it] = pv1[it];
+    }
 }
 
 int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
@@ -1423,10 +1468,11 @@ int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_b
     fill_blur_table(plan, &T);
     LevelTable LT;
     fill_level_table(plan, &LT);
-    // grid sized for the capacity; waves beyond d_count[b] exit immediately
+    // a fixed number of waves per image walks the keypoints (waves beyond d_count[b] exit immediately)
     const int max_kp = min(kp_capacity, kMaxRows);
+    const int blocks = min(kDescBlocksPerImage, (max_kp + kDescWaves - 1) / kDescWaves);
     ProfScope prof__(stream, "orb_describe_kernel");
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + kDescWaves - 1) / kDescWaves, B), dim3(kDescWaves * 64), 0, stream, T, LT, d_imgs,
+    hipLaunchKernelGGL(orb_describe_kernel, dim3(blocks, B), dim3(kDescWaves * 64), 0, stream, T, LT, d_imgs,
                        img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_blur, (size_t)plan.blur_bytes, d_kps, d_cs, kp_capacity, d_count, d_desc);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
