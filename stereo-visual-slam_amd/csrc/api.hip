@@ -120,8 +120,10 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
                               c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
     if ((rc = launch_orb_select(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel,
                                 c->orb.d_sel_cnt, c->orb.d_status, c->stream))) return rc;
-    if ((rc = launch_orb_anms(c->plan, B, c->orb.d_sel, c->orb.d_sel_cnt, c->plan.sel_cap, anms_num, regroup, d_kps, c->orb.d_cs, c->p.kp_capacity,
+    if ((rc = launch_orb_anms(c->plan, B, c->orb.d_sel, c->orb.d_sel_cnt, c->plan.sel_cap, anms_num, regroup, d_kps, nullptr, c->p.kp_capacity,
                               d_count, c->orb.d_status, c->orb.d_rad, c->stream))) return rc;
+    // orientation (and the rBRIEF rotation) only for the keypoints the ANMS kept
+    if ((rc = launch_orb_orient(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, d_kps, c->orb.d_cs, c->p.kp_capacity, d_count, c->stream))) return rc;
     if (describe) {
         if ((rc = launch_orb_blur(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
         if ((rc = launch_orb_describe(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, c->p.kp_capacity, d_count,

@@ -891,29 +891,23 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     int nout = nk;
     if (nout > sel_cap) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStSelOverflow); nout = sel_cap; }
     OPH(3);
-    // ---- orientation + output (wave per keypoint)
+    // ---- output.  The orientation is computed AFTER the ANMS (orb_orient_kernel): nothing between here and there reads it, and
+    // the ANMS discards half of these keypoints at N = 1500 (five sixths at the reference's 500).
     vslam_keypoint* out = d_sel + ((size_t)b * kNLevels + l) * sel_cap;
-    const int grp = threadIdx.x >> 4, ngrp = kSelBlock >> 4;
     const float scale = T.scale[l];
-    const IcRowWeights icw = ic_row_weights();
-    for (int i0 = 0; i0 < nout; i0 += ngrp) { // uniform trip count: the group shuffles need whole waves
-        const int i = i0 + grp;
-        const bool valid = i < nout;
-        const unsigned long long e = valid ? keep[i] : 0ull;
+    for (int i = threadIdx.x; i < nout; i += kSelBlock) {
+        const unsigned long long e = keep[i];
         const uint32_t raster = (uint32_t)(e >> 32);
         const int x = raster & 0xFFF, y = raster >> 12;
-        const float ang = ic_angle_group16(V, x, y, valid, icw);
-        if (valid && (threadIdx.x & 15) == 0) {
-            vslam_keypoint kp;
-            kp.x = __fmul_rn((float)x, scale);
-            kp.y = __fmul_rn((float)y, scale);
-            kp.size = __fmul_rn(31.f, scale);
-            kp.angle = ang;
-            kp.response = float_from_order_key((uint32_t)e);
-            kp.octave = l;
-            kp.class_id = -1;
-            out[i] = kp;
-        }
+        vslam_keypoint kp;
+        kp.x = __fmul_rn((float)x, scale);
+        kp.y = __fmul_rn((float)y, scale);
+        kp.size = __fmul_rn(31.f, scale);
+        kp.angle = 0.f;
+        kp.response = float_from_order_key((uint32_t)e);
+        kp.octave = l;
+        kp.class_id = -1;
+        out[i] = kp;
     }
     __syncthreads();
     OPH(4);
@@ -943,6 +937,72 @@ int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
 // ------------------------------------------------------------------------------------------- K5 ANMS
 constexpr int kAnmsBlock = 1024;
 constexpr int kAnmsBrute = 160; // at most this many stronger keypoints: scanning them beats walking the grid
+
+// K3b orb_orient_kernel: intensity-centroid orientation of the keypoints that survived the ANMS, and the (cos, sin) of the rBRIEF
+// rotation.  A 16-lane group per keypoint (four per wave); a fixed set of groups per image walks the list.  The level
+// coordinates are recovered as cvRound(pt / scale), the same identity the descriptor stage uses (orb.cpp computeDescriptors).
+#ifndef VSLAM_ORIENT_BLOCKS
+#define VSLAM_ORIENT_BLOCKS 48
+#endif
+constexpr int kOrientBlocks = VSLAM_ORIENT_BLOCKS, kOrientThreads = 256;
+__global__ __launch_bounds__(kOrientThreads) void orb_orient_kernel(LevelTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes, int pitch0,
+                                                                  const uint8_t* __restrict__ d_pyr, size_t pyr_bytes,
+                                                                  vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, int kp_capacity,
+                                                                  const int32_t* __restrict__ d_count) {
+    const int b = blockIdx.y;
+    const int n = min(d_count[b], kp_capacity);
+    const int ngrp = gridDim.x * (kOrientThreads >> 4);
+    const int grp = blockIdx.x * (kOrientThreads >> 4) + (threadIdx.x >> 4);
+    vslam_keypoint* kps = d_kps + (size_t)b * kp_capacity;
+    const IcRowWeights icw = ic_row_weights();
+    // the f64 cos / sin of the rotation is evaluated AFTER the walk, one lane per keypoint of this workgroup (inside the walk it would
+    // run on one lane in sixteen, four keypoints per wave pass)
+    constexpr int kSlots = 16 * (kOrientThreads >> 4); // up to 16 trips of the walk (kp_capacity <= 16 * groups per image, checked at launch)
+    __shared__ float s_ang[kSlots];
+    __shared__ int s_j[kSlots];
+    for (int t = threadIdx.x; t < kSlots; t += kOrientThreads) s_j[t] = -1;
+    __syncthreads();
+    const int wave_first = grp - ((threadIdx.x >> 4) & 3); // first group of this wave: the trip count must be uniform per wave (shuffles)
+    int trip = 0;
+    for (int j0 = wave_first; j0 < n; j0 += ngrp, ++trip) {
+        const int j = j0 + ((threadIdx.x >> 4) & 3);
+        const bool valid = j < n;
+        const vslam_keypoint kp = kps[valid ? j : 0];
+        const int l = min(max(kp.octave, 0), kNLevels - 1);
+        const LevelView V = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
+        const float inv_scale = __fdiv_rn(1.f, T.scale[l]);
+        const int x = __float2int_rn(__fmul_rn(kp.x, inv_scale)), y = __float2int_rn(__fmul_rn(kp.y, inv_scale));
+        // (keypoints come from the detector: >= 31 px from the level border, so the 31 x 31 patch is inside the level)
+        const bool ok = valid && x >= 15 && y >= 15 && x + 16 <= V.w && y + 15 < V.h;
+        const float ang = ic_angle_group16(V, x, y, ok, icw);
+        if (valid && (threadIdx.x & 15) == 0) {
+            kps[j].angle = ang;
+            const int slot = trip * (kOrientThreads >> 4) + (threadIdx.x >> 4);
+            s_ang[slot] = ang; s_j[slot] = j;
+        }
+    }
+    __syncthreads();
+    if (d_cs)
+        for (int t = threadIdx.x; t < kSlots; t += kOrientThreads) {
+            const int j = s_j[t];
+            if (j < 0) continue;
+            // rotation of the rBRIEF pattern: a = (float)cos(angle * pi/180), b = (float)sin(...), evaluated in f64 like the CPU side
+            const float rad = __fmul_rn(s_ang[t], (float)(3.1415926535897932384626433832795 / 180.f));
+            d_cs[(size_t)b * kp_capacity + j] = make_float2((float)cos((double)rad), (float)sin((double)rad));
+        }
+}
+
+int launch_orb_orient(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, vslam_keypoint* d_kps,
+                      float2* d_cs, int kp_capacity, const int32_t* d_count, hipStream_t stream) {
+    LevelTable T;
+    fill_level_table(plan, &T);
+    if (kp_capacity > 16 * kOrientBlocks * (kOrientThreads >> 4)) { set_error("kp_capacity %d exceeds the orientation walk (%d)", kp_capacity, 16 * kOrientBlocks * (kOrientThreads >> 4)); return VSLAM_ERR_ARG; }
+    ProfScope prof__(stream, "orb_orient_kernel");
+    hipLaunchKernelGGL(orb_orient_kernel, dim3(kOrientBlocks, B), dim3(kOrientThreads), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
+                       (size_t)plan.pyr_bytes, d_kps, d_cs, kp_capacity, d_count);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
 
 __device__ inline int block_rank_1024(bool flag, int* s_wave_tot, int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

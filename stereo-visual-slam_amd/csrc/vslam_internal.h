@@ -112,6 +112,8 @@ int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, in
                      double* d_rad, hipStream_t stream);
 int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, uint8_t* d_blur,
                     hipStream_t stream);
+int launch_orb_orient(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, vslam_keypoint* d_kps,
+                      float2* d_cs, int kp_capacity, const int32_t* d_count, hipStream_t stream);
 int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
                         const uint8_t* d_blur, const vslam_keypoint* d_kps, const float2* d_cs, int kp_capacity, const int32_t* d_count,
                         uint8_t* d_desc, hipStream_t stream);
