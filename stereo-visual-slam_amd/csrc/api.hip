@@ -120,13 +120,13 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
                               c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
     if ((rc = launch_orb_select(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel,
                                 c->orb.d_sel_cnt, c->orb.d_status, c->stream))) return rc;
-    if ((rc = launch_orb_anms(c->plan, B, c->orb.d_sel, c->orb.d_sel_cnt, c->plan.sel_cap, anms_num, regroup, d_kps, nullptr, c->p.kp_capacity,
+    if ((rc = launch_orb_anms(c->plan, B, c->orb.d_sel, c->orb.d_sel_cnt, c->plan.sel_cap, anms_num, regroup, d_kps, nullptr, c->orb.d_order, c->p.kp_capacity,
                               d_count, c->orb.d_status, c->orb.d_rad, c->stream))) return rc;
     // orientation (and the rBRIEF rotation) only for the keypoints the ANMS kept
-    if ((rc = launch_orb_orient(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, d_kps, c->orb.d_cs, c->p.kp_capacity, d_count, c->stream))) return rc;
+    if ((rc = launch_orb_orient(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, d_kps, c->orb.d_cs, c->orb.d_order, c->p.kp_capacity, d_count, c->stream))) return rc;
     if (describe) {
         if ((rc = launch_orb_blur(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
-        if ((rc = launch_orb_describe(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, c->p.kp_capacity, d_count,
+        if ((rc = launch_orb_describe(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, c->orb.d_order, c->p.kp_capacity, d_count,
                                       d_desc, c->stream))) return rc;
     }
     if (getenv("VSLAM_ORB_PROFILE")) orb_debug_dump(c->stream);
@@ -191,6 +191,7 @@ int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** ou
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_status, B);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_blur, B * c->plan.blur_bytes);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_cs, B * (size_t)p->kp_capacity);
+    if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_order, B * (size_t)p->kp_capacity);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->orb.d_rad, B * (size_t)kMaxRows);
     if (rc == VSLAM_OK) rc = dev_alloc(c, &c->match.d_train_best, B * kMaxRows);
     if (rc != VSLAM_OK) { vslam_destroy(reinterpret_cast<vslam_ctx*>(c)); return rc; }
@@ -207,7 +208,7 @@ void vslam_destroy(vslam_ctx* ctx) {
     if (c->d_sgbm) hipFree(c->d_sgbm);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->lm.buf) hipFree(c->lm.buf);
-    void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs, c->orb.d_rad,
+    void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs, c->orb.d_order, c->orb.d_rad,
                     c->match.d_train_best, c->d_stage};
     for (void* q : ptrs) if (q) hipFree(q);
     if (c->prof) {
@@ -311,7 +312,7 @@ int vslam_anms(vslam_ctx* ctx, vslam_keypoint* kps, int n, int num, int* n_out) 
     VS_HIP(hipMemcpyAsync(d_in, kps, sizeof(vslam_keypoint) * n, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
-    if ((rc = launch_anms_flat(1, d_in, d_n, kMaxRows, num, 0, c->p.img_w, c->p.img_h, d_out, nullptr, kMaxRows, d_cnt, c->orb.d_status, c->orb.d_rad, c->stream))) return rc;
+    if ((rc = launch_anms_flat(1, d_in, d_n, kMaxRows, num, 0, c->p.img_w, c->p.img_h, d_out, nullptr, nullptr, kMaxRows, d_cnt, c->orb.d_status, c->orb.d_rad, c->stream))) return rc;
     int32_t m = 0;
     VS_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(m), hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
@@ -346,9 +347,9 @@ int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stri
     VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
     if ((rc = launch_orb_pyramid(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->stream))) return rc;
-    if ((rc = launch_anms_flat(1, d_in, d_n, kc, 0, 1, w, h, d_kps, c->orb.d_cs, kc, d_cnt, c->orb.d_status, c->orb.d_rad, c->stream))) return rc;
+    if ((rc = launch_anms_flat(1, d_in, d_n, kc, 0, 1, w, h, d_kps, c->orb.d_cs, nullptr, kc, d_cnt, c->orb.d_status, c->orb.d_rad, c->stream))) return rc;
     if ((rc = launch_orb_blur(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
-    if ((rc = launch_orb_describe(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, kc, d_cnt, d_desc, c->stream))) return rc;
+    if ((rc = launch_orb_describe(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, nullptr, kc, d_cnt, d_desc, c->stream))) return rc;
     int32_t m = 0;
     VS_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(m), hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));

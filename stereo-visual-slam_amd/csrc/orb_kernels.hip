@@ -947,8 +947,8 @@ constexpr int kAnmsBrute = 160; // at most this many stronger keypoints: scannin
 constexpr int kOrientBlocks = VSLAM_ORIENT_BLOCKS, kOrientThreads = 256;
 __global__ __launch_bounds__(kOrientThreads) void orb_orient_kernel(LevelTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes, int pitch0,
                                                                   const uint8_t* __restrict__ d_pyr, size_t pyr_bytes,
-                                                                  vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, int kp_capacity,
-                                                                  const int32_t* __restrict__ d_count) {
+                                                                  vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, const int32_t* __restrict__ d_order,
+                                                                  int kp_capacity, const int32_t* __restrict__ d_count) {
     const int b = blockIdx.y;
     const int n = min(d_count[b], kp_capacity);
     const int ngrp = gridDim.x * (kOrientThreads >> 4);
@@ -963,11 +963,13 @@ __global__ __launch_bounds__(kOrientThreads) void orb_orient_kernel(LevelTable T
     for (int t = threadIdx.x; t < kSlots; t += kOrientThreads) s_j[t] = -1;
     __syncthreads();
     const int wave_first = grp - ((threadIdx.x >> 4) & 3); // first group of this wave: the trip count must be uniform per wave (shuffles)
+    const int32_t* order = d_order ? d_order + (size_t)b * kp_capacity : nullptr;
     int trip = 0;
     for (int j0 = wave_first; j0 < n; j0 += ngrp, ++trip) {
-        const int j = j0 + ((threadIdx.x >> 4) & 3);
-        const bool valid = j < n;
-        const vslam_keypoint kp = kps[valid ? j : 0];
+        const int i = j0 + ((threadIdx.x >> 4) & 3); // position in the walk; j: the output slot it refers to
+        const bool valid = i < n;
+        const int j = valid ? (order ? min(max(order[i], 0), n - 1) : i) : 0;
+        const vslam_keypoint kp = kps[j];
         const int l = min(max(kp.octave, 0), kNLevels - 1);
         const LevelView V = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
         const float inv_scale = __fdiv_rn(1.f, T.scale[l]);
@@ -993,13 +995,13 @@ __global__ __launch_bounds__(kOrientThreads) void orb_orient_kernel(LevelTable T
 }
 
 int launch_orb_orient(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, vslam_keypoint* d_kps,
-                      float2* d_cs, int kp_capacity, const int32_t* d_count, hipStream_t stream) {
+                      float2* d_cs, const int32_t* d_order, int kp_capacity, const int32_t* d_count, hipStream_t stream) {
     LevelTable T;
     fill_level_table(plan, &T);
     if (kp_capacity > 16 * kOrientBlocks * (kOrientThreads >> 4)) { set_error("kp_capacity %d exceeds the orientation walk (%d)", kp_capacity, 16 * kOrientBlocks * (kOrientThreads >> 4)); return VSLAM_ERR_ARG; }
     ProfScope prof__(stream, "orb_orient_kernel");
     hipLaunchKernelGGL(orb_orient_kernel, dim3(kOrientBlocks, B), dim3(kOrientThreads), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
-                       (size_t)plan.pyr_bytes, d_kps, d_cs, kp_capacity, d_count);
+                       (size_t)plan.pyr_bytes, d_kps, d_cs, d_order, kp_capacity, d_count);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
@@ -1034,7 +1036,7 @@ static_assert(2 * anms_lds_bytes(kAnmsCapPipe) <= 160 * 1024, "two ANMS workgrou
 template <int CAP>
 __global__ __launch_bounds__(kAnmsBlock, 8) void orb_anms_kernel(const vslam_keypoint* __restrict__ d_in, const int32_t* __restrict__ d_nin,
                                                              int nlists, int in_capacity, int anms_num, int regroup, int img_w,
-                                                             int img_h, vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, int kp_capacity,
+                                                             int img_h, vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, int32_t* __restrict__ d_order, int kp_capacity,
                                                              int32_t* __restrict__ d_count, int32_t* __restrict__ d_status, double* __restrict__ d_rad) {
     const int b = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1071,6 +1073,28 @@ __global__ __launch_bounds__(kAnmsBlock, 8) void orb_anms_kernel(const vslam_key
         if (d_cs) {
             const float ang = __fmul_rn(kp->angle, (float)(3.1415926535897932384626433832795 / 180.f));
             d_cs[(size_t)b * kp_capacity + r] = make_float2((float)cos((double)ang), (float)sin((double)ang));
+        }
+    };
+    // Walk order for the stages that follow (orientation, descriptors): the output slots sorted by their SOURCE index.  The source lists
+    // are raster-sorted per level, so consecutive entries are neighbours in the image and the patches the next kernels fetch share cache
+    // lines; in response order every 39 x 40 patch is ~5 KB of lines nobody else touches.  One mark per source index (the upper half of
+    // the sort buffer is free by now), then a ranked compaction over the source indices.
+    auto emit_order = [&](int cnt, auto src_of) {
+        if (!d_order) return;
+        uint16_t* mark = reinterpret_cast<uint16_t*>(smem + (size_t)kMaxRows * 4);
+        __syncthreads();
+        for (int g = threadIdx.x; g < N; g += kAnmsBlock) mark[g] = 0xFFFFu;
+        __syncthreads();
+        for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) mark[src_of(r)] = (uint16_t)r;
+        __syncthreads();
+        int written = 0;
+        for (int base = 0; base < N; base += kAnmsBlock) {
+            const int g = base + threadIdx.x;
+            const uint32_t m = g < N ? mark[g] : 0xFFFFu;
+            int total;
+            const int rk = block_rank_1024(m != 0xFFFFu, s_wave_tot, total);
+            if (m != 0xFFFFu) d_order[(size_t)b * kp_capacity + written + rk] = (int32_t)m;
+            written += total;
         }
     };
     const bool do_anms = anms_num > 0 && N >= anms_num; // visual_odometry.cpp:100
@@ -1245,18 +1269,20 @@ __global__ __launch_bounds__(kAnmsBlock, 8) void orb_anms_kernel(const vslam_key
         if (cnt > kp_capacity) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStOutOverflow); cnt = kp_capacity; }
         for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) emit(r, src_ptr(sord[k32[r] & 0xFFFFu]));
         if (threadIdx.x == 0) d_count[b] = cnt;
+        emit_order(cnt, [&](int r) -> int { return sord[k32[r] & 0xFFFFu]; });
         OPH(27);
     } else {
         int cnt = M;
         if (cnt > kp_capacity) { if (threadIdx.x == 0) atomicOr(&d_status[b], kStOutOverflow); cnt = kp_capacity; }
         for (int r = threadIdx.x; r < cnt; r += kAnmsBlock) emit(r, src_ptr(sord[r]));
         if (threadIdx.x == 0) d_count[b] = cnt;
+        emit_order(cnt, [&](int r) -> int { return sord[r]; });
     }
 }
 
 template <int CAP>
 static int launch_anms_t(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int nlists, int in_capacity, int anms_num,
-                         int regroup, int img_w, int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count,
+                         int regroup, int img_w, int img_h, vslam_keypoint* d_kps, float2* d_cs, int32_t* d_order, int kp_capacity, int32_t* d_count,
                          int32_t* d_status, double* d_rad, hipStream_t stream) {
     constexpr size_t smem = anms_lds_bytes(CAP);
     static bool attr_set[16] = {false}; // per device: the > 64 KB dynamic-LDS opt-in is a per-device function attribute
@@ -1268,22 +1294,22 @@ static int launch_anms_t(int B, const vslam_keypoint* d_in, const int32_t* d_nin
     }
     ProfScope prof__(stream, "orb_anms_kernel");
     hipLaunchKernelGGL(orb_anms_kernel<CAP>, dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
-                       img_w, img_h, d_kps, d_cs, kp_capacity, d_count, d_status, d_rad);
+                       img_w, img_h, d_kps, d_cs, d_order, kp_capacity, d_count, d_status, d_rad);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
 
 int launch_orb_anms(const OrbPlan& plan, int B, const vslam_keypoint* d_sel, const int32_t* d_sel_cnt, int sel_cap, int anms_num,
-                    int regroup, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status, double* d_rad,
+                    int regroup, vslam_keypoint* d_kps, float2* d_cs, int32_t* d_order, int kp_capacity, int32_t* d_count, int32_t* d_status, double* d_rad,
                     hipStream_t stream) {
-    return launch_anms_t<kAnmsCapPipe>(B, d_sel, d_sel_cnt, kNLevels, sel_cap, anms_num, regroup, plan.w, plan.h, d_kps, d_cs, kp_capacity, d_count,
+    return launch_anms_t<kAnmsCapPipe>(B, d_sel, d_sel_cnt, kNLevels, sel_cap, anms_num, regroup, plan.w, plan.h, d_kps, d_cs, d_order, kp_capacity, d_count,
                                        d_status, d_rad, stream);
 }
 
 int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int in_capacity, int anms_num, int regroup, int img_w,
-                     int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status, double* d_rad,
+                     int img_h, vslam_keypoint* d_kps, float2* d_cs, int32_t* d_order, int kp_capacity, int32_t* d_count, int32_t* d_status, double* d_rad,
                      hipStream_t stream) {
-    return launch_anms_t<kMaxRows>(B, d_in, d_nin, 1, in_capacity, anms_num, regroup, img_w, img_h, d_kps, d_cs, kp_capacity, d_count, d_status, d_rad,
+    return launch_anms_t<kMaxRows>(B, d_in, d_nin, 1, in_capacity, anms_num, regroup, img_w, img_h, d_kps, d_cs, d_order, kp_capacity, d_count, d_status, d_rad,
                                    stream);
 }
 
@@ -1412,14 +1438,24 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
                                                                       size_t img_bytes, int pitch0, const uint8_t* __restrict__ d_pyr,
                                                                       size_t pyr_bytes, const uint8_t* __restrict__ d_blur, size_t blur_bytes,
                                                                       const vslam_keypoint* __restrict__ d_kps, const float2* __restrict__ d_cs,
-                                                                      int kp_capacity, const int32_t* __restrict__ d_count,
-                                                                      uint8_t* __restrict__ d_desc) {
+                                                                      const int32_t* __restrict__ d_order, int kp_capacity,
+                                                                      const int32_t* __restrict__ d_count, uint8_t* __restrict__ d_desc) {
     const int b = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nwaves = gridDim.x * kDescWaves;
     const int n = min(d_count[b], kp_capacity);
-    int j = blockIdx.x * kDescWaves + wave; // wave-uniform
-    if (j >= n) return; // no block-level barrier below
+    // the wave visits walk positions i = wave id + k * #waves; lane k preloads the output slot of the k-th visit (d_order: the slots in
+    // (octave, raster) order, so that waves running side by side fetch neighbouring patches)
+    const int i0 = blockIdx.x * kDescWaves + wave; // wave-uniform
+    if (i0 >= n) return; // no block-level barrier below
+    int slots;
+    {
+        const int i = i0 + lane * nwaves;
+        slots = i < n ? (d_order ? min(max(d_order[(size_t)b * kp_capacity + i], 0), n - 1) : i) : -1;
+    }
+    const int nvisit = min((n - i0 + nwaves - 1) / nwaves, 64);
+    int visit = 0;
+    int j = __builtin_amdgcn_readlane(slots, 0);
     const vslam_keypoint* kps = d_kps + (size_t)b * kp_capacity;
     const float2* css = d_cs + (size_t)b * kp_capacity;
     __shared__ __attribute__((aligned(16))) uint8_t patch[kDescWaves][kDescRows * kDescPitch];
@@ -1463,9 +1499,10 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
     Geo g = geometry(kp);
     uint32_t pv[kDescPatchIters];
     patch_fetch(g, pv);
-    int j1 = j + nwaves;                           // next keypoint: record in flight
-    vslam_keypoint kp1 = kps[min(j1, n - 1)];
-    float2 cs1 = css[min(j1, n - 1)];
+    auto slot_of = [&](int v) -> int { return v < nvisit ? __builtin_amdgcn_readlane(slots, v) : -1; }; // v is wave-uniform
+    int j1 = slot_of(1);                           // next keypoint: record in flight
+    vslam_keypoint kp1 = kps[max(j1, 0)];
+    float2 cs1 = css[max(j1, 0)];
     for (;;) {
         // patch of keypoint j: registers -> LDS
         if (g.inside) {
@@ -1476,10 +1513,10 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
         // keypoint j1: its patch goes in flight now; keypoint j2: its record
         const Geo g1 = geometry(kp1);
         uint32_t pv1[kDescPatchIters];
-        if (j1 < n) patch_fetch(g1, pv1);
-        const int j2 = j1 + nwaves;
-        const vslam_keypoint kp2 = kps[min(j2, n - 1)];
-        const float2 cs2 = css[min(j2, n - 1)];
+        if (j1 >= 0) patch_fetch(g1, pv1);
+        const int j2 = slot_of(visit + 2);
+        const vslam_keypoint kp2 = kps[max(j2, 0)];
+        const float2 cs2 = css[max(j2, 0)];
         __builtin_amdgcn_wave_barrier(); // LDS traffic of one wave is ordered; this only pins the compiler
         const float ca = cs.x, sa = cs.y;
         int nib = 0;
@@ -1513,8 +1550,9 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
         }
         const int hi = __shfl_down(nib, 1);
         if ((lane & 1) == 0) d_desc[((size_t)b * kp_capacity + j) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
-        if (j1 >= n) break;
+        if (j1 < 0) break;
         __builtin_amdgcn_wave_barrier(); // the tests above have read the patch before the next one overwrites it
+        ++visit;
         j = j1; j1 = j2; g = g1; cs = cs1; kp1 = kp2; cs1 = cs2;
 #pragma unroll
         for (int it = 0; it < kDescPatchIters; ++it) pv[it] = pv1[it];
@@ -1522,7 +1560,7 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
 }
 
 int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
-                        const uint8_t* d_blur, const vslam_keypoint* d_kps, const float2* d_cs, int kp_capacity, const int32_t* d_count,
+                        const uint8_t* d_blur, const vslam_keypoint* d_kps, const float2* d_cs, const int32_t* d_order, int kp_capacity, const int32_t* d_count,
                         uint8_t* d_desc, hipStream_t stream) {
     BlurTable T;
     fill_blur_table(plan, &T);
@@ -1533,7 +1571,7 @@ int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_b
     const int blocks = min(kDescBlocksPerImage, (max_kp + kDescWaves - 1) / kDescWaves);
     ProfScope prof__(stream, "orb_describe_kernel");
     hipLaunchKernelGGL(orb_describe_kernel, dim3(blocks, B), dim3(kDescWaves * 64), 0, stream, T, LT, d_imgs,
-                       img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_blur, (size_t)plan.blur_bytes, d_kps, d_cs, kp_capacity, d_count, d_desc);
+                       img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_blur, (size_t)plan.blur_bytes, d_kps, d_cs, d_order, kp_capacity, d_count, d_desc);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }

@@ -90,6 +90,7 @@ struct OrbBuffers {
     vslam_keypoint* d_det; // B x kp_capacity: detect output (level asc, raster) when ANMS is run as a separate call
     uint8_t* d_blur;       // B x blur_bytes: Gaussian-blurred pyramid (rBRIEF samples these)
     float2* d_cs;          // B x kp_capacity: per-keypoint (cos, sin) of the rBRIEF rotation
+    int32_t* d_order;      // B x kp_capacity: the output slots in (octave, raster) order -- the walk order of orient / describe
     double* d_rad;         // B x kMaxRows: ANMS suppression radii (f64)
 };
 
@@ -104,18 +105,18 @@ int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
 // gather per-level lists (level asc) -> ANMS(num) -> regroup by octave -> d_kps (B x kp_capacity), d_count
 // anms_num <= 0: no ANMS (detect order).  regroup: apply cv::ORB::compute's border cull + octave regrouping.
 int launch_orb_anms(const OrbPlan& plan, int B, const vslam_keypoint* d_sel, const int32_t* d_sel_cnt, int sel_cap,
-                    int anms_num, int regroup, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status,
+                    int anms_num, int regroup, vslam_keypoint* d_kps, float2* d_cs, int32_t* d_order, int kp_capacity, int32_t* d_count, int32_t* d_status,
                     double* d_rad, hipStream_t stream);
 // same ANMS kernel on a flat list per image (d_in: B x in_capacity, d_nin[b]) for the stand-alone vslam_anms call
 int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, int in_capacity, int anms_num, int regroup,
-                     int img_w, int img_h, vslam_keypoint* d_kps, float2* d_cs, int kp_capacity, int32_t* d_count, int32_t* d_status,
+                     int img_w, int img_h, vslam_keypoint* d_kps, float2* d_cs, int32_t* d_order, int kp_capacity, int32_t* d_count, int32_t* d_status,
                      double* d_rad, hipStream_t stream);
 int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, uint8_t* d_blur,
                     hipStream_t stream);
 int launch_orb_orient(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr, vslam_keypoint* d_kps,
-                      float2* d_cs, int kp_capacity, const int32_t* d_count, hipStream_t stream);
+                      float2* d_cs, const int32_t* d_order, int kp_capacity, const int32_t* d_count, hipStream_t stream);
 int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
-                        const uint8_t* d_blur, const vslam_keypoint* d_kps, const float2* d_cs, int kp_capacity, const int32_t* d_count,
+                        const uint8_t* d_blur, const vslam_keypoint* d_kps, const float2* d_cs, const int32_t* d_order, int kp_capacity, const int32_t* d_count,
                         uint8_t* d_desc, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- matcher
