@@ -436,8 +436,8 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
     // (a) compass pre-test on the score region (tile + halo 1): a 9-arc always contains two ADJACENT compass pixels (ring
     // positions 0, 4, 8, 12), so a corner needs two adjacent compass pixels all brighter or all darker.  Cheap, and it
     // thins the candidates before the full 16-pixel test runs with all lanes busy.  One lane tests the four pixels of an aligned
-    // dword of the pixel tile: five dword LDS reads, the bytes widened to packed i16 pairs (v_perm), "brighter" / "darker" as
-    // signed differences (c - (v + t) > 0, (v - t) - c > 0), AND = packed min, OR = packed max.
+    // dword of the pixel tile: five dword LDS reads, the bytes widened to packed i16 pairs (v_perm), AND = packed min, OR = packed max,
+    // the verdict the sign of a packed difference.
     {
         constexpr int kGroups = (kScW + 3 + 3) / 4; // pixel-tile columns 3 .. kScW + 2 in dwords of four
         const s16x2 vthr = {(short)thr, (short)thr};
@@ -457,11 +457,11 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
                 const s16x2 c8 = as_s16x2(__builtin_amdgcn_perm(0u, U, h ? 0x0c030c02u : 0x0c010c00u));
                 const s16x2 c4 = as_s16x2(h ? __builtin_amdgcn_perm(0u, D2, 0x0c020c01u) : __builtin_amdgcn_perm(D2, D1, 0x0c040c03u));   // x + 3
                 const s16x2 c12 = as_s16x2(h ? __builtin_amdgcn_perm(D1, D0, 0x0c040c03u) : __builtin_amdgcn_perm(0u, D0, 0x0c020c01u)); // x - 3
-                const s16x2 hi = v + vthr, lo = v - vthr;
-                const s16x2 b0 = c0 - hi, b4 = c4 - hi, b8 = c8 - hi, b12 = c12 - hi;
-                const s16x2 d0 = lo - c0, d4 = lo - c4, d8 = lo - c8, d12 = lo - c12;
-                s16x2 m = pk_max(pk_max(pk_min(b0, b4), pk_min(b4, b8)), pk_max(pk_min(b8, b12), pk_min(b12, b0)));
-                m = pk_max(m, pk_max(pk_max(pk_min(d0, d4), pk_min(d4, d8)), pk_max(pk_min(d8, d12), pk_min(d12, d0))));
+                // "two adjacent compass pixels both brighter than v + t": the largest of the four pairwise minima exceeds v + t;
+                // "both darker than v - t": the smallest of the four pairwise maxima is below v - t
+                const s16x2 brightest_pair = pk_max(pk_max(pk_min(c0, c4), pk_min(c4, c8)), pk_max(pk_min(c8, c12), pk_min(c12, c0)));
+                const s16x2 darkest_pair = pk_min(pk_min(pk_max(c0, c4), pk_max(c4, c8)), pk_min(pk_max(c8, c12), pk_max(c12, c0)));
+                const s16x2 m = pk_max(brightest_pair - (v + vthr), (v - vthr) - darkest_pair);
                 mask |= (uint32_t)(m.x > 0) << (2 * h) | (uint32_t)(m.y > 0) << (2 * h + 1);
             }
             // valid score columns: sx = 4 g - 3 + k in [0, kScW), image column x = ox - 1 + sx < V.w - 3
