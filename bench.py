@@ -57,7 +57,7 @@ def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
     # kernel's own time, and over the family's time
     orb_alg, _ = algorithmic_bytes("orb_", pipe, args.anms)
     orb_total_ms = 0.0
-    for name in ("orb_resize_kernel", "orb_pyramid_kernel", "orb_fast_kernel", "orb_select_kernel", "orb_anms_kernel", "orb_blur_kernel", "orb_describe_kernel"):
+    for name in ("orb_resize_kernel", "orb_pyramid_kernel", "orb_fast_kernel", "orb_select_kernel", "orb_anms_kernel", "orb_orient_kernel", "orb_blur_kernel", "orb_describe_kernel"):
         k = prof.get(name)
         if not k or k[0] <= 0:
             continue
@@ -94,7 +94,7 @@ def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
         used = wi * pipe.B
         out.append({"kernel": "lm_window_kernel", "bound": "valu-issue", "achieved": round(used / t / 1e12, 3), "peak": round(256 * 4 * 2.4e9 / 4.0 / 1e12, 3),
                     "unit": "T wave-instructions/s", "frac": round(used / slots, 4),
-                    "note": "SQ_INSTS_VALU of the BA schedule (profiles/r01c_ba_sq_issue_stall_summary.txt) over the live kernel time; two waves per SIMD (256 VGPRs)"})
+                    "note": "SQ_INSTS_VALU of the BA schedule (profiles/r02_ba_sq_issue_stall_summary.txt) over the live kernel time; two waves per SIMD (256 VGPRs)"})
     return out
 
 
