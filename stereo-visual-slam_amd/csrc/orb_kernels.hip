@@ -369,14 +369,6 @@ __device__ inline s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, 
 __device__ inline s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ inline s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
-__device__ inline bool ring9(uint32_t m) {
-    const uint32_t x = m | (m << 16);
-    const uint32_t a = x & (x >> 1);
-    const uint32_t b = a & (a >> 2);
-    const uint32_t c = b & (b >> 4);
-    return ((c & (x >> 8)) & 0xFFFFu) != 0;
-}
-
 // ring offsets in the order of cv::FAST (pattern 16): (dx, dy)
 #define RING_LOAD(P, pitch)                                                                                   \
     {(P)[0 + 3 * (pitch)],  (P)[1 + 3 * (pitch)],  (P)[2 + 2 * (pitch)],  (P)[3 + 1 * (pitch)],             \
@@ -476,29 +468,18 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
         }
     }
     __syncthreads();
-    // (b) full FAST-9/16 test on the survivors
+    // (b) the survivors' corner score (largest threshold for which the pixel is still a FAST-9/16 corner).  A pixel is a corner at
+    // `thr` exactly when that score is >= thr, so the score doubles as the full 16-pixel test: no separate ring-mask pass.
     const int nq = qcount;
     for (int q = threadIdx.x; q < nq; q += 256) {
         const int i = queue[q];
         const int sy = i / kScW, sx = i - sy * kScW;
-        const uint8_t* p = &pix[(sy + 3) * kPixPitch + sx + 3];
-        const int v = p[0], hi = v + thr, lo = v - thr;
-        const int r[16] = RING_LOAD(p, kPixPitch);
-        uint32_t bright = 0, dark = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { bright |= (uint32_t)(r[k] > hi) << k; dark |= (uint32_t)(r[k] < lo) << k; }
-        if (ring9(bright) || ring9(dark)) cqueue[atomicAdd(&ccount, 1)] = (uint16_t)i;
+        const int score = fast_score(&pix[(sy + 3) * kPixPitch + sx + 3], thr);
+        if (score >= thr) { sc[i] = (uint8_t)score; cqueue[atomicAdd(&ccount, 1)] = (uint16_t)i; }
     }
     __syncthreads();
     OPH(17);
-    // (c) corner scores
     const int nc = ccount;
-    for (int q = threadIdx.x; q < nc; q += 256) {
-        const int i = cqueue[q];
-        const int sy = i / kScW, sx = i - sy * kScW;
-        sc[i] = (uint8_t)fast_score(&pix[(sy + 3) * kPixPitch + sx + 3], thr);
-    }
-    __syncthreads();
     OPH(18);
     // (d) 3x3 non-max suppression + border cull (edgeThreshold 31): survivors collected in LDS, ONE global atomic per block
     for (int q = threadIdx.x; q < nc; q += 256) {
