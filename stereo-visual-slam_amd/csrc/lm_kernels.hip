@@ -412,6 +412,15 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         if (l < ncache) { double2* q = reinterpret_cast<double2*>(sDinv + 6 * l); q[0] = make_double2(Di[0], Di[1]); q[1] = make_double2(Di[2], Di[3]); q[2] = make_double2(Di[4], Di[5]); }
         else { double2* q = reinterpret_cast<double2*>(Dinv + 6 * (size_t)l); q[0] = make_double2(Di[0], Di[1]); q[1] = make_double2(Di[2], Di[3]); q[2] = make_double2(Di[4], Di[5]); }
     };
+    // Prefetching form for the Schur loops: rows whose lanes are ALL cached (landmark ids ascend along a list, so that is every row but
+    // one per list) read LDS on a wave-uniform path of their own.  On the mixed path the LDS reads and the global loads share their
+    // destination registers and the compiler orders them with an `s_waitcnt vmcnt(0)` in front of the LDS reads -- right after the
+    // row's prefetch loads were issued, i.e. one full memory round trip per row (650 of the 2500 cycles of a hit row).
+    auto loadD_row = [&](int l, double2& Da, double2& Db, double2& Dc) {
+        if (__ballot(l >= ncache) == 0ull) { const double2* q = reinterpret_cast<const double2*>(sDinv + 6 * l); Da = q[0]; Db = q[1]; Dc = q[2]; }
+        else if (l < ncache) { const double2* q = reinterpret_cast<const double2*>(sDinv + 6 * l); Da = q[0]; Db = q[1]; Dc = q[2]; }
+        else { const double2* q = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)l); Da = q[0]; Db = q[1]; Dc = q[2]; }
+    };
     auto loadD = [&](int l, double2& Da, double2& Db, double2& Dc) {
         if (l < ncache) { const double2* q = reinterpret_cast<const double2*>(sDinv + 6 * l); Da = q[0]; Db = q[1]; Dc = q[2]; }
         else { const double2* q = reinterpret_cast<const double2*>(Dinv + 6 * (size_t)l); Da = q[0]; Db = q[1]; Dc = q[2]; }
@@ -1002,11 +1011,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         loadD(ln, Da, Db, Dc);
                         double g0 = PC(bl, 0, ln), g1 = PC(bl, 1, ln), g2 = PC(bl, 2, ln);
                         for (; j < jend; j += 64) {
+                            double2 Dan, Dbn, Dcn;
+                            loadD_row(lnn, Dan, Dbn, Dcn); // (first: see loadD_row -- nothing of THIS row's prefetch is in flight yet)
                             const int lnnn = kf_lm[min(j + 128, jend - 1)];
                             const double wan = recW[min(j + 64, jend - 1)];
                             const double paxn = PC(P, 0, lnn), payn = PC(P, 1, lnn), pazn = PC(P, 2, lnn);
-                            double2 Dan, Dbn, Dcn;
-                            loadD(lnn, Dan, Dbn, Dcn);
                             const double g0n = PC(bl, 0, lnn), g1n = PC(bl, 1, lnn), g2n = PC(bl, 2, lnn);
                             double A1[12], B1[6];
                             double4 ra; // the linearisation record {x, y, 1/Z, w}: camera-frame part recomputed from the landmark
@@ -1072,11 +1081,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         double2 Da, Db, Dc;
                         loadD(h.y, Da, Db, Dc);
                         for (; j < jend; j += 64) {
+                            double2 Dan, Dbn, Dcn;
+                            loadD_row(hn.y, Dan, Dbn, Dcn); // (first: see loadD_row)
                             const int2 hnn = hits[min(j + 128, jend - 1)];
                             const double wan = recW[hn.x & 0xFFFF], wbn = recW[(unsigned)hn.x >> 16];
                             const double paxn = PC(P, 0, hn.y), payn = PC(P, 1, hn.y), pazn = PC(P, 2, hn.y);
-                            double2 Dan, Dbn, Dcn;
-                            loadD(hn.y, Dan, Dbn, Dcn);
                             double A1[12], A2[12], B1[6], B2[6];
                             double4 ra, rb; // both observations of the landmark: 24 B of landmark + two weights instead of 64 B of records
                             cam_norm(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
