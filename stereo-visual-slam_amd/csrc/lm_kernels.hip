@@ -1285,14 +1285,14 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     for (int u = 0; u < kLmU; ++u) {
                         const int l = min(l0 + u * kLmBlock, nl - 1);
                         in[u] = l0 + u * kLmBlock < nl;
+                        double2 da, dbb, dc;
+                        loadD_row(l, da, dbb, dc); // (first: behind the batch's global loads its LDS reads would wait for all of them)
+                        Dq[u][0] = da.x; Dq[u][1] = da.y; Dq[u][2] = dbb.x; Dq[u][3] = dbb.y; Dq[u][4] = dc.x; Dq[u][5] = dc.y;
                         cn[u] = lcnt[l];
 #pragma unroll
                         for (int q = 0; q < kLmE; ++q) { kk[u][q] = skf[(size_t)q * nl + l]; zz[u][q] = suv[(size_t)q * nl + l]; }
                         px[u] = PC(P, 0, l); py[u] = PC(P, 1, l); pz[u] = PC(P, 2, l);
                         g0[u] = PC(bl, 0, l); g1[u] = PC(bl, 1, l); g2[u] = PC(bl, 2, l);
-                        double2 da, dbb, dc;
-                        loadD(l, da, dbb, dc);
-                        Dq[u][0] = da.x; Dq[u][1] = da.y; Dq[u][2] = dbb.x; Dq[u][3] = dbb.y; Dq[u][4] = dc.x; Dq[u][5] = dc.y;
                     }
 #pragma unroll
                     for (int u = 0; u < kLmU; ++u) on[u] = cn[u] > 0 && in[u];
