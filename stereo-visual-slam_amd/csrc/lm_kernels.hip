@@ -521,10 +521,12 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         for (int u = 0; u < 3; ++u) {
             const int l = min(l0 + u * kLmBlock, nl - 1);
             on[u] = true; cn[u] = 1;
-            if (!IMPL) {
-                cn[u] = lm_ptr[l + 1] - lm_ptr[l];
-                on[u] = cn[u] > 0 && a.lm_inlier[lm0 + l] != 0;
-                if (with_lm && a.reliable) on[u] = on[u] && a.reliable[lm0 + l] != 0;
+            if (!IMPL) { // (plain loads first, the logic after: a load behind `&&` sits in its own branch, one dependent round trip each)
+                const int p0 = lm_ptr[l], p1 = lm_ptr[l + 1];
+                const uint8_t inl = a.lm_inlier[lm0 + l];
+                const uint8_t rel = (with_lm && a.reliable) ? a.reliable[lm0 + l] : (uint8_t)1;
+                cn[u] = p1 - p0;
+                on[u] = (cn[u] > 0) & (inl != 0) & (rel != 0);
             }
         }
 #pragma unroll
@@ -565,10 +567,16 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             int l1 = lmi[min(e_lo + lane, el)], l2 = lmi[min(e_lo + lane + 64, el)];
             int k1v = kfi[min(e_lo + lane, el)], k2v = kfi[min(e_lo + lane + 64, el)];
             int a1 = act[l1];
+            const float2* uv2e = reinterpret_cast<const float2*>(uv);
+            float2 z1 = uv2e[min(e_lo + lane, el)]; // (the observation travels with the ids: loaded inside the per-keyframe branches below it
+                                                    // was one dependent round trip per keyframe present in the batch)
             for (int base = e_lo; base < e_hi; base += 64) {
                 const int e = base + lane;
                 const int l3 = lmi[min(e + 128, el)], k3v = kfi[min(e + 128, el)];
                 const int a2 = act[l2];
+                const float2 z2 = uv2e[min(e + 64, el)];
+                const float2 zcur = z1;
+                z1 = z2;
                 const int k = (e < e_hi && a1) ? k1v : -1;
                 const int lcur = l1;
                 l1 = l2; l2 = l3; k1v = k2v; k2v = k3v; a1 = a2;
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int kk = 0; kk < kMaxKf; ++kk) {
                     if (kk < nk) {
                         const unsigned long long m = __ballot(k == kk);
-                        if (pass && k == kk) { const int slot = run[kk] + __popcll(m & lt_mask); kf_pos[e] = slot; kf_lm[slot] = lcur; uvk2[slot] = reinterpret_cast<const float2*>(uv)[e]; }
+                        if (pass && k == kk) { const int slot = run[kk] + __popcll(m & lt_mask); kf_pos[e] = slot; kf_lm[slot] = lcur; uvk2[slot] = zcur; }
                         run[kk] += __popcll(m);
                     }
                 }
@@ -1395,8 +1403,22 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             if (ratio > 0.5) break;
             th *= 2;
         }
-        for (int l = tid; l < nl; l += kLmBlock)
-            if (act[l]) a.lm_inlier[lm0 + l] = !(chi2k[kf_pos[lm_ptr[l + 1] - 1]] > th); // last edge of the landmark wins (ascending edge order)
+        // last edge of the landmark wins (ascending edge order).  lm_ptr -> kf_pos -> chi2 is a chain of three dependent loads: four
+        // landmarks per lane per trip, level by level (a strided loop is left serial: one round trip per load per landmark)
+        for (int l0 = tid; l0 < nl; l0 += 4 * kLmBlock) {
+            int la[4], pe[4], pp[4];
+            uint8_t av[4];
+            double cv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { la[u] = min(l0 + u * kLmBlock, nl - 1); av[u] = act[la[u]]; pe[u] = lm_ptr[la[u] + 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pp[u] = kf_pos[min(max(pe[u] - 1, 0), max(ne - 1, 0))];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cv[u] = chi2k[min(max(pp[u], 0), max(ne - 1, 0))];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (l0 + u * kLmBlock < nl && av[u]) a.lm_inlier[lm0 + la[u]] = !(cv[u] > th);
+        }
         if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
     }
     // ------------------------------------------------------------------ write-back (:272-287, :429-435)
