@@ -631,8 +631,16 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int base = l_lo; base < l_hi; base += 64) {
                     const int l = base + lane;
                     uint32_t w6[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                    if (l < l_hi && act[l]) {
-                        const int b0 = lm_ptr[l], b1 = lm_ptr[l + 1];
+                    // (two levels of unconditional, clamped loads -- flag and list bounds, then the first five observations -- instead of a
+                    // chain inside the branch: flag -> bounds -> observations was three dependent round trips per row of 64 landmarks)
+                    const int lc = min(l, max(nl - 1, 0));
+                    const uint8_t act_l = act[lc];
+                    const int b0 = lm_ptr[lc], b1 = lm_ptr[lc + 1];
+                    constexpr int kPre = 5;
+                    int kq[kPre], pq[kPre];
+#pragma unroll
+                    for (int q = 0; q < kPre; ++q) { const int e = min(max(b0 + q, 0), max(ne - 1, 0)); kq[q] = kfi[e]; pq[q] = kf_pos[e]; }
+                    if (l < l_hi && act_l) {
                         auto put = [&](int k, int ps) {
                             const int wi = k >> 1, sh = 16 * (k & 1);
 #pragma unroll
@@ -642,12 +650,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                     w6[i] = (w6[i] & ~(0xFFFFu << sh)) | ((uint32_t)ps << sh);
                                 }
                         };
-                        int kq[4], pq[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { const int e = min(b0 + q, ne - 1); kq[q] = kfi[e]; pq[q] = kf_pos[e]; }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) if (b0 + q < b1) put(kq[q], pq[q]);
-                        for (int e = b0 + 4; e < b1; ++e) put(kfi[e], kf_pos[e]);
+                        for (int q = 0; q < kPre; ++q) if (b0 + q < b1) put(kq[q], pq[q]);
+                        for (int e = b0 + kPre; e < b1; ++e) put(kfi[e], kf_pos[e]);
                     }
                     // which lanes' landmarks are seen by keyframe K: one ballot per keyframe, then a pair's hit mask is the AND of
                     // two scalar masks (creation-ordered landmarks: most pairs of a row are empty and cost three scalar ops)
