@@ -68,3 +68,25 @@ def test_window_with_unobserved_landmarks(vo, oracle, synth):
     assert np.array_equal(r["xyz"][-2:], xyz[-2:]) and np.array_equal(x[-2:], xyz[-2:])
     assert np.allclose(r["xyz"], x, rtol=1e-4, atol=1e-4)
     assert r["lm_inlier"][-2:].tolist() == [1, 1]   # no edge writes their flag
+
+
+@pytest.mark.parametrize("shape", [(376, 1241), (257, 333)])
+def test_saturated_background_and_odd_sizes(pkg, oracle, shape):
+    """white (255) background with dark rectangles: the 8-bit Gaussian blur of cv::GaussianBlur saturates there (its taps add up to 257
+    per pass, so sum >> 16 reaches 257 before saturate_cast) and the rBRIEF tests read saturated pixels; (257, 333) is a size
+    whose pyramid levels end in partial tiles / partial 16-byte chunks in every tiled kernel"""
+    h, w = shape
+    rng = np.random.default_rng(5)
+    img = np.full((h, w), 255, np.uint8)
+    for _ in range(160 if w > 1000 else 40):
+        x0, y0 = int(rng.integers(0, w - 12)), int(rng.integers(0, h - 12))
+        img[y0:y0 + int(rng.integers(6, 40)), x0:x0 + int(rng.integers(6, 60))] = int(rng.integers(0, 60))
+    ctx = pkg.VO(device=0, max_batch=1, img_w=w, img_h=h, orb_nfeatures=3000, anms_num=500)
+    try:
+        k, d = ctx.feature_detection(img)
+        wk, wd = oracle.feature_detection(img, 3000, 500)
+        assert len(wk) > 20
+        assert len(k) == len(wk) and all(np.array_equal(k[f], wk[f]) for f in ("x", "y", "angle", "response", "octave"))
+        assert np.array_equal(d, wd)
+    finally:
+        ctx.close()
