@@ -95,6 +95,21 @@ def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
         out.append({"kernel": "lm_window_kernel", "bound": "valu-issue", "achieved": round(used / t / 1e12, 3), "peak": round(256 * 4 * 2.4e9 / 4.0 / 1e12, 3),
                     "unit": "T wave-instructions/s", "frac": round(used / slots, 4),
                     "note": "SQ_INSTS_VALU of the BA schedule (profiles/r02_ba_sq_issue_stall_summary.txt) over the live kernel time; two waves per SIMD (256 VGPRs)"})
+    # ... and in FP64 vector terms (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of the BA schedule, tools/profile_f64.sh): the f64 pipe is the
+    # unit the two big phases of the kernel saturate at two waves per SIMD (tools/scratch/valu_rate.hip: a wave64 f64 op holds its SIMD
+    # ~4 cycles, an f32 / integer op ~2)
+    try:
+        fj = json.load(open(os.path.join(ROOT, "profiles", "r02_ba_valu_f64.json")))["per_window_schedule"]
+    except Exception:
+        fj = None
+    if k and k[0] > 0 and fj and pipe.lms_per_window == 3000 and pipe.n_kf == 10:
+        sets = k[2] if len(k) > 2 and k[2] else n_steps
+        t = k[0] / 1e3 / sets
+        tflops = fj["f64_flop"] * pipe.B / t / 1e12
+        simd_cycles = (fj["f64_total"] * 4.0 + (fj["valu"] - fj["f64_total"]) * 2.0) * pipe.B / 1024.0  # per SIMD
+        out.append({"kernel": "lm_window_kernel", "bound": "fp64-vector", "achieved": round(tflops, 2), "peak": 78.6, "unit": "TFLOP/s (f64, FMA = 2)",
+                    "frac": round(tflops / 78.6, 4), "valu_pipe_busy_frac_at_2.4GHz": round(simd_cycles / (t * 2.4e9), 3),
+                    "note": "f64 ops are 66 % of the kernel's VALU wave-instructions (profiles/r02_ba_valu_f64.json); pipe occupancy = (4 x f64 + 2 x other) cycles per SIMD over the live kernel time"})
     return out
 
 
