@@ -304,6 +304,14 @@ __device__ inline void jac_point_norm(double x, double y, double rho, const doub
         B[3 + c] = rho * fma(y, R[6 + c], -R[3 + c]);
     }
 }
+// the same without the factor rho (the Schur passes fold it into their scalar weights: six multiplies less per observation)
+__device__ inline void jac_point_unit(double x, double y, const double* R, double B[6]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        B[c] = fma(x, R[6 + c], -R[c]);
+        B[3 + c] = fma(y, R[6 + c], -R[3 + c]);
+    }
+}
 // evaluation of one observation: normalised error en, pixel chi2, robust rho, Huber weight
 __device__ inline void eval_obs(const CamK& ck, double x, double y, float2 z, double delta, double& enx, double& eny, double& chi, double& rob, double& wgt) {
     enx = fma((double)z.x, ck.ifx, ck.kx) - x;
@@ -1034,8 +1042,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             double4 ra; // the linearisation record {x, y, 1/Z, w}: camera-frame part recomputed from the landmark
                             cam_norm(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
                             jac_norm(ra.x, ra.y, ra.z, A1);
-                            jac_point_norm(ra.x, ra.y, ra.z, R1, B1);
-                            const double l0 = ra.w * ck.fx2, l1 = ra.w * ck.fy2;
+                            jac_point_unit(ra.x, ra.y, R1, B1); // (Bt = rho B1: rho goes into l0, l1 below)
+                            const double wr = ra.w * ra.z;
+                            const double l0 = wr * ck.fx2, l1 = wr * ck.fy2; // = w rho fx^2, w rho fy^2
                             double BD[6];
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
@@ -1104,9 +1113,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                             cam_norm(R1, pax, pay, paz, ra.x, ra.y, ra.z); ra.w = wa;
                             cam_norm(R2, pax, pay, paz, rb.x, rb.y, rb.z); rb.w = wb;
                             jac_norm(ra.x, ra.y, ra.z, A1);
-                            jac_point_norm(ra.x, ra.y, ra.z, R1, B1);
+                            jac_point_unit(ra.x, ra.y, R1, B1); // (Bt = rho B: the two rhos go into ww below)
                             jac_norm(rb.x, rb.y, rb.z, A2);
-                            jac_point_norm(rb.x, rb.y, rb.z, R2, B2);
+                            jac_point_unit(rb.x, rb.y, R2, B2);
                             double BD[6];
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
@@ -1114,7 +1123,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 BD[3 * r + 1] = B1[3 * r] * Da.y + B1[3 * r + 1] * Db.y + B1[3 * r + 2] * Dc.x;
                                 BD[3 * r + 2] = B1[3 * r] * Db.x + B1[3 * r + 1] * Dc.x + B1[3 * r + 2] * Dc.y;
                             }
-                            const double ww = ra.w * rb.w; // M = L1 (Bt1 D Bt2^T) L2 with L = w diag(fx^2, fy^2)
+                            const double ww = (ra.w * ra.z) * (rb.w * rb.z); // M = L1 (Bt1 D Bt2^T) L2 with L = w diag(fx^2, fy^2), Bt = rho B
                             const double lw[4] = {ww * ck.fx2 * ck.fx2, ww * ck.fx2 * ck.fy2, ww * ck.fy2 * ck.fx2, ww * ck.fy2 * ck.fy2};
                             double M[4];
 #pragma unroll
