@@ -141,15 +141,22 @@ def cpu_baseline(pipe, out, anms_num, n_single=24, per_core=2, chunk_len=8):
         n1 = min(n_single, B)
         t0 = time.perf_counter()
         prev, pnp_o, pnp_g, ba_o, ba_g, int_mismatch = None, [], [], [], [], 0
+        stage_s = {"orb_lr_match_triangulate": 0.0, "f2f_match_motion_only_lm": 0.0, "local_ba_schedule": 0.0}
         for b in range(n1):
+            ts = time.perf_counter()
             cur = W.front_end(pipe.frame_of[b])
+            stage_s["orb_lr_match_triangulate"] += time.perf_counter() - ts
             int_mismatch += int(out["cnt"][b] != len(cur[0])) + int(out["cnt"][B + b] != cur[5]) + int(out["nlr"][b] != len(cur[2]))
             if prev is not None:
+                ts = time.perf_counter()
                 T, npts, ninl, nf = W.track(prev, cur)
+                stage_s["f2f_match_motion_only_lm"] += time.perf_counter() - ts
                 int_mismatch += int(out["nf2f"][b - 1] != nf) + int(out["pn"][b - 1] != npts) + int(out["ninl"][b - 1] != ninl)
                 if npts >= 6:
                     pnp_o.append(T); pnp_g.append(out["Tpnp"][b - 1])
+            ts = time.perf_counter()
             Tb, inl = W.ba_schedule(pipe.h_windows[b % pipe.unique_windows])
+            stage_s["local_ba_schedule"] += time.perf_counter() - ts
             ba_o.append(Tb); ba_g.append(out["ba_T"][b])
             lo, hi = pipe.h_lm_off[b], pipe.h_lm_off[b + 1]
             int_mismatch += int((out["ba_inl"][lo:hi] != inl).sum())
@@ -185,7 +192,8 @@ def cpu_baseline(pipe, out, anms_num, n_single=24, per_core=2, chunk_len=8):
     finally:
         os.unlink(tmp.name)
     res = dict(unit="keyframes/s", kind="port",
-               single_thread=dict(value=n1 / dt1, cores=1, keyframes=n1, seconds=round(dt1, 2)),
+               single_thread=dict(value=n1 / dt1, cores=1, keyframes=n1, seconds=round(dt1, 2),
+                                  stage_ms_per_keyframe={k: round(1e3 * v / n1, 2) for k, v in stage_s.items()}),
                sample=("oracle/libvo_oracle.so per stereo keyframe: 2 ORB images (3000 -> ANMS %d -> rBRIEF), L/R + frame-to-frame match, DLT, "
                        "motion-only LM, BA schedule 5+5+10+10 on one 10x%d window; single thread: %d keyframes in %.1f s" % (anms_num, int(pipe.lms_per_window), n1, dt1)))
     if all_cores:
