@@ -6,7 +6,9 @@
  * PARITY UNPINNED for everything marked [UPSTREAM]: OpenCV is not in this image; these are restatements of
  * the published OpenCV 3.2 algorithms (modules/features2d/src/{orb,fast,fast_score,keypoint}.cpp,
  * modules/imgproc/src/{imgwarp,smooth,filter}.cpp, modules/core/src/mathfuncs_core.cpp), pinned only by the
- * known-answer tests in tests/.
+ * known-answer tests in tests/.  One piece IS pinned against independent third-party code: the FAST-9/16 corner set equals
+ * scikit-image 0.18.3's corner_fast(n=9, threshold=20) on three seeded images (tests/golden/skimage_fast9.npz,
+ * generator tests/golden/make_skimage_fast9.py, check tests/test_oracle_orb.py).
  *
  * Deviation (documented in DESIGN.md): OpenCV's retainBest leaves keypoints in std::nth_element order, which
  * is implementation-defined.  This oracle defines the total order "level ascending, raster (y,x) within a

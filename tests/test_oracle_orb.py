@@ -3,6 +3,8 @@
 PARITY UNPINNED against real OpenCV (absent from the image and from the reference repo: no golden vectors exist).  These
 tests pin the restatement against (a) constants derivable by hand from the published algorithm, (b) independent numpy
 restatements written from the definitions, (c) structural properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -112,6 +114,21 @@ def test_fast_matches_definition(oracle, synth):
     assert (kn["response"] == full[kn["y"].astype(int), kn["x"].astype(int)]).all()
     order = np.lexsort((kn["x"], kn["y"]))
     assert (order == np.arange(len(kn))).all()  # raster order
+
+
+def test_fast_corner_set_matches_scikit_image(oracle):
+    """third-party pin: the corner set of scikit-image's corner_fast(n=9, threshold=20) on three seeded images
+    (tests/golden/skimage_fast9.npz, generator tests/golden/make_skimage_fast9.py -- scikit-image itself is not needed here)"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skimage_fast9.npz"))
+    for k in range(3):
+        img = g["img%d" % k]
+        h, w = img.shape
+        want = np.unpackbits(g["mask%d" % k])[:h * w].reshape(h, w).astype(bool)
+        assert want[3:h - 3, 3:w - 3].sum() > 500 and not want[:3].any() and not want[:, :3].any()
+        c = oracle.fast9_16(img, 20, nonmax=False)
+        got = np.zeros((h, w), bool)
+        got[c["y"].astype(int), c["x"].astype(int)] = True
+        assert np.array_equal(got, want), "image %d: %d differing pixels" % (k, int((got != want).sum()))
 
 
 def test_fast_hand_made_patches(oracle):
