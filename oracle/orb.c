@@ -8,7 +8,9 @@
  * modules/imgproc/src/{imgwarp,smooth,filter}.cpp, modules/core/src/mathfuncs_core.cpp), pinned only by the
  * known-answer tests in tests/.  One piece IS pinned against independent third-party code: the FAST-9/16 corner set equals
  * scikit-image 0.18.3's corner_fast(n=9, threshold=20) on three seeded images (tests/golden/skimage_fast9.npz,
- * generator tests/golden/make_skimage_fast9.py, check tests/test_oracle_orb.py).
+ * generator tests/golden/make_skimage_fast9.py, check tests/test_oracle_orb.py), and the intensity-centroid angle agrees with
+ * scikit-image's corner_orientations on the same 749-pixel circular patch within 0.01 degree at 200 seeded points
+ * (tests/golden/skimage_ic_angle.npz, generator tests/golden/make_skimage_ic_angle.py).
  *
  * Deviation (documented in DESIGN.md): OpenCV's retainBest leaves keypoints in std::nth_element order, which
  * is implementation-defined.  This oracle defines the total order "level ascending, raster (y,x) within a

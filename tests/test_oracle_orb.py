@@ -158,6 +158,17 @@ def test_fast_atan2(oracle):
         assert 0 <= got <= 360 and min(abs(got - ref), 360 - abs(got - ref)) < 0.3  # the polynomial is a ~0.3 deg approximation
 
 
+def test_ic_angle_matches_scikit_image(oracle):
+    """third-party pin: scikit-image's corner_orientations on its OFAST_MASK (the same 749-pixel circular patch) at 200 seeded points
+    (tests/golden/skimage_ic_angle.npz, generator tests/golden/make_skimage_ic_angle.py); scikit-image uses atan2 in double
+    precision, OpenCV the fastAtan2 polynomial (~0.01 degree): same angle within 0.05 degree"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skimage_ic_angle.npz"))
+    img, pts, want = g["img"], g["pts"], np.degrees(g["angle_rad"]) % 360.0
+    got = np.array([oracle.ic_angle(img, int(c), int(r)) for r, c in pts])
+    diff = (got - want + 180.0) % 360.0 - 180.0
+    assert np.abs(diff).max() < 0.05, np.abs(diff).max()
+
+
 def test_ic_angle_on_ramps(oracle):
     yy, xx = np.mgrid[0:64, 0:64]
     for gx, gy, want in ((1, 0, 0.0), (0, 1, 90.0), (-1, 0, 180.0), (0, -1, 270.0), (1, 1, 45.0)):
