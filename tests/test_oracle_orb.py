@@ -37,6 +37,19 @@ def test_blur_matches_numpy_fixed_point(oracle):
     assert np.array_equal(oracle.gaussian_blur7(img), want)
 
 
+def test_blur_close_to_scipy_gaussian(oracle):
+    """third-party pin of kernel shape and border mode: scipy.ndimage.gaussian_filter(sigma=2, radius 3, mode="mirror" = reflect-101)
+    in float64.  cv::GaussianBlur's 8-bit path uses the taps cvRound(256 k) = {18,34,49,55,49,34,18}, which add up to 257: the
+    fixed-point result is the float Gaussian times (257/256)^2, rounded -- within one grey level after that gain"""
+    from scipy.ndimage import gaussian_filter, uniform_filter
+    rng = np.random.default_rng(5)
+    img = uniform_filter(rng.integers(0, 256, (97, 131)).astype(np.float64), 3).astype(np.uint8)
+    got = oracle.gaussian_blur7(img).astype(np.float64)
+    want = gaussian_filter(img.astype(np.float64), sigma=2.0, truncate=1.5, mode="mirror") * (257.0 / 256.0) ** 2
+    diff = np.abs(got - want)
+    assert diff.max() < 0.9 and diff.mean() < 0.35, (diff.max(), diff.mean())
+
+
 def test_resize_matches_numpy_fixed_point(oracle):
     """independent vectorised restatement of the 11-bit fixed-point INTER_LINEAR path"""
     rng = np.random.default_rng(1)
@@ -62,6 +75,16 @@ def test_resize_matches_numpy_fixed_point(oracle):
         assert np.array_equal(oracle.resize_linear(src, dw, dh), want)
     const = np.full((30, 40), 77, np.uint8)
     assert (oracle.resize_linear(const, 33, 25) == 77).all()
+
+
+def test_resize_geometry_matches_scikit_image(oracle):
+    """third-party pin of the geometry (pixel-centre alignment, replicated edge): scikit-image's float64 bilinear resize at the ORB
+    scale 1.2 (tests/golden/skimage_resize.npz, generator tests/golden/make_skimage_resize.py); the 8-bit fixed-point path must
+    stay within one grey level of it"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skimage_resize.npz"))
+    got = oracle.resize_linear(g["img"], int(g["dw"]), int(g["dh"])).astype(np.float64)
+    diff = np.abs(got - g["out"].astype(np.float64))
+    assert diff.max() < 0.9 and diff.mean() < 0.35, (diff.max(), diff.mean())
 
 
 def test_pyramid_chain_is_level_from_previous_level(oracle, synth):
