@@ -226,6 +226,23 @@ def test_harris_matches_numpy(oracle):
     assert oracle.harris_response(img, x0, y0) == pytest.approx(float(want), rel=1e-6)
 
 
+def test_harris_matches_scipy_sobel_and_box(oracle):
+    """the same response composed from third-party building blocks: scipy.ndimage.sobel (the 3 x 3 Sobel derivative, its sign and
+    smoothing convention) and a 7 x 7 box sum, in float64; cv::cornerHarris' scale 1 / (4 * blockSize * 255) for 8-bit input to the
+    fourth power, k = 0.04.  The oracle works in int32 sums and float32 like orb.cpp's HarrisResponses: relative 1e-5"""
+    from scipy.ndimage import sobel, uniform_filter
+    rng = np.random.default_rng(9)
+    img = uniform_filter(rng.integers(0, 256, (60, 70)).astype(np.float64), 3).astype(np.uint8)
+    I = img.astype(np.float64)
+    Ix, Iy = sobel(I, axis=1, mode="nearest"), sobel(I, axis=0, mode="nearest")
+    box = lambda A: uniform_filter(A, size=7, mode="nearest") * 49.0
+    a, b, c = box(Ix * Ix), box(Iy * Iy), box(Ix * Iy)
+    R = (a * b - c * c - 0.04 * (a + b) ** 2) * (1.0 / (4 * 7 * 255)) ** 4
+    for _ in range(50):
+        x, y = int(rng.integers(8, 62)), int(rng.integers(8, 52))
+        assert oracle.harris_response(img, x, y) == pytest.approx(R[y, x], rel=2e-5, abs=1e-12)
+
+
 def test_retain_best_keeps_ties(oracle):
     kps = np.zeros(10, oracle.KEYPOINT_DTYPE)
     kps["response"] = [5, 9, 7, 7, 7, 1, 8, 7, 2, 3]; kps["x"] = np.arange(10)
