@@ -10,6 +10,9 @@ DLT triangulation, frame-to-frame match, motion-only LM pose, local BA (10 KF x 
 10 pose-only).  Keyframes shard across ranks with no data-path collective ("weak" scaling); the only collective is the
 RCCL all-gather of the per-keyframe poses (56 B each) once per step.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N ranks
+(one per GPU, rendezvous on 127.0.0.1); under a launcher, --gpus must equal WORLD_SIZE.  It refuses to run on fewer GPUs.
+
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, timed live with HIP events on
 the launch stream through the library's stage profiler) and `cpu_baseline` (the CPU oracle -- a "port", the reference
 itself is unbuildable here -- timed on this host, rank 0 at N=1, on a bounded sample of the same workload).
@@ -205,6 +208,101 @@ def cpu_baseline(pipe, out, anms_num, n_single=24, per_core=2, chunk_len=8):
     return res, parity
 
 
+def host_input_region(pipe, args, timed_region, one_step, torch):
+    """--inputs host: the same steps with every step's 2B images arriving from pinned host memory: ring of two device batches, the
+    hipMemcpyAsync of step k+1 on a copy stream overlapped with step k (the reference reads its pairs from disk per frame,
+    visual_odometry.cpp:37-68).  Returns keyframes/s with the upload inside the timed region, and the H2D time per step alone."""
+    dev = pipe.dev
+    h_ring = [torch.from_numpy(pipe.h_imgs).pin_memory(), torch.from_numpy(pipe.h_imgs.copy()).pin_memory()]
+    d_ring = [pipe.d_imgs, torch.empty_like(pipe.d_imgs)]
+    copy_stream = torch.cuda.Stream(dev)
+    copied = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [torch.cuda.Event(), torch.cuda.Event()]
+    # H2D alone: one batch, synchronous bracket
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(copy_stream):
+        d_ring[1].copy_(h_ring[1], non_blocking=True)
+        e0.record(copy_stream)
+        for _ in range(3):
+            d_ring[1].copy_(h_ring[1], non_blocking=True)
+        e1.record(copy_stream)
+    torch.cuda.synchronize(dev)
+    h2d_ms = e0.elapsed_time(e1) / 3.0
+    nbytes = pipe.h_imgs.nbytes
+    state = {"k": 0}
+    with torch.cuda.stream(copy_stream):       # prologue: batch 0 in flight
+        d_ring[0].copy_(h_ring[0], non_blocking=True)
+        copied[0].record(copy_stream)
+    for ev in consumed:
+        ev.record(pipe.stream)
+
+    def step_from_host():
+        cur = state["k"] & 1
+        nxt = cur ^ 1
+        with torch.cuda.stream(copy_stream):   # upload of the NEXT step's images, once the step that last read that buffer has finished its ORB stage
+            copy_stream.wait_event(consumed[nxt])
+            d_ring[nxt].copy_(h_ring[nxt], non_blocking=True)
+            copied[nxt].record(copy_stream)
+        pipe.stream.wait_event(copied[cur])
+        pipe.d_imgs = d_ring[cur]
+        pipe.stage_orb()
+        if pipe.depth == "sgbm":
+            pipe.stage_stereo_match(); consumed[cur].record(pipe.stream)
+        else:
+            consumed[cur].record(pipe.stream); pipe.stage_stereo_match()
+        pipe.stage_track()
+        pipe.stage_ba()
+        state["k"] += 1
+
+    for _ in range(2):
+        step_from_host()
+    el = timed_region(step_from_host)
+    torch.cuda.synchronize(dev)
+    pipe.d_imgs = d_ring[0]
+    return {"value": round(pipe.B * args.steps / el, 3), "unit": "keyframes/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+            "h2d_ms_per_step": round(h2d_ms, 4), "h2d_gbs": round(nbytes / (h2d_ms * 1e-3) / 1e9, 2), "h2d_bytes_per_step": int(nbytes),
+            "how": "pinned host ring of 2 batches; hipMemcpyAsync of step k+1 on a copy stream overlapped with step k; the upload is inside the timed region"}
+
+
+def host_info():
+    """lscpu-style identification of the host the cpu_baseline ran on + run-time probe for the reference's own libraries"""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except Exception:
+        pass
+    info = {"cpu_model": model, "logical_cpus": os.cpu_count()}
+    try:
+        info["cpus_available_to_this_process"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # SURVEY 8(d) row 2: the real cv::ORB / BFMatcher / g2o path, if and only if the libraries exist on this host
+    import ctypes.util
+    import importlib.util
+    have_cv2 = importlib.util.find_spec("cv2") is not None
+    g2o = ctypes.util.find_library("g2o_core")
+    ocv = ctypes.util.find_library("opencv_features2d")
+    info["reference_libs"] = {"cv2_python": have_cv2, "libopencv_features2d": ocv, "libg2o_core": g2o}
+    return info, have_cv2
+
+
+def reference_lib_timing(pipe, anms_num, n=8):
+    """real cv::ORB(3000) detect + compute and BFMatcher(HAMMING, crossCheck) through cv2 -- only if cv2 exists on this host"""
+    import cv2
+    orb = cv2.ORB_create(3000); bf = cv2.BFMatcher(cv2.NORM_HAMMING, True)
+    t0 = time.perf_counter()
+    for u in range(n):
+        L = np.ascontiguousarray(pipe.h_imgs_unique_left[u % pipe.unique_frames][:, :pipe.w]); R = np.ascontiguousarray(pipe.h_imgs_unique_right[u % pipe.unique_frames][:, :pipe.w])
+        kL, dL = orb.detectAndCompute(L, None); kR, dR = orb.detectAndCompute(R, None)
+        bf.match(dL, dR)
+    dt = time.perf_counter() - t0
+    return {"opencv_version": cv2.__version__, "orb_lr_match_ms_per_keyframe": round(1e3 * dt / n, 2), "keyframes": n,
+            "note": "cv2.ORB_create(3000).detectAndCompute on L and R + BFMatcher(NORM_HAMMING, crossCheck=True); no ANMS (reference C++ only), no g2o"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,7 +312,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="stereo keyframes per GPU per step")
     ap.add_argument("--anms", type=int, default=1500, help="keypoints per image after ANMS (BASELINE config 2: ~1500; reference: 500)")
     ap.add_argument("--landmarks", type=int, default=3000)
-    ap.add_argument("--unique-frames", type=int, default=64, help="rendered stereo keyframes (one sequence, laid over the batch as a ping-pong)")
+    ap.add_argument("--unique-frames", type=int, default=256, help="rendered stereo keyframes (one sequence, laid over the batch as a ping-pong)")
+    ap.add_argument("--inputs", choices=["resident", "host"], default="host",
+                    help="host: additionally time the same steps with the images arriving from pinned host memory (ring of 2 batches, "
+                         "hipMemcpyAsync on a copy stream overlapped with the previous step) and report it under `inputs_from_host`; "
+                         "the headline `value` is always the HBM-resident one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--depth", choices=["match", "sgbm"], default="match",
@@ -224,17 +326,42 @@ def main():
                          "gathered over RCCL and chained on rank 0 (stereo-visual-slam_amd/sharding.py); 0 = independent batches per rank")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
 
     import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become N ranks (one process per GPU over RCCL) instead of silently timing one GPU
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run (no single-GPU stand-in for an N-GPU line)" % (args.gpus, n_dev))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d (launch with --nproc-per-node %d, or drop the launcher and let "
+                         "bench.py start the ranks itself)" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+        assert dist.get_world_size() == args.gpus
+    try:
+        host_cores = len(os.sched_getaffinity(0))
+    except Exception:
+        host_cores = os.cpu_count() or 1
+    render_workers = max(1, min(host_cores // max(world, 1), 32))
 
     from stereo_visual_slam_amd.pipeline import KeyframePipeline
     from stereo_visual_slam_amd import sharding
@@ -246,10 +373,11 @@ def main():
         h_lo = sharding.halo_start(lo)
         B = hi - h_lo
         pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=0, verbose=args.verbose and rank == 0,
-                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence))
+                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence),
+                                render_workers=render_workers)
     else:
         pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
-                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames)
+                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, render_workers=render_workers)
     dev = pipe.dev
     chained = [None]
 
@@ -266,17 +394,17 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
-    copy_gbs = pipe.vo.hbm_copy_probe(1 << 30, 5) if rank == 0 else 0.0
-    pipe.vo.profile_enable(True)
-    pipe.vo.profile_read()
-    rep_s = []
-    for rep in range(max(args.repeats, 1)):   # every repeat: EXACTLY `steps` steps between barrier + synchronize brackets, max over ranks
+    copy_probe = pipe.vo.hbm_copy_probe_best(1 << 30, 5) if rank == 0 else {"gbs": 0.0}
+    copy_gbs = copy_probe["gbs"]
+
+    def timed_region(step_fn):
+        """EXACTLY `steps` steps between barrier + synchronize brackets; max over ranks"""
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            one_step()
+            step_fn()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -286,11 +414,24 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        rep_s.append(el)
+        return el
+
+    # the timed repeats run WITHOUT the stage profiler (its hipEvent brackets sit between the kernels) ...
+    rep_s = [timed_region(one_step) for _ in range(max(args.repeats, 1))]
+    # ... and one extra, untimed-for-the-headline repeat of the same `steps` steps WITH it: per-kernel durations from HIP events on the launch stream
+    pipe.vo.profile_enable(True)
+    pipe.vo.profile_read()
+    profiled_s = timed_region(one_step)
     prof = pipe.vo.profile_read()
     pipe.vo.profile_enable(False)
+    n_prof_steps = args.steps
+    host_inputs = None
+    if args.inputs == "host" and not seq_mode and world == 1:
+        try:
+            host_inputs = host_input_region(pipe, args, timed_region, one_step, torch)
+        except Exception as e:  # the extra measurement must never cost the headline
+            host_inputs = {"error": repr(e)}
     elapsed = float(np.median(rep_s))
-    n_timed_steps = args.steps * len(rep_s)
     # a step that overflowed an ORB capacity or whose BA windows were rejected must not count as processed keyframes
     n_img = pipe.B if args.depth == "sgbm" else 2 * pipe.B
     orb_bad = int((pipe.vo.orb_status(n_img) != 0).sum())
@@ -305,19 +446,31 @@ def main():
         kern = sorted(prof.items(), key=lambda kv: -kv[1][0])
         dom, (dom_ms, dom_launches, dom_calls) = kern[0]
         alg, formula = algorithmic_bytes(dom, pipe, args.anms)
+        if dom.startswith("sgbm_"):
+            # --depth sgbm: the roofline line is the SGBM FAMILY (one bracket = one vslam_disparity_map_dev call = B pairs): compulsory bytes of a
+            # fully fused design = the (w - 96) x h x 96 x i16 cost volume once + both images in + the f32 map out, per pair
+            fam = [(k, v) for k, v in kern if k.startswith("sgbm_")]
+            dom = "sgbm_* (family: %s)" % ", ".join(k for k, _ in fam)
+            dom_ms = sum(v[0] for _, v in fam); dom_launches = sum(v[1] for _, v in fam); dom_calls = args.steps
+            cv = (pipe.w - 96) * pipe.h * 96 * 2
+            alg = B * (cv + 2 * pipe.w * pipe.h + 4 * pipe.w * pipe.h)
+            formula = "B pairs x ((w-96)*h*96*2 B cost volume once + 2*w*h B images in + 4*w*h B f32 disparity out)"
         per_bracket_s = dom_ms / 1e3 / max(dom_calls, 1)
         achieved = alg / per_bracket_s / 1e9 if per_bracket_s > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         try:  # measured offline with rocprofv3 PMC passes (tools/profile_round.sh); only valid for the same kernel and batch
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj.get("kernel") == dom and tj.get("batch") == B:
                 traffic = int(tj["hbm_bytes_per_launch_set"])
+            traffic_src = tj.get("source")
         except Exception:
             traffic = None
         nt = max(B - 1, 1)
         res = {
             "metric": "stereo keyframes/sec (ORB+match+tri+local-BA), KITTI-00 1241x376",
             "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "world_size": (dist.get_world_size() if dist is not None else 1),
+            "collective": ("RCCL %s over torch.distributed backend nccl" % ".".join(str(x) for x in torch.cuda.nccl.version())) if dist is not None else "none (1 rank)",
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if seq_mode else "weak", "vs_baseline": None,
             "dtype": "u8+f64", "data": "synthetic",
             "config": {"workload": ("stereo keyframe hot path, north_star stages (NOT the reference's SGBM depth / solvePnPRansac pose, which are built "
@@ -331,23 +484,36 @@ def main():
                        "parallelism": ("one %d-frame sequence in %d contiguous chunks with a 1-frame halo, relative poses gathered and chained on rank 0" % (args.sequence, world))
                                       if seq_mode else "%d independent replicas, sharded keyframes" % world},
             "timing": {"repeats": len(rep_s), "ms_per_step_each": [round(1e3 * x / args.steps, 4) for x in rep_s], "reported": "median",
-                       "spread_pct": round(100.0 * (max(rep_s) - min(rep_s)) / elapsed, 2)},
+                       "spread_pct": round(100.0 * (max(rep_s) - min(rep_s)) / elapsed, 2),
+                       "stage_profiler": "off in the timed repeats; on in one extra repeat of the same %d steps (%.4f ms/step) that feeds `roofline` and "
+                                         "`kernels_ms_per_step`" % (args.steps, 1e3 * profiled_s / args.steps)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "copy_ceiling_gbs": round(copy_gbs, 1), "frac_of_copy_ceiling": round(achieved / copy_gbs, 6) if copy_gbs > 0 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "copy_ceiling_gbs": round(copy_gbs, 1), "copy_probe": copy_probe, "copy_ceiling_guide_gbs": 6290.0, "frac_of_copy_ceiling": round(achieved / copy_gbs, 6) if copy_gbs > 0 else None,
                          "algorithmic_bytes_per_launch_set": int(alg), "formula": formula,
                          "avg_ms_per_launch_set": round(1e3 * per_bracket_s, 4), "kernel_launches_per_set": dom_launches // max(dom_calls, 1)},
-            "kernels_ms_per_step": {k: round(v[0] / n_timed_steps, 4) for k, v in kern},
-            "other_rooflines": other_rooflines(prof, pipe, args, n_timed_steps, copy_gbs),
+            "kernels_ms_per_step": {k: round(v[0] / n_prof_steps, 4) for k, v in kern},
+            "other_rooflines": other_rooflines(prof, pipe, args, n_prof_steps, copy_gbs),
             "stats": {"keypoints_per_image": float(out["cnt"].mean()), "lr_matches": float(out["nlr"].mean()), "lr_matches_min": int(out["nlr"].min()),
                       "f2f_matches": float(out["nf2f"][:nt].mean()), "pnp_points": float(out["pn"][:nt].mean()), "pnp_points_min": int(out["pn"][:nt].min()),
                       "pnp_inliers": float(out["ninl"][:nt].mean()), "pnp_inliers_min": int(out["ninl"][:nt].min()),
                       "orb_status_nonzero": orb_bad, "ba_status_nonzero": ba_bad},
         }
+        if host_inputs is not None:
+            res["inputs_from_host"] = host_inputs
         if seq_mode and chained[0] is not None:
             res["trajectory"] = {"frames": int(len(chained[0])), "final_position": [float(x) for x in sharding.camera_centre(chained[0][-1])]}
         if world == 1 and not args.no_cpu_baseline and not args.no_ba and args.depth == "match" and not seq_mode:
             res["cpu_baseline"], res["pose_rmse_vs_oracle"] = cpu_baseline(pipe, out, args.anms)
+            info, have_cv2 = host_info()
+            res["cpu_baseline"]["host"] = info
+            if have_cv2:
+                try:
+                    res["cpu_baseline"]["reference_libs_timing"] = reference_lib_timing(pipe, args.anms)
+                except Exception as e:
+                    res["cpu_baseline"]["reference_libs_timing"] = "cv2 present but failed: %r" % (e,)
+            else:
+                res["cpu_baseline"]["reference_libs_timing"] = "unavailable on this host (no cv2 / OpenCV / g2o found at run time)"
         print(json.dumps(res), flush=True)
     pipe.close()
     if world > 1:

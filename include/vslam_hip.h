@@ -35,6 +35,12 @@ extern "C" {
 #define VSLAM_ERR_CAPACITY (-3)  /* an internal or caller capacity was exceeded (results truncated) */
 #define VSLAM_ERR_NO_DEVICE (-4) /* no gfx950-class GPU visible */
 
+/* ABI revision of this header.  Bumped whenever a struct grows or a signature changes position-wise (revision 2 inserted K4 into
+ * vslam_local_ba / vslam_pose_only_window; revision 3 added struct_size / abi_version to vslam_params and the alignment contract
+ * of vslam_feature_matching_dev).  vslam_create refuses a vslam_params whose struct_size / abi_version do not match the library's,
+ * so a caller compiled against an older header fails with VSLAM_ERR_ARG instead of having its arguments reinterpreted. */
+#define VSLAM_ABI_VERSION 3
+
 #define VSLAM_ORB_NLEVELS 8
 #define VSLAM_MAX_KF 12          /* keyframes per optimisation window (reference: Map::num_keyframes_ = 10, map.hpp:22) */
 #define VSLAM_LM_MAX_ITERS 32
@@ -69,6 +75,8 @@ typedef struct vslam_params {
     double stereo_row_tol;         /* 2.0 px    epipolar gate of the L/R-match depth stage (vslam_triangulate*): a pair is kept
                                       only if |vL - vR| <= tol and uL > uR; < 0 = off.  No counterpart in the reference, whose
                                       depth is SGBM (row-constrained by construction, visual_odometry.cpp:159-174)         */
+    int32_t struct_size;           /* sizeof(vslam_params) of the caller's header; set by vslam_default_params, checked by vslam_create */
+    int32_t abi_version;           /* VSLAM_ABI_VERSION of the caller's header; likewise                                  */
 } vslam_params;
 
 typedef struct vslam_lm_stats {
@@ -88,6 +96,7 @@ int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** ou
 void vslam_destroy(vslam_ctx* ctx);
 const char* vslam_last_error(void);
 const char* vslam_version(void);
+int vslam_abi_version(void);       /* VSLAM_ABI_VERSION the library was built with */
 int vslam_sync(vslam_ctx* ctx);
 /* bytes of device memory the context holds */
 size_t vslam_device_bytes(const vslam_ctx* ctx);
@@ -122,7 +131,9 @@ int vslam_feature_matching(vslam_ctx* ctx, const uint8_t* q, int nq, const uint8
                            int gate, vslam_dmatch* out, int* n_out);
 
 /* Batched, device-resident: item b matches d_q + b*q_stride_bytes (d_nq[b] rows) against d_t + b*t_stride_bytes
- * (d_nt[b] rows); writes d_out + b*out_capacity (ascending queryIdx) and d_nout[b].  d_gap: per-item frame gap. */
+ * (d_nt[b] rows); writes d_out + b*out_capacity (ascending queryIdx) and d_nout[b].  d_gap: per-item frame gap.
+ * Alignment contract: d_q, d_t and both strides must be multiples of 16 bytes (the kernel reads descriptors with 16-byte
+ * loads); anything else is VSLAM_ERR_ARG.  (The host-buffer call above stages into aligned memory itself.) */
 int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stride_bytes, const int32_t* d_nq,
                                const uint8_t* d_t, size_t t_stride_bytes, const int32_t* d_nt,
                                const double* d_gap, int gate, int B, int max_rows,
@@ -185,8 +196,10 @@ int vslam_pnp_motion_only_dev(vslam_ctx* ctx, const float* d_xyz_w, const float*
 /* The reference's own pose stage: cv::solvePnPRansac(pts3d, pts2d, K, Mat(), rvec, tvec, false, 100, 4.0, 0.99, inliers) at
  * visual_odometry.cpp:277 -- OpenCV's RNG (seed (uint64)-1, multiply-with-carry) and 5-point subset draw, EPnP on every subset
  * from scratch (no pose guess: useExtrinsicGuess = false), f32 squared reprojection errors against (float)(reproj_err^2), the
- * strict "more inliers than max(best, 4)" acceptance, RANSACUpdateNumIters, refinement on the inliers of the best model, mask =
- * RANSAC mask.  All `max_iters` hypotheses are solved (one wave each) and scored in parallel on the device (they do not depend on
+ * strict "more inliers than max(best, 4)" acceptance, RANSACUpdateNumIters, mask = RANSAC mask.
+ * lm_iters = 0: T_c_w = the best RANSAC model itself -- what OpenCV 3.2.0 (the version the reference pins, README.md:72) returns: its
+ * solvePnPRansac runs solvePnP on the inliers and then assigns `_local_model` to rvec / tvec (solvepnp.cpp), discarding the refined pose.
+ * lm_iters > 0: T_c_w = the pose refined on the inliers of the best model (OpenCV 3.4.2+ behaviour).  All `max_iters` hypotheses are solved (one wave each) and scored in parallel on the device (they do not depend on
  * each other); the adaptive stopping rule is then replayed over the counts in order, so the result is that of the sequential loop.
  * Remaining deviations from OpenCV (the final refinement is this library's least-squares LM, not CvLevMarq; the eigen-solver's
  * basis for the null space of the 5-point system) are listed in oracle/ransac.c / epnp.c.  T_c_w: OUTPUT only (untouched on failure).
@@ -282,6 +295,10 @@ int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_o
 /* Measurement aid: a float4 streaming copy of `bytes` (read + write), `reps` launches timed with hipEvents on the context
  * stream; *gbs_out = moved GB/s.  The achievable-bandwidth figure reported next to the 8 TB/s HBM spec. */
 int vslam_hbm_copy_probe(vslam_ctx* ctx, size_t bytes, int reps, double* gbs_out);
+/* One shape of that copy (unroll, non-temporal or not, workgroups per CU): variant = 0 .. vslam_hbm_copy_probe_variants() - 1;
+ * name_out (>= 64 bytes, may be NULL) receives its description.  vslam_hbm_copy_probe reports the best of them. */
+int vslam_hbm_copy_probe_variants(void);
+int vslam_hbm_copy_probe_variant(vslam_ctx* ctx, size_t bytes, int reps, int variant, double* gbs_out, char* name_out);
 
 /* ------------------------------------------------------------------ raw device memory helpers ---------- */
 /* For hosts without their own device allocator (the C++ mirror in host/); bench.py passes torch tensors. */

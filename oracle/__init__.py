@@ -384,7 +384,7 @@ def pnp_ransac_hypothesis(xyz, uv, it, K=K_KITTI, reproj_err=4.0):
     return T, n, sub
 
 
-def pnp_ransac(xyz, uv, T0=None, K=K_KITTI, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+def pnp_ransac(xyz, uv, T0=None, K=K_KITTI, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=0):
     """T0 is ignored (kept for call compatibility): like the reference's call, no pose guess is consumed"""
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
     T = np.array([0, 0, 0, 1, 0, 0, 0], np.float64) if T0 is None else _d(T0, 7).copy(); inl = np.zeros(max(len(xyz), 1), np.uint8); it = C.c_int()

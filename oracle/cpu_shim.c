@@ -39,13 +39,16 @@ void vslam_default_params(vslam_params* p) { /* the reference's constants, same 
     p->cam[0] = 718.856; p->cam[1] = 718.856; p->cam[2] = 607.1928; p->cam[3] = 185.2157; p->cam[4] = 0.573;
     p->depth_min = 10; p->depth_max = 400; p->depth_reliable = 40;
     p->match_ratio = 2.0; p->match_gap_thr = 30.0; p->huber_delta = 5.991; p->pnp_reproj_thr = 4.0; p->stereo_row_tol = 2.0;
+    p->struct_size = (int32_t)sizeof(vslam_params); p->abi_version = VSLAM_ABI_VERSION;
 }
+int vslam_abi_version(void) { return VSLAM_ABI_VERSION; }
 const char* vslam_last_error(void) { return g_err; }
 const char* vslam_version(void) { return "vslam CPU oracle shim (test infrastructure)"; }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
     (void)device; (void)stream;
     if (!p || !out) { set_error("null argument"); return VSLAM_ERR_ARG; }
+    if (p->struct_size != (int32_t)sizeof(vslam_params) || p->abi_version != VSLAM_ABI_VERSION) { set_error("vslam_params from a different ABI"); return VSLAM_ERR_ARG; }
     /* the oracle hard-codes the constants the reference hard-codes; refuse configurations it cannot honour */
     if (p->fast_threshold != 20 || p->depth_min != 10 || p->depth_max != 400 || p->depth_reliable != 40 || p->match_ratio != 2.0 ||
         p->match_gap_thr != 30.0) { set_error("CPU shim: only the reference's constants are supported"); return VSLAM_ERR_ARG; }

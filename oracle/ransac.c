@@ -12,13 +12,15 @@
  *     ((u - u')^2 + (v - v')^2 on Point2f / Matx21f) and compared with (float)(4.0 * 4.0); a model replaces the best one only
  *     when it has strictly more inliers than max(best, modelPoints - 1), then niters = RANSACUpdateNumIters(...);
  *   - count == modelPoints: the single model, every point an inlier;
- *   - on success the pose is refined on the inliers of the best model; the returned mask is the RANSAC mask.
+ *   - on success the returned mask is the RANSAC mask; the returned pose is the best RANSAC model (lm_iters = 0, OpenCV 3.2.0) or
+ *     that model refined on its inliers (lm_iters > 0, OpenCV 3.4.2+), see R2.
  * Remaining documented deviations (the GPU path makes the same ones, so GPU-vs-oracle parity is exact up to floating point):
  *   R2  final refinement: OpenCV runs solvePnP(ITERATIVE) on the inliers -- a DLT / homography start followed by CvLevMarq
  *       (<= 20 iterations, plain L2); here the same least-squares cost is minimised by the package's LM from the best RANSAC
  *       model (both stop at the same local minimum of the reprojection error; OpenCV's stopping rule is not restated).
- *       (Whether 3.2.0 returns this refined pose or the RANSAC model itself differs between 3.x point releases; the refined
- *       pose is what 3.3+ return and what is returned here.)
+ *       Which pose is RETURNED differs between 3.x point releases: 3.2.0 (the reference's pinned version) runs the refinement and
+ *       then assigns `_local_model` -- the unrefined best RANSAC model -- to rvec / tvec; 3.4.2+ return the refined pose.  lm_iters = 0
+ *       selects the former (the host mirror's default), lm_iters > 0 the latter.
  *   R3' the hypothesis rotation goes R -> rvec -> R through cv::Rodrigues in OpenCV (model = [rvec | tvec]); here R is used
  *       as EPnP returns it (a 1e-16 effect).
  *   SVD: see epnp.c (OpenCV's basis for the 2-dimensional null space of the 5-point system is not reproducible).
@@ -135,7 +137,9 @@ int vo_pnp_ransac(const float* xyz_w, const float* uv, int n, const double K[4],
         for (int i = 0; i < n; ++i) if (best_mask[i]) { memcpy(ix + 3 * m, xyz_w + 3 * i, 12); memcpy(iu + 2 * m, uv + 2 * i, 8); ++m; }
         double best_T[7];
         pose_from_Rt(best_R, best_t, best_T);
-        vo_pnp_motion_only(ix, iu, m, K, best_T, lm_iters, 1e300, reproj_err, NULL, NULL); /* R2 */
+        /* lm_iters = 0: the best RANSAC model itself -- OpenCV 3.2.0 assigns `_local_model` to rvec / tvec after (and regardless of) the
+         * refinement; lm_iters > 0: the refined pose (3.4.2+), deviation R2 */
+        if (lm_iters > 0) vo_pnp_motion_only(ix, iu, m, K, best_T, lm_iters, 1e300, reproj_err, NULL, NULL);
         memcpy(T_c_w, best_T, sizeof(best_T));
         if (inlier) memcpy(inlier, best_mask, (size_t)n);
         free(ix); free(iu);

@@ -31,7 +31,11 @@ class Params(C.Structure):
                 ("anms_num", C.c_int32), ("fast_threshold", C.c_int32), ("kp_capacity", C.c_int32),
                 ("cam", C.c_double * 5), ("depth_min", C.c_double), ("depth_max", C.c_double),
                 ("depth_reliable", C.c_double), ("match_ratio", C.c_double), ("match_gap_thr", C.c_double),
-                ("huber_delta", C.c_double), ("pnp_reproj_thr", C.c_double), ("stereo_row_tol", C.c_double)]
+                ("huber_delta", C.c_double), ("pnp_reproj_thr", C.c_double), ("stereo_row_tol", C.c_double),
+                ("struct_size", C.c_int32), ("abi_version", C.c_int32)]
+
+
+ABI_VERSION = 3  # VSLAM_ABI_VERSION of include/vslam_hip.h this binding was written against
 
 
 class LmStats(C.Structure):
@@ -63,6 +67,7 @@ ABI_SYMBOLS = [
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
     "vslam_profile_enable", "vslam_profile_read", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
+    "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant",
 ]
 
 
@@ -110,6 +115,18 @@ def load_library():
     lib.vslam_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.vslam_destroy.argtypes = [C.c_void_p]
     lib.vslam_sync.argtypes = [C.c_void_p]
+    if not hasattr(lib, "vslam_abi_version") or lib.vslam_abi_version() != ABI_VERSION:
+        raise VslamError("libvslam_hip.so was built from a different ABI revision than this binding (%s vs %d): rebuild it"
+                         % (lib.vslam_abi_version() if hasattr(lib, "vslam_abi_version") else "pre-3", ABI_VERSION))
+    # positional signatures that changed between ABI revisions get explicit argtypes: a stale call site fails in ctypes, not in the kernel
+    vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+    lib.vslam_local_ba.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.vslam_pose_only_window.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.vslam_ba_batch_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32]
+    lib.vslam_pnp_ransac.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, i32, vp, vp, vp]
+    lib.vslam_pnp_ransac_models.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, i32, vp, vp, vp, vp, vp]
+    lib.vslam_feature_matching_dev.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp, vp, i32, i32, i32, vp, i32, vp]
+    lib.vslam_hbm_copy_probe_variant.argtypes = [vp, C.c_size_t, i32, i32, vp, vp]
     _lib = lib
     return lib
 
@@ -289,9 +306,10 @@ class VO:
                                                        int(match_cap), int(B), _p(d_uvQ), _p(d_uvT)), "vslam_gather_matched_uv_dev")
 
     # ------------------------------------------------------------ VO::motion_estimation (north_star motion-only stage)
-    def motion_estimation_ransac(self, xyz_w, uv, T_init=None, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+    def motion_estimation_ransac(self, xyz_w, uv, T_init=None, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=0):
         """VO::motion_estimation's pose stage (cv::solvePnPRansac(..., false, 100, 4.0, 0.99), visual_odometry.cpp:277): EPnP per
         5-point hypothesis, no pose guess is consumed (T_init only pre-fills the output, which stays untouched on failure).
+        lm_iters = 0: the best RANSAC model itself (OpenCV 3.2.0, the reference's pinned version); > 0: refined on the inliers (3.4.2+).
         Returns (T, inlier mask, n_inliers, iterations evaluated); n_inliers == 0 means no model was found."""
         xyz = np.ascontiguousarray(xyz_w, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
         T = np.array([0, 0, 0, 1, 0, 0, 0], np.float64) if T_init is None else np.ascontiguousarray(T_init, np.float64).copy(); n = len(xyz)
@@ -300,7 +318,7 @@ class VO:
                                             int(lm_iters), _p(inl), C.byref(ni), C.byref(it)), "vslam_pnp_ransac")
         return T, inl[:n], ni.value, it.value
 
-    def motion_estimation_ransac_models(self, xyz_w, uv, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=10):
+    def motion_estimation_ransac_models(self, xyz_w, uv, max_iters=100, reproj_err=4.0, confidence=0.99, lm_iters=0):
         """diagnostic form: (T, mask, n_inliers, iterations, models (max_iters, 12) [R | t], counts (max_iters,))"""
         xyz = np.ascontiguousarray(xyz_w, np.float32).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
         T = np.array([0, 0, 0, 1, 0, 0, 0], np.float64); n = len(xyz)
@@ -378,6 +396,16 @@ class VO:
         g = C.c_double()
         self._chk(self.lib.vslam_hbm_copy_probe(self.h, C.c_size_t(nbytes), int(reps), C.byref(g)), "vslam_hbm_copy_probe")
         return g.value
+
+    def hbm_copy_probe_best(self, nbytes=1 << 30, reps=5):
+        """every shape of the streaming copy (csrc/geom_kernels.hip): {"gbs": best GB/s, "variant": its description, "all": {name: GB/s}}"""
+        res = {}
+        for v in range(self.lib.vslam_hbm_copy_probe_variants()):
+            g = C.c_double(); name = C.create_string_buffer(64)
+            self._chk(self.lib.vslam_hbm_copy_probe_variant(self.h, C.c_size_t(nbytes), int(reps), v, C.byref(g), name), "vslam_hbm_copy_probe_variant")
+            res[name.value.decode()] = round(g.value, 1)
+        best = max(res, key=res.get)
+        return {"gbs": res[best], "variant": best, "bytes": int(nbytes), "all": res}
 
     def ba_status(self, n_windows):
         st = np.zeros(n_windows, np.int32)

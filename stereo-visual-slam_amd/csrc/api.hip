@@ -153,14 +153,18 @@ void vslam_default_params(vslam_params* p) {
     p->cam[0] = 718.856; p->cam[1] = 718.856; p->cam[2] = 607.1928; p->cam[3] = 185.2157; p->cam[4] = 0.573;
     p->depth_min = 10; p->depth_max = 400; p->depth_reliable = 40;
     p->match_ratio = 2.0; p->match_gap_thr = 30.0; p->huber_delta = 5.991; p->pnp_reproj_thr = 4.0; p->stereo_row_tol = 2.0;
+    p->struct_size = (int32_t)sizeof(vslam_params); p->abi_version = VSLAM_ABI_VERSION;
 }
 
 const char* vslam_last_error(void) { return g_err; }
-const char* vslam_version(void) { return "vslam_hip 0.1 (gfx950)"; }
-const char* vslam_kernel_names(void) {
-    return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_blur_kernel orb_describe_kernel match_train_nearest_kernel "
-           "match_finalize_kernel sgbm_prefilter_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel sgbm_lrcheck_kernel "
-           "sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel sgbm_ccl_apply_kernel triangulate_kernel find3d_disparity_kernel gather_uv_kernel lm_window_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel";
+const char* vslam_version(void) { return "vslam_hip 0.3 (gfx950, ABI 3)"; }
+int vslam_abi_version(void) { return VSLAM_ABI_VERSION; }
+const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tests/test_abi.py checks the list against the sources)
+    return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_orient_kernel orb_blur_kernel orb_describe_kernel "
+           "match_train_nearest_kernel match_finalize_kernel sgbm_prefilter_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel "
+           "sgbm_wta_kernel sgbm_lrcheck_kernel sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel "
+           "sgbm_ccl_apply_kernel sgbm_ccl_kernels triangulate_kernel find3d_disparity_kernel gather_uv_kernel build_pnp_inputs_kernel lm_window_kernel "
+           "lm_window_kernel<pnp> pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel";
 }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
@@ -169,6 +173,11 @@ int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** ou
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libvslam_hip has no CPU path)"); return VSLAM_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return VSLAM_ERR_ARG; }
+    if (p->struct_size != (int32_t)sizeof(vslam_params) || p->abi_version != VSLAM_ABI_VERSION) {
+        set_error("vslam_params from a different ABI (struct_size %d / abi_version %d, library has %d / %d): rebuild the caller against include/vslam_hip.h and "
+                  "fill the struct with vslam_default_params", p->struct_size, p->abi_version, (int)sizeof(vslam_params), VSLAM_ABI_VERSION);
+        return VSLAM_ERR_ARG;
+    }
     if (p->max_batch <= 0 || p->kp_capacity < 64 || p->kp_capacity > kMaxRows || p->orb_nfeatures <= 0) { set_error("bad params (max_batch>0, 64<=kp_capacity<=%d)", kMaxRows); return VSLAM_ERR_ARG; }
     VS_HIP(hipSetDevice(device));
     Ctx* c = new Ctx();
@@ -383,6 +392,10 @@ int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stri
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !d_q || !d_t || !d_nq || !d_nt || !d_gap || !d_out || !d_nout || out_capacity <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if (B > c->p.max_batch) { set_error("batch %d exceeds context max_batch %d", B, c->p.max_batch); return VSLAM_ERR_ARG; }
+    if ((((uintptr_t)d_q | (uintptr_t)d_t | (uintptr_t)q_stride_bytes | (uintptr_t)t_stride_bytes) & 15) != 0) {
+        set_error("vslam_feature_matching_dev: d_q, d_t and both strides must be multiples of 16 bytes (the matcher reads descriptors with 16-byte loads)");
+        return VSLAM_ERR_ARG;
+    }
     VS_ENTER(c);
     return launch_match(d_q, q_stride_bytes, d_nq, d_t, t_stride_bytes, d_nt, d_gap, gate, c->p.match_ratio, c->p.match_gap_thr, B, max_rows,
                         c->match.d_train_best, d_out, out_capacity, d_nout, c->stream);
@@ -684,7 +697,7 @@ static int pnp_ransac_impl(vslam_ctx* ctx, const float* xyz_w, const float* uv, 
     }
     if (iters_run) *iters_run = it;
     if (best < 0) return VSLAM_OK;
-    // 4. mask of the best model, refinement on its inliers (solvePnP on the inliers; deviation R2 of oracle/ransac.c)
+    // 4. mask of the best model; lm_iters > 0: refinement on its inliers (solvePnP on the inliers; deviation R2 of oracle/ransac.c)
     std::vector<uint8_t> mask(n, 1);
     if (!single) {
         if ((rc = launch_pnp_count_inliers(d_x, d_u, n, d_Rt, d_ok, best, 1, K, reproj_err, nullptr, d_mask, c->stream))) return rc;
@@ -695,6 +708,13 @@ static int pnp_ransac_impl(vslam_ctx* ctx, const float* xyz_w, const float* uv, 
     for (int i = 0; i < n; ++i) if (mask[i]) { ix.insert(ix.end(), xyz_w + 3 * (size_t)i, xyz_w + 3 * (size_t)i + 3); iu.insert(iu.end(), uv + 2 * (size_t)i, uv + 2 * (size_t)i + 2); }
     const int m = (int)(iu.size() / 2);
     if (m != max_good) { set_error("RANSAC inlier recount mismatch (%d vs %d)", m, max_good); return VSLAM_ERR_HIP; }
+    if (lm_iters <= 0) { // OpenCV 3.2.0: solvePnPRansac assigns _local_model (the best RANSAC model) to rvec / tvec; the refined pose is discarded
+        VS_HIP(hipMemcpyAsync(T_c_w, d_hT + 7 * (size_t)best, 56, hipMemcpyDeviceToHost, c->stream));
+        VS_HIP(hipStreamSynchronize(c->stream));
+        if (inlier) memcpy(inlier, mask.data(), n);
+        if (n_inliers) *n_inliers = max_good;
+        return VSLAM_OK;
+    }
     VS_HIP(hipMemcpyAsync(d_ix, ix.data(), ix.size() * 4, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_iu, iu.data(), iu.size() * 4, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_T, d_hT + 7 * (size_t)best, 56, hipMemcpyDeviceToDevice, c->stream));
@@ -890,9 +910,11 @@ int vslam_build_pnp_inputs_dev(vslam_ctx* ctx, const vslam_dmatch* d_f2f, const 
 
 // float4 streaming copy of `bytes` (src -> dst, both allocated here), `reps` timed launches after one warm-up, hipEvents on the
 // context stream: *gbs_out = (bytes read + bytes written) / time.  The achievable-HBM figure bench.py reports next to the spec peak.
-int vslam_hbm_copy_probe(vslam_ctx* ctx, size_t bytes, int reps, double* gbs_out) {
+int vslam_hbm_copy_probe_variants(void) { return hbm_copy_probe_variants(); }
+
+int vslam_hbm_copy_probe_variant(vslam_ctx* ctx, size_t bytes, int reps, int variant, double* gbs_out, char* name_out) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    if (!c || !gbs_out || bytes < (1u << 20) || reps <= 0) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if (!c || !gbs_out || bytes < (1u << 20) || reps <= 0 || variant < 0 || variant >= hbm_copy_probe_variants()) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     VS_ENTER(c);
     bytes &= ~(size_t)15;
     void *a = nullptr, *b = nullptr;
@@ -903,18 +925,32 @@ int vslam_hbm_copy_probe(vslam_ctx* ctx, size_t bytes, int reps, double* gbs_out
         set_error("copy probe: allocation failed"); rc = VSLAM_ERR_HIP;
     } else {
         (void)hipMemsetAsync(a, 1, bytes, c->stream);
-        rc = launch_hbm_copy_probe(a, b, bytes, c->stream);
+        rc = launch_hbm_copy_probe(a, b, bytes, variant, c->stream);
         (void)hipEventRecord(e0, c->stream);
-        for (int r = 0; r < reps && rc == VSLAM_OK; ++r) rc = launch_hbm_copy_probe(a, b, bytes, c->stream);
+        for (int r = 0; r < reps && rc == VSLAM_OK; ++r) rc = launch_hbm_copy_probe(a, b, bytes, variant, c->stream);
         (void)hipEventRecord(e1, c->stream);
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { set_error("copy probe: timing failed"); rc = VSLAM_ERR_HIP; }
     }
     if (rc == VSLAM_OK) *gbs_out = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+    if (rc == VSLAM_OK && name_out) { strncpy(name_out, hbm_copy_probe_name(variant), 63); name_out[63] = 0; }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     return rc;
+}
+
+int vslam_hbm_copy_probe(vslam_ctx* ctx, size_t bytes, int reps, double* gbs_out) { // best of the variants
+    if (!gbs_out) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    double best = 0.0;
+    for (int v = 0; v < hbm_copy_probe_variants(); ++v) {
+        double g = 0.0;
+        const int rc = vslam_hbm_copy_probe_variant(ctx, bytes, reps, v, &g, nullptr);
+        if (rc != VSLAM_OK) return rc;
+        if (g > best) best = g;
+    }
+    *gbs_out = best;
+    return VSLAM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- raw device memory helpers

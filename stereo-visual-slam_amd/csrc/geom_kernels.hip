@@ -217,19 +217,52 @@ int launch_gather_uv(const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT,
     return VSLAM_OK;
 }
 
-// ---- measurement aid: what a plain streaming copy reaches on this box (the achievable HBM ceiling next to the 8 TB/s spec)
-__global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) { // four independent 16-B loads in flight per lane before the first store
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+// ---- measurement aid: what a plain streaming copy reaches on this box (the achievable HBM ceiling next to the 8 TB/s spec).
+// Several shapes of the same 16-B-per-lane copy; bench.py reports the best one and its name.  A workgroup owns contiguous
+// 256 x U x 16 B chunks (grid-stride over chunks), issues its U independent loads before the first store; NT = non-temporal
+// loads and stores (the copy has no reuse, so it should not displace L2 / Infinity Cache lines).
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst, size_t n) {
+    const size_t chunk = (size_t)256 * U, nchunks = n / chunk;
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const size_t base = c * chunk + threadIdx.x;
+        v4f r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = NT ? __builtin_nontemporal_load(src + base + (size_t)u * 256) : src[base + (size_t)u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NT) __builtin_nontemporal_store(r[u], dst + base + (size_t)u * 256);
+            else dst[base + (size_t)u * 256] = r[u];
+        }
     }
-    for (; i < n; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0)
+        for (size_t i = nchunks * chunk + threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
-int launch_hbm_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t stream) {
+struct CopyVariant { const char* name; int U; bool nt; int wg_per_cu; };
+static const CopyVariant kCopyVariants[] = {
+    {"U4 plain, 8 WG/CU", 4, false, 8},        {"U8 plain, 8 WG/CU", 8, false, 8},   {"U8 nontemporal, 8 WG/CU", 8, true, 8},
+    {"U8 nontemporal, 16 WG/CU", 8, true, 16}, {"U8 nontemporal, 32 WG/CU", 8, true, 32}, {"U16 nontemporal, 8 WG/CU", 16, true, 8},
+    {"U4 nontemporal, one chunk per WG", 4, true, 0}, {"U8 plain, one chunk per WG", 8, false, 0},
+};
+int hbm_copy_probe_variants() { return (int)(sizeof(kCopyVariants) / sizeof(kCopyVariants[0])); }
+const char* hbm_copy_probe_name(int v) { return (v >= 0 && v < hbm_copy_probe_variants()) ? kCopyVariants[v].name : ""; }
+int launch_hbm_copy_probe(const void* src, void* dst, size_t bytes, int variant, hipStream_t stream) {
+    if (variant < 0 || variant >= hbm_copy_probe_variants()) return VSLAM_ERR_ARG;
+    const CopyVariant& cv = kCopyVariants[variant];
     const size_t n = bytes / 16;
-    hipLaunchKernelGGL(hbm_copy_probe_kernel, dim3(256 * 8), dim3(256), 0, stream, (const float4*)src, (float4*)dst, n);
+    const size_t nchunks = n / ((size_t)256 * cv.U);
+    size_t grid = cv.wg_per_cu > 0 ? (size_t)256 * cv.wg_per_cu : nchunks;
+    if (grid > nchunks) grid = nchunks;
+    if (grid < 1) grid = 1;
+    const v4f* s = (const v4f*)src; v4f* d = (v4f*)dst;
+#define VS_COPY(UU, NTT) hipLaunchKernelGGL((hbm_copy_probe_kernel<UU, NTT>), dim3((unsigned)grid), dim3(256), 0, stream, s, d, n)
+    if (cv.U == 4 && !cv.nt) VS_COPY(4, false);
+    else if (cv.U == 4) VS_COPY(4, true);
+    else if (cv.U == 8 && !cv.nt) VS_COPY(8, false);
+    else if (cv.U == 8) VS_COPY(8, true);
+    else VS_COPY(16, true);
+#undef VS_COPY
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }

@@ -143,7 +143,9 @@ int launch_build_pnp_inputs(const vslam_dmatch* d_m, const int32_t* d_nm, int ma
 int launch_gather_uv(const vslam_keypoint* d_kpsQ, const vslam_keypoint* d_kpsT, int kp_capacity, const vslam_dmatch* d_m,
                      const int32_t* d_nm, int match_capacity, int B, float* d_uvQ, float* d_uvT, hipStream_t stream);
 
-int launch_hbm_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t stream);
+int launch_hbm_copy_probe(const void* src, void* dst, size_t bytes, int variant, hipStream_t stream);
+int hbm_copy_probe_variants();
+const char* hbm_copy_probe_name(int variant);
 
 // ----------------------------------------------------------------------------------------------- LM
 struct LmWindowArgs {

@@ -115,4 +115,24 @@ void optimize_pose_only(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>
     run(ctx, keyframes, landmarks, K, true, if_update_map, false, num_ite, q1_quirk);
 }
 
+namespace {
+vslam_ctx* g_backend_ctx = nullptr;
+bool g_backend_q1 = true;
+} // namespace
+
+void set_optimizer_backend(vslam_ctx* ctx, bool q1_quirk) { g_backend_ctx = ctx; g_backend_q1 = q1_quirk; }
+vslam_ctx* optimizer_backend() { return g_backend_ctx; }
+
+void optimize_map(std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks, const Mat33& K,
+                  bool if_update_map, bool if_update_landmark, int num_ite) {
+    if (!g_backend_ctx) throw std::runtime_error("optimize_map: no optimiser backend (construct a VO or call set_optimizer_backend first)");
+    run(g_backend_ctx, keyframes, landmarks, K, false, if_update_map, if_update_landmark, num_ite, g_backend_q1);
+}
+
+void optimize_pose_only(std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks, const Mat33& K,
+                        bool if_update_map, int num_ite) {
+    if (!g_backend_ctx) throw std::runtime_error("optimize_pose_only: no optimiser backend (construct a VO or call set_optimizer_backend first)");
+    run(g_backend_ctx, keyframes, landmarks, K, true, if_update_map, false, num_ite, g_backend_q1);
+}
+
 } // namespace vslam

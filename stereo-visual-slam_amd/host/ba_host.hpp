@@ -17,4 +17,15 @@ void optimize_map(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>& keyf
 void optimize_pose_only(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks,
                         const Mat33& K, bool if_update_map, int num_ite, bool q1_quirk = true);
 
+
+// The reference's exact signatures (optimization.hpp:137-139, :150-152): no context, no quirk switch.  They run on the process-level
+// backend below, which VO's constructor sets to its own context (the reference's optimisers are free functions with no state either;
+// the GPU context is this build's only addition and lives behind this accessor).
+void set_optimizer_backend(vslam_ctx* ctx, bool q1_quirk = true);
+vslam_ctx* optimizer_backend();
+void optimize_map(std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks, const Mat33& K,
+                  bool if_update_map, bool if_update_landmark, int num_ite);
+void optimize_pose_only(std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks, const Mat33& K,
+                        bool if_update_map, int num_ite);
+
 } // namespace vslam

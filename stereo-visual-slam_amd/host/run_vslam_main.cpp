@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
     std::remove(traj.c_str());
     vslam::Map my_map(if_write_pose, traj);
     vslam::VO my_VO(dataset, ctx, my_map);
+    vslam::set_optimizer_backend(ctx, q1); // VO's constructor already bound ctx; the Q1 switch is this driver's option
     my_VO.depth_source_ = sgbm ? vslam::DepthSGBM : vslam::DepthStereoMatch;
     my_VO.pnp_mode_ = ransac ? vslam::PnpRansac : vslam::PnpMotionOnlyLM;
     // run_vslam.cpp:34-38: K and the baseline are constants of the node (the same numbers Frame carries, types_def.hpp:53-54)
@@ -67,10 +68,11 @@ int main(int argc, char** argv) {
             std::fprintf(trace, "\n");
         }
         if (if_insert_keyframe && my_map.keyframes_.size() >= 10) { // :58-71
-            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, K, false, false, 5, q1);
-            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, K, false, false, 5, q1);
-            vslam::optimize_map(ctx, my_map.keyframes_, my_map.landmarks_, K, true, false, 10, q1);
-            vslam::optimize_pose_only(ctx, my_map.keyframes_, my_map.landmarks_, K, true, 10, q1);
+            // reject the outliers, then do the optimization; then pose only -- the four calls exactly as run_vslam.cpp:61-70 spells them
+            vslam::optimize_map(my_map.keyframes_, my_map.landmarks_, K, false, false, 5);
+            vslam::optimize_map(my_map.keyframes_, my_map.landmarks_, K, false, false, 5);
+            vslam::optimize_map(my_map.keyframes_, my_map.landmarks_, K, true, false, 10);
+            vslam::optimize_pose_only(my_map.keyframes_, my_map.landmarks_, K, true, 10);
             ++n_ba;
             if (trace) {
                 size_t n_in = 0;

@@ -2,6 +2,7 @@
 // (/root/reference/src/stereo_visual_slam_main/visual_odometry.cpp:348-432, :491-706), re-implemented over the C-ABI.
 // Host code stays on the CPU: it is O(N) association and policy; the kernels do the arithmetic.
 #include "vo_host.hpp"
+#include "ba_host.hpp"
 
 #include <zlib.h>
 
@@ -120,6 +121,12 @@ int ImageSource::read(int id, Image& left, Image& right) const {
 }
 
 // ---------------------------------------------------------------------------------------------- kernels behind methods
+// visual_odometry.hpp:69 `VO(std::string dataset, ros::NodeHandle&, Map&)`: the node handle's place is taken by the GPU context, which also
+// becomes the backend of the free optimize_map / optimize_pose_only functions (ba_host.hpp)
+VO::VO(std::string dataset, vslam_ctx* ctx, Map& map) : my_map_(map), source_(std::move(dataset)), ctx_(ctx) {
+    if (!optimizer_backend()) set_optimizer_backend(ctx);
+}
+
 int VO::feature_detection(const Image& img, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors) {
     if (img.empty()) { std::cout << "Could not open or find the image" << std::endl; return -1; } // :73-77
     const int cap = 4096;
@@ -222,7 +229,7 @@ void VO::motion_estimation(Frame& frame) {
     if (rows.size() >= 4) {
         int n_in = 0;
         if (pnp_mode_ == PnpRansac) // the reference's call: solvePnPRansac(..., false, 100, 4.0, 0.99, inliers) (:277)
-            check(vslam_pnp_ransac(ctx_, pts3d.data(), pts2d.data(), (int)rows.size(), T.data(), 100, 4.0, 0.99, pnp_iterations_, inlier.data(), &n_in, nullptr), "motion_estimation (RANSAC)");
+            check(vslam_pnp_ransac(ctx_, pts3d.data(), pts2d.data(), (int)rows.size(), T.data(), 100, 4.0, 0.99, ransac_refine_iterations_, inlier.data(), &n_in, nullptr), "motion_estimation (RANSAC)");
         else
             check(vslam_pnp_motion_only(ctx_, pts3d.data(), pts2d.data(), (int)rows.size(), T.data(), pnp_iterations_, inlier.data(), &n_in, nullptr), "motion_estimation");
         num_inliers_ = n_in;

@@ -41,14 +41,16 @@ public:
     int num_lost_ = 0;
     int curr_keyframe_id_ = 0;
     int curr_landmark_id_ = 0;
-    int pnp_iterations_ = 10;
+    int pnp_iterations_ = 10;         // motion-only LM stage (PnpMotionOnlyLM)
+    int ransac_refine_iterations_ = 0; // PnpRansac: 0 = return the best RANSAC model itself, as OpenCV 3.2.0's solvePnPRansac does (it computes the refined
+                                       // pose and then assigns _local_model, solvepnp.cpp); > 0 = return the pose refined on the inliers (3.4.2+ behaviour)
     DepthSource depth_source_ = DepthSGBM;   // the reference's algorithm by default (visual_odometry.cpp:159-217, :277)
     PnpMode pnp_mode_ = PnpRansac;
     // diagnostics of the latest tracking() call, for the CPU-path vs GPU-path trace comparison (not in the reference)
     int last_num_detected_ = 0, last_num_matches_ = 0;
     uint64_t last_match_hash_ = 0; // FNV-1a over (queryIdx, trainIdx, distance) of the gated frame-to-frame matches
 
-    VO(std::string dataset, vslam_ctx* ctx, Map& map) : my_map_(map), source_(std::move(dataset)), ctx_(ctx) {}
+    VO(std::string dataset, vslam_ctx* ctx, Map& map);
 
     int read_img(int id, Image& left_img, Image& right_img) { return source_.read(id, left_img, right_img); }
     int feature_detection(const Image& img, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors);

@@ -20,7 +20,7 @@ from . import synth
 
 class KeyframePipeline:
     def __init__(self, B, device=0, anms_num=1500, n_lm=3000, n_kf=10, unique_frames=64, unique_windows=None, seed=0, verbose=False,
-                 with_ba=True, depth="match", frame_range=None):
+                 with_ba=True, depth="match", frame_range=None, render_workers=0, sequence=None):
         """depth = "match": north_star stage (right-image ORB, L/R match, DLT); "sgbm": the reference's own depth path
         (VO::disparity_map + Frame::find_3d on the left keypoints; the right image is only consumed by SGBM).
         Inputs: ONE rendered sequence of `unique_frames` consecutive stereo keyframes, laid over the batch as a ping-pong
@@ -47,7 +47,9 @@ class KeyframePipeline:
         # ---- inputs: 2B images [left 0..B-1 | right 0..B-1]; consecutive keyframes of `unique_scenes` short sequences
         imgs = np.zeros((2 * B, self.h, self.pitch), np.uint8)
         n_u = max(2, min(unique_frames, B if frame_range is None else int(frame_range[2]))) if (B > 1 or frame_range is not None) else 1
-        seq = synth.stereo_sequence(n_u, seed=seed, w=self.w, h=self.h)
+        # `sequence`: an already rendered synth.stereo_sequence(n_u, seed) (tests that build several pipelines over the same frames)
+        seq = sequence if sequence is not None else synth.stereo_sequence(n_u, seed=seed, w=self.w, h=self.h, workers=render_workers)
+        assert len(seq) == n_u, (len(seq), n_u)
         if verbose:
             print("rendered %d stereo keyframes" % n_u, flush=True)
         period = max(2 * (n_u - 1), 1)

@@ -186,14 +186,41 @@ def trajectory(n_frames, seed=0):
     return out
 
 
-def stereo_sequence(n_frames, seed=0, w=W_KITTI, h=H_KITTI):
-    """list of (left u8, right u8, T_c_w, depth_left).  Walls are spread over the whole path (about 1 m per frame) so that
-    the last frames still see structure within the 10-40 m reliable-depth range (visual_odometry.cpp:194,201)."""
+def _sequence_scene(n_frames, seed):
     traj = trajectory(n_frames, seed)
     centres = np.array([-R_from_quat(T[:4]).T @ T[4:] for T in traj])
     far = centres[-1] + 200.0 * (R_from_quat(traj[-1][:4]).T @ np.array([0, 0, 1.0]))  # the last heading extended beyond the walls
     path = np.vstack([centres[:, [0, 2]], far[[0, 2]]])
-    sc = Scene(seed, n_walls=10 + n_frames // 2, z_far=80.0 + 1.2 * n_frames, antialias=True, path=path)
+    return traj, Scene(seed, n_walls=10 + n_frames // 2, z_far=80.0 + 1.2 * n_frames, antialias=True, path=path)
+
+
+def _render_frames(job):
+    """pool worker of stereo_sequence: frames `idx` of the (n_frames, seed) sequence; every frame depends only on the scene and its pose"""
+    n_frames, seed, w, h, idx = job
+    traj, sc = _sequence_scene(n_frames, seed)
+    out = []
+    for i in idx:
+        L, depth = sc.render(traj[i], w, h)
+        Rr, _ = sc.render(traj[i], w, h, x_offset=BASELINE)
+        out.append((i, L, Rr, depth))
+    return out
+
+
+def stereo_sequence(n_frames, seed=0, w=W_KITTI, h=H_KITTI, workers=0):
+    """list of (left u8, right u8, T_c_w, depth_left).  Walls are spread over the whole path (about 1 m per frame) so that
+    the last frames still see structure within the 10-40 m reliable-depth range (visual_odometry.cpp:194,201).
+    workers > 1: the frames are rendered by a pool of spawned processes (numpy only); the result does not depend on it."""
+    traj, sc = _sequence_scene(n_frames, seed)
+    workers = int(min(workers, n_frames))
+    if workers > 1:
+        import multiprocessing as mp
+        jobs = [(n_frames, seed, w, h, list(range(k, n_frames, 4 * workers))) for k in range(min(4 * workers, n_frames))]
+        frames = [None] * n_frames
+        with mp.get_context("spawn").Pool(workers) as pool:
+            for part in pool.imap_unordered(_render_frames, jobs):
+                for i, L, Rr, depth in part:
+                    frames[i] = (L, Rr, traj[i], depth)
+        return frames
     out = []
     for T in traj:
         L, depth = sc.render(T, w, h)

@@ -1,32 +1,25 @@
 #!/usr/bin/env python3
-"""Randomised GPU-vs-oracle parity sweep (not part of pytest: minutes of runtime).  Sizes and seeds are drawn at random;
-any mismatch prints the reproducer and exits non-zero.  usage: python tests/fuzz_parity.py [--seconds 120] [--seed 0]"""
+"""Randomised GPU-vs-oracle parity sweep.  Sizes and seeds are drawn at random; any mismatch reports the reproducer.
+Stand-alone (minutes): python tests/fuzz_parity.py [--seconds 120] [--seed 0] [--only kind]; a fixed-seed slice of it runs inside
+`pytest -m gpu` (tests/test_gpu_fuzz.py)."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import oracle as O
-import stereo_visual_slam_amd as pkg
-from stereo_visual_slam_amd import synth
 
-ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--only", default="")
-a = ap.parse_args()
-O.build()
-rng = np.random.default_rng(a.seed)
-vo = pkg.VO(device=0, max_batch=2)
-t_end = time.time() + a.seconds
-n = dict(match=0, sgbm=0, orb=0, ba=0, pnp=0, ransac=0)
+KINDS = ["match", "sgbm", "orb", "ba", "pnp", "ransac"]
 
 
-def fail(what, **kw):
-    print("MISMATCH", what, kw); sys.exit(1)
+class Mismatch(AssertionError):
+    pass
 
 
 def kps_equal(x, y):
     return len(x) == len(y) and all(np.array_equal(x[f], y[f]) for f in ("x", "y", "size", "angle", "response", "octave", "class_id"))
 
 
-while time.time() < t_end:
-    kind = a.only or rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac"])
+def one_case(kind, rng, vo, pkg, O, synth):
+    def fail(what, **kw):
+        raise Mismatch("MISMATCH %s %r" % (what, kw))
     seed = int(rng.integers(1 << 30))
     if kind == "match":
         nq, nt = int(rng.integers(1, 2200)), int(rng.integers(1, 2200))
@@ -81,10 +74,43 @@ while time.time() < t_end:
     else:
         M = int(rng.integers(5, 1200))
         p = synth.pnp_problem(M=M, seed=seed, outlier_frac=float(rng.choice([0.0, 0.2, 0.45])), sigma_px=0.4)
-        gT, gi, gn, git = vo.motion_estimation_ransac(p["xyz"], p["uv"], p["T0"])
-        wT, wi, wn, wit = O.pnp_ransac(p["xyz"], p["uv"], p["T0"])
+        lmi = int(rng.choice([0, 10]))   # 0: the RANSAC model itself (OpenCV 3.2.0), 10: refined on the inliers
+        gT, gi, gn, git = vo.motion_estimation_ransac(p["xyz"], p["uv"], p["T0"], lm_iters=lmi)
+        wT, wi, wn, wit = O.pnp_ransac(p["xyz"], p["uv"], p["T0"], lm_iters=lmi)
         if not (git == wit and gn == wn and np.array_equal(gi, wi) and np.allclose(gT, wT, rtol=1e-4, atol=1e-6)):
             fail("ransac", M=M, seed=seed, got=(gn, git), want=(wn, wit))
-    n[kind] += 1
-print("fuzz ok:", n)
-vo.close()
+
+
+def run(seconds=120.0, seed=0, only="", vo=None, max_cases=None, schedule=None):
+    """returns the per-kind case counts; raises Mismatch with the reproducer on the first difference.  schedule: explicit list of
+    kinds to cycle through (the pytest slice uses it so that every stage gets its share inside a short budget)"""
+    import oracle as O
+    import stereo_visual_slam_amd as pkg
+    from stereo_visual_slam_amd import synth
+    O.build()
+    rng = np.random.default_rng(seed)
+    own = vo is None
+    if own:
+        vo = pkg.VO(device=0, max_batch=2)
+    t_end = time.time() + seconds
+    n = {k: 0 for k in KINDS}
+    i = 0
+    try:
+        while time.time() < t_end and (max_cases is None or i < max_cases):
+            kind = only or (schedule[i % len(schedule)] if schedule else rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac"]))
+            one_case(kind, rng, vo, pkg, O, synth)
+            n[kind] += 1
+            i += 1
+    finally:
+        if own:
+            vo.close()
+    return n
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    try:
+        print("fuzz ok:", run(a.seconds, a.seed, a.only))
+    except Mismatch as e:
+        print(e); sys.exit(1)

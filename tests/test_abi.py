@@ -1,5 +1,6 @@
 """CPU: the C-ABI library builds, loads and exports every symbol include/vslam_hip.h declares; the product has no CPU
 fallback (context creation fails loudly without a GPU) and never touches oracle/."""
+import ctypes
 import os
 import re
 import subprocess
@@ -88,3 +89,25 @@ def test_check_motion_host_scalar(pkg, oracle):
         T = oracle.se3_exp(xi); n = int(rng.integers(0, 25)); gap = float(rng.integers(1, 4))
         got = lib.vslam_check_motion(n, T.ctypes.data_as(C.c_void_p), C.c_double(gap))
         assert bool(got) == oracle.check_motion(n, T, gap)
+
+
+def test_kernel_name_list_covers_every_profiler_bracket():
+    """vslam_kernel_names() is the cross-reference for rocprofv3 / the stage profiler: every ProfScope name in csrc/ must be on it"""
+    import glob
+    import re
+    import stereo_visual_slam_amd as pkg
+    names = set(pkg.load_library().vslam_kernel_names().decode().split())
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "stereo-visual-slam_amd", "csrc", "*.hip")))
+    used = set(re.findall(r'ProfScope \w+\(\w+, "([^"]+)"', src))
+    assert used, "no ProfScope found"
+    missing = [u for u in used if u not in names and re.sub(r"<.*>", "", u) not in names]
+    assert not missing, missing
+
+
+def test_params_abi_guard():
+    """a vslam_params from another header revision is refused before anything is read out of it (positional ABI breaks)"""
+    import stereo_visual_slam_amd as pkg
+    lib = pkg.load_library()
+    assert lib.vslam_abi_version() == pkg.ABI_VERSION
+    p = pkg.default_params()
+    assert p.struct_size == ctypes.sizeof(pkg.Params) and p.abi_version == pkg.ABI_VERSION

@@ -1,0 +1,55 @@
+"""Run-twice determinism of the HIP path: "fixed summation order, no floating-point atomics"  as a test.
+The same device-resident step (ORB on 2 x 4 images, both matchers, DLT, motion-only LM, the BA schedule on 8 windows) is executed
+twice from identical inputs; EVERY output must be identical to the bit, including the f64 poses."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, name):
+    assert a.dtype == b.dtype and a.shape == b.shape, name
+    assert np.array_equal(a.view(np.uint8) if a.dtype.kind == "f" else a, b.view(np.uint8) if b.dtype.kind == "f" else b), name
+
+
+def test_step_twice_bit_identical(synth):
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    pipe = KeyframePipeline(8, device=0, anms_num=1500, n_lm=3000, unique_frames=4, seed=3)
+    try:
+        pipe.step(); a = pipe.download()
+        chi_a = None
+        pipe.step(); b = pipe.download()
+        assert (pipe.vo.orb_status(16) == 0).all() and (pipe.vo.ba_status(8) == 0).all()
+        cnt = a["cnt"]
+        _same(a["cnt"], b["cnt"], "keypoint counts")
+        for i in range(16):   # outputs beyond the count are scratch
+            _same(a["kps"][i][:cnt[i]], b["kps"][i][:cnt[i]], "keypoints %d" % i)
+            _same(a["desc"][i][:cnt[i]], b["desc"][i][:cnt[i]], "descriptors %d" % i)
+        for k in ("nlr", "nf2f", "pn", "ninl", "Tpnp", "ba_T", "ba_inl"):
+            _same(a[k], b[k], k)
+        for i in range(8):
+            _same(a["lr"][i][:a["nlr"][i]], b["lr"][i][:a["nlr"][i]], "L/R matches %d" % i)
+            _same(a["xyz"][i][:a["nlr"][i]], b["xyz"][i][:a["nlr"][i]], "triangulated points %d" % i)
+        for i in range(7):
+            _same(a["f2f"][i][:a["nf2f"][i]], b["f2f"][i][:a["nf2f"][i]], "frame-to-frame matches %d" % i)
+            _same(a["inl"][i][:a["pn"][i]], b["inl"][i][:a["pn"][i]], "PnP inlier flags %d" % i)
+        assert a["cnt"].min() > 500 and a["nlr"].min() > 50
+    finally:
+        pipe.close()
+
+
+def test_ba_window_twice_bit_identical(vo, synth):
+    """host-buffer tier: optimize_map on one window twice (different arena state in between)"""
+    w = synth.ba_window(n_kf=10, n_lm=1200, seed=77)
+    r1 = vo.optimize_map(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], True, True, 10)
+    vo.optimize_pose_only(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], True, 3)
+    r2 = vo.optimize_map(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], True, True, 10)
+    for k in ("T", "xyz", "chi2", "lm_inlier"):
+        assert np.array_equal(r1[k], r2[k]), k
+    assert r1["stats"] == r2["stats"]
+
+
+def test_sgbm_twice_bit_identical(vo, synth):
+    L = synth.noise_image(5, 640, 200); R = np.roll(L, -11, axis=1)
+    a = vo.disparity_map(L, R); b = vo.disparity_map(L, R)
+    assert np.array_equal(a, b)

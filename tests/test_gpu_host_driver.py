@@ -58,3 +58,5 @@ def test_gpu_path_matches_cpu_path(sequence, synth, anms, q1, depth, pnp):
     rows, err = _ground_truth_errors(os.path.join(d, "traj_%s_gpu.txt" % tag), gt, synth)
     assert rows.shape[1] == 13 and len(set(rows[:, 0].astype(int))) == len(rows)
     assert np.median(err) < 0.05 * path_len + 0.2, (err, path_len)
+    if q1 == 0:   # without the Q1 quirk no keyframe pose may be badly off either (the parity above shares the host code and the oracle's choices)
+        assert err.max() < 0.10 * path_len + 0.5, (err.max(), path_len)

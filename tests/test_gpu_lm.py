@@ -102,11 +102,14 @@ def test_pnp_ransac_parity(vo, oracle, synth, M, outl, seed):
     """vslam_pnp_ransac vs oracle/ransac.c: same subset sequence, EPnP per hypothesis (no pose guess), same accepted hypothesis,
     same number of iterations, identical inlier mask (f32 error rule), pose within 1e-4 (cv::solvePnPRansac, visual_odometry.cpp:277)"""
     p = synth.pnp_problem(M=M, seed=seed, outlier_frac=outl, sigma_px=0.4)
-    gT, ginl, gn, git = vo.motion_estimation_ransac(p["xyz"], p["uv"])
-    wT, winl, wn, wit = oracle.pnp_ransac(p["xyz"], p["uv"])
-    assert git == wit and gn == wn
-    assert np.array_equal(ginl, winl)
-    assert np.allclose(gT, wT, rtol=RTOL, atol=1e-7)
+    for lm_iters in (0, 10):   # 0: the best RANSAC model itself (OpenCV 3.2.0, the default); 10: refined on its inliers (3.4.2+)
+        gT, ginl, gn, git = vo.motion_estimation_ransac(p["xyz"], p["uv"], lm_iters=lm_iters)
+        wT, winl, wn, wit = oracle.pnp_ransac(p["xyz"], p["uv"], lm_iters=lm_iters)
+        assert git == wit and gn == wn
+        assert np.array_equal(ginl, winl)
+        assert np.allclose(gT, wT, rtol=RTOL, atol=1e-7)
+        if lm_iters == 0 and gn > 0:
+            assert np.allclose(gT, wT, rtol=1e-12, atol=1e-14)   # no optimiser in between: the hypothesis model, bit-identical up to the quaternion conversion
     if M >= 60:
         assert gn >= (1 - outl) * M * 0.8
 

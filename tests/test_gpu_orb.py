@@ -19,7 +19,10 @@ def images(synth):
     sc = synth.Scene(0)
     T = synth.trajectory(1, 0)[0]
     left, _ = sc.render(T)
-    return [synth.noise_image(0), synth.noise_image(1), left]
+    # + 8 frames of the rendered, anti-aliased driving sequence bench.py uses (left of frames 0, 5, 10, 15, right of 2, 7, 12, 17)
+    seq = synth.stereo_sequence(18, seed=0, workers=8)
+    drive = [seq[i][0] for i in (0, 5, 10, 15)] + [seq[i][1] for i in (2, 7, 12, 17)]
+    return [synth.noise_image(0), synth.noise_image(1), left] + drive
 
 
 def test_orb_detect_parity(vo, oracle, images):

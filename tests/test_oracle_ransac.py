@@ -37,14 +37,22 @@ def test_update_num_iters_closed_form(oracle):
 
 def test_ransac_rejects_gross_outliers_and_stops_early(oracle, synth):
     p = synth.pnp_problem(M=400, seed=9, outlier_frac=0.35, sigma_px=0.4)
-    T, inl, n, iters = oracle.pnp_ransac(p["xyz"], p["uv"], p["T0"])
+    T, inl, n, iters = oracle.pnp_ransac(p["xyz"], p["uv"], p["T0"], lm_iters=10)   # refined on the inliers (OpenCV 3.4.2+)
     truth = ~p["outlier"]
     assert n == inl.sum() and 0.55 * 400 < n < 0.75 * 400
+    # lm_iters = 0 (the default: OpenCV 3.2.0, the reference's pinned version, returns `_local_model`): the accepted 5-point EPnP model itself,
+    # same mask / count / iterations; an algebraic 5-point estimate, so further from the truth than its refinement
+    T0, inl0, n0, iters0 = oracle.pnp_ransac(p["xyz"], p["uv"])
+    assert (n0, iters0) == (n, iters) and np.array_equal(inl0, inl)
+    hyp = [oracle.pnp_ransac_hypothesis(p["xyz"], p["uv"], h) for h in range(iters)]
+    best = max(range(iters), key=lambda h: (hyp[h][1], -h))
+    assert hyp[best][1] == n and np.allclose(T0, hyp[best][0], atol=1e-12)
     assert 1 <= iters < 100                                  # 35 % outliers: the adaptive rule stops before the cap
     # plain (non-robust, non-RANSAC) least squares on the contaminated set lands elsewhere
     Tls, _, _, _ = oracle.pnp_motion_only(p["xyz"], p["uv"], p["T0"], iters=10, huber_delta=1e300)
     ang = lambda A, B: np.linalg.norm(oracle.se3_log(oracle.se3_mul(A, oracle.se3_inv(B))))
     assert ang(T, p["T_true"]) < 0.02 and ang(T, p["T_true"]) < 0.5 * ang(Tls, p["T_true"])
+    assert ang(T, p["T_true"]) < ang(T0, p["T_true"]) < 0.2
     assert (inl.astype(bool) & ~truth).sum() <= 0.03 * 400    # a gross outlier lands within 4 px only by chance
 
 
