@@ -60,7 +60,7 @@ def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
     # kernel's own time, and over the family's time
     orb_alg, _ = algorithmic_bytes("orb_", pipe, args.anms)
     orb_total_ms = 0.0
-    for name in ("orb_resize_kernel", "orb_pyramid_kernel", "orb_fast_kernel", "orb_select_kernel", "orb_anms_kernel", "orb_orient_kernel", "orb_blur_kernel", "orb_describe_kernel"):
+    for name in ("orb_resize_kernel", "orb_pyrblur_kernel", "orb_fast_kernel", "orb_select_kernel", "orb_anms_kernel", "orb_orient_kernel", "orb_blur_kernel", "orb_describe_kernel"):
         k = prof.get(name)
         if not k or k[0] <= 0:
             continue

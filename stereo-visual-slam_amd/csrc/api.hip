@@ -115,7 +115,12 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
     if (B <= 0) return VSLAM_OK;
     if (B > c->p.max_batch) { set_error("batch %d exceeds context max_batch %d", B, c->p.max_batch); return VSLAM_ERR_ARG; }
     int rc;
-    if ((rc = launch_orb_pyramid(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->stream))) return rc;
+    // with descriptors wanted, every level is staged once for both its successor and its blurred copy (orb_pyrblur_kernel);
+    // VSLAM_ORB_UNFUSED=1 (tuning aid) keeps the separate resize / blur kernels for A/B measurements
+    static const bool unfused = getenv("VSLAM_ORB_UNFUSED") != nullptr;
+    const bool fused = describe && !unfused;
+    if (fused) { if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc; }
+    else if ((rc = launch_orb_pyramid(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->stream))) return rc;
     if ((rc = launch_orb_fast(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->p.fast_threshold, c->orb.d_corners,
                               c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
     if ((rc = launch_orb_select(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel,
@@ -125,7 +130,7 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
     // orientation (and the rBRIEF rotation) only for the keypoints the ANMS kept
     if ((rc = launch_orb_orient(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, d_kps, c->orb.d_cs, c->orb.d_order, c->p.kp_capacity, d_count, c->stream))) return rc;
     if (describe) {
-        if ((rc = launch_orb_blur(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
+        if (!fused && (rc = launch_orb_blur(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
         if ((rc = launch_orb_describe(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, c->orb.d_order, c->p.kp_capacity, d_count,
                                       d_desc, c->stream))) return rc;
     }
@@ -160,7 +165,7 @@ const char* vslam_last_error(void) { return g_err; }
 const char* vslam_version(void) { return "vslam_hip 0.3 (gfx950, ABI 3)"; }
 int vslam_abi_version(void) { return VSLAM_ABI_VERSION; }
 const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tests/test_abi.py checks the list against the sources)
-    return "orb_resize_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_orient_kernel orb_blur_kernel orb_describe_kernel "
+    return "orb_resize_kernel orb_pyrblur_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_orient_kernel orb_blur_kernel orb_describe_kernel "
            "match_train_nearest_kernel match_finalize_kernel sgbm_prefilter_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel "
            "sgbm_wta_kernel sgbm_lrcheck_kernel sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel "
            "sgbm_ccl_apply_kernel sgbm_ccl_kernels triangulate_kernel find3d_disparity_kernel gather_uv_kernel build_pnp_inputs_kernel lm_window_kernel "
@@ -355,9 +360,8 @@ int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stri
     VS_HIP(hipMemcpyAsync(d_in, kps, sizeof(vslam_keypoint) * n, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
-    if ((rc = launch_orb_pyramid(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->stream))) return rc;
+    if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
     if ((rc = launch_anms_flat(1, d_in, d_n, kc, 0, 1, w, h, d_kps, c->orb.d_cs, nullptr, kc, d_cnt, c->orb.d_status, c->orb.d_rad, c->stream))) return rc;
-    if ((rc = launch_orb_blur(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
     if ((rc = launch_orb_describe(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, nullptr, kc, d_cnt, d_desc, c->stream))) return rc;
     int32_t m = 0;
     VS_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(m), hipMemcpyDeviceToHost, c->stream));

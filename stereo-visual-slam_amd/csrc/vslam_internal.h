@@ -72,6 +72,11 @@ struct OrbTables {
     int* d_yofs;
     short* d_ibeta;
     int x_off[kNLevels], y_off[kNLevels];
+    // orb_pyrblur_kernel: source level l is cut into 256 x 64 tiles; tile column tx OWNS the output columns dx of level l + 1 whose
+    // left source pixel xofs[dx] falls into it: [tile_dx[tdx_off[l] + tx], tile_dx[tdx_off[l] + tx + 1]); rows likewise
+    int* d_tile_dx;
+    int* d_tile_dy;
+    int tdx_off[kNLevels], tdy_off[kNLevels];
 };
 
 void orb_debug_enable();
@@ -97,6 +102,9 @@ struct OrbBuffers {
 // launches (all asynchronous on `stream`)
 int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch,
                        int B, uint8_t* d_pyr, hipStream_t stream);
+// pyramid level l + 1 AND the blurred level l from ONE staging of the level-l tile (8 launches: the levels depend on each other)
+int launch_orb_pyrblur(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, uint8_t* d_pyr,
+                       uint8_t* d_blur, hipStream_t stream);
 int launch_orb_fast(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
                     int fast_thr, uint32_t* d_corners, int32_t* d_corner_cnt, int32_t* d_status, hipStream_t stream);
 int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
