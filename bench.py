@@ -324,6 +324,8 @@ def main():
     ap.add_argument("--sequence", type=int, default=0, metavar="F",
                     help="BASELINE config 5: one F-frame sequence split into contiguous chunks with a 1-frame halo across the ranks, relative poses "
                          "gathered over RCCL and chained on rank 0 (stereo-visual-slam_amd/sharding.py); 0 = independent batches per rank")
+    ap.add_argument("--render-workers", type=int, default=-1, help="processes that render the synthetic frames (-1: one per available core up to 32; 0: in-process, "
+                                                                     "e.g. under rocprofv3, which would otherwise attach to every worker)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -361,7 +363,7 @@ def main():
         host_cores = len(os.sched_getaffinity(0))
     except Exception:
         host_cores = os.cpu_count() or 1
-    render_workers = max(1, min(host_cores // max(world, 1), 32))
+    render_workers = max(1, min(host_cores // max(world, 1), 32)) if args.render_workers < 0 else args.render_workers
 
     from stereo_visual_slam_amd.pipeline import KeyframePipeline
     from stereo_visual_slam_amd import sharding
