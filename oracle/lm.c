@@ -149,7 +149,7 @@ static int run_lm(lm_problem* p, int iters, vo_lm_stats* st) {
     double* Hpl = (double*)calloc((size_t)(ne ? ne : 1) * 18, sizeof(double));
     double* S = (double*)malloc(sizeof(double) * (size_t)np * np);
     double* bs = (double*)malloc(sizeof(double) * (size_t)np);
-    double* xp = (double*)malloc(sizeof(double) * (size_t)np);
+    double* xp = (double*)calloc((size_t)np, sizeof(double));
     double* xl = (double*)calloc((size_t)(nl ? nl : 1) * 3, sizeof(double));
     double* Dinv = (double*)malloc(sizeof(double) * (size_t)(nl ? nl : 1) * 9);
     double* W = (double*)malloc(sizeof(double) * (size_t)nk * 18);
@@ -242,7 +242,7 @@ static int run_lm(lm_problem* p, int iters, vo_lm_stats* st) {
                 }
             }
             if (ok2) ok2 = chol_solve(S, np, bs, xp);
-            if (!ok2) memset(xp, 0, sizeof(double) * (size_t)np);
+            if (!ok2 && !(vo_variant_flags & VO_VAR_STALE_UPDATE)) memset(xp, 0, sizeof(double) * (size_t)np); /* variant: g2o's stale x of the previous solve */
             for (int l = 0; l < nl; ++l) {
                 double c[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
                 for (int j = p->lm_ptr[l]; j < p->lm_ptr[l + 1]; ++j) {

@@ -106,6 +106,8 @@ void vo_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_
         uint8_t* D = dst + (size_t)dy * dstride;
         for (int dx = 0; dx < dw; ++dx) {
             int v = (((b0 * (rows[0][dx] >> 4)) >> 16) + ((b1 * (rows[1][dx] >> 4)) >> 16) + 2) >> 2;
+            if (vo_variant_flags & VO_VAR_RESIZE_ROUND) /* one rounding of the full 22-bit product instead of the library's >>4, >>16, +2 >>2 chain */
+                v = (b0 * rows[0][dx] + b1 * rows[1][dx] + (1 << 21)) >> 22;
             D[dx] = (uint8_t)v; /* uchar(...) truncation; value is always within 0..255 */
         }
     }
@@ -280,7 +282,18 @@ float vo_harris_response(const uint8_t* img, int stride, int x0, int y0) {
     return ((float)a * (float)b - (float)c * (float)c - harris_k * ((float)a + (float)b) * ((float)a + (float)b)) * scale_sq_sq;
 }
 
+/* ------------------------------------------------------------------ [UPSTREAM] ambiguity switches ----
+ * tests/oracle_sensitivity.py flips ONE reading of an OpenCV / g2o detail at a time and counts what changes downstream.
+ * 0 (the default, and the only value the parity tests and the HIP path ever see) = the readings documented in DESIGN.md. */
+unsigned vo_variant_flags = 0;
+void vo_set_variant(unsigned flags) { vo_variant_flags = flags; }
+unsigned vo_get_variant(void) { return vo_variant_flags; }
+
 float vo_fast_atan2(float y, float x) {
+    if (vo_variant_flags & VO_VAR_ATAN2F) { /* libm atan2f in degrees instead of cv::fastAtan2's 7th-order polynomial */
+        float a = atan2f(y, x) * (float)(180.0 / 3.1415926535897932384626433832795);
+        return a < 0 ? a + 360.f : a;
+    }
     static const float rad2deg = (float)(180.0 / 3.1415926535897932384626433832795);
     const float p1 = 0.9997878412794807f * rad2deg, p3 = -0.3258083974640975f * rad2deg;
     const float p5 = 0.1555786518463281f * rad2deg, p7 = -0.04432655554792128f * rad2deg;
@@ -334,6 +347,16 @@ int vo_retain_best(vo_keypoint* kps, int n, int npoints) {
     float cut = r[npoints - 1];
     free(r);
     int m = 0;
+    if (vo_variant_flags & VO_VAR_RETAIN_EXACT) { /* exactly npoints: ties at the cut are dropped in raster order (one possible nth_element outcome) */
+        int above = 0;
+        for (int i = 0; i < n; ++i) above += kps[i].response > cut;
+        int ties_left = npoints - above;
+        for (int i = 0; i < n; ++i) {
+            if (kps[i].response > cut) kps[m++] = kps[i];
+            else if (kps[i].response == cut && ties_left > 0) { kps[m++] = kps[i]; --ties_left; }
+        }
+        return m;
+    }
     for (int i = 0; i < n; ++i)
         if (kps[i].response >= cut) kps[m++] = kps[i];
     return m;
@@ -496,6 +519,7 @@ int vo_orb_compute(const uint8_t* img, int w, int h, int stride, vo_keypoint* kp
         float angle = kpt->angle;
         angle *= (float)(3.1415926535897932384626433832795 / 180.f);
         float a = (float)cos((double)angle), b = (float)sin((double)angle);
+        if (vo_variant_flags & VO_VAR_COSF) { a = cosf(angle); b = sinf(angle); } /* the float overloads instead of the double ones */
         int cy = cv_round_f(kpt->y * scale) + B, cx = cv_round_f(kpt->x * scale) + B;
         const uint8_t* center = ext[l] + (size_t)cy * estride[l] + cx;
         const int step = estride[l];

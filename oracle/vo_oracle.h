@@ -214,4 +214,14 @@ void vo_rotmat_to_quat(const double R[9], double q[4]);
 #ifdef __cplusplus
 }
 #endif
+/* [UPSTREAM] ambiguity switches (tests/oracle_sensitivity.py); 0 = the documented readings */
+#define VO_VAR_COSF 1u          /* rBRIEF rotation: cosf / sinf instead of (float)cos((double)) */
+#define VO_VAR_RETAIN_EXACT 2u  /* KeyPointsFilter::retainBest: exactly n survivors instead of all ties at the cut */
+#define VO_VAR_RESIZE_ROUND 4u  /* 8-bit INTER_LINEAR: one rounding of the 22-bit product instead of the >>4, >>16, +2 >>2 chain */
+#define VO_VAR_ATAN2F 8u        /* IC angle: libm atan2f instead of cv::fastAtan2 */
+#define VO_VAR_STALE_UPDATE 16u /* g2o failed linear solve: stale update instead of x_p = 0 */
+extern unsigned vo_variant_flags;
+void vo_set_variant(unsigned flags);
+unsigned vo_get_variant(void);
+
 #endif /* VO_ORACLE_H */
