@@ -21,6 +21,8 @@
 //   sgbm_to_float_kernel    int16 / 16 -> f32 (invalid = -1)
 #include "vslam_internal.h"
 
+#include <stdlib.h>
+
 namespace vslam {
 
 struct SgbmDims {
@@ -282,6 +284,186 @@ __global__ __launch_bounds__(64) void sgbm_path_kernel(SgbmDims dm, const int16_
     }
 }
 
+// ------------------------------------------------------------------------------------------- fused top-down pass
+// sgbm_down_kernel = pixel cost + horizontal box + vertical box + the vertical path (0, 1) in ONE sweep: a workgroup owns kDnCols
+// columns of the cost volume and walks down the rows.  Per row: (1) the Birchfield-Tomasi cost of its columns plus the 4-column
+// halo goes into a small LDS tile (one work item = one pixel x 6 disparities, operands prefetched a row ahead); (2) the lane that
+// owns (column, 6 disparities) of the path sums its nine tile entries = hsum; a nine-deep REGISTER ring of hsum rows turns it into
+// the sliding vertical sum C (top rows replicated, the last SH2 rows frozen, column 0 frozen after the first row -- the library's
+// border rules, see sgbm_vsum_kernel); (3) C is stored for the other four paths and consumed on the spot by the vertical path's
+// recurrence, whose L goes out as T.  hsum never exists in memory and C is not re-read: 2 volume writes instead of
+// 1 write (hsum) + 2 reads + 1 write (vsum) + 1 read + 1 write (path 0,1).
+#ifndef VSLAM_SGBM_DN_COLS
+#define VSLAM_SGBM_DN_COLS 24
+#endif
+#ifdef VSLAM_SGBM_PROFILE // tuning aid (tools/build_variant.sh ... -DVSLAM_SGBM_PROFILE): cycles per phase of one workgroup's wave 0
+__device__ long long g_sgbm_dbg[8];
+#define DN_T(slot) do { if (dbg__) { const long long t1__ = clock64(); acc__[slot] += t1__ - t0__; t0__ = t1__; } } while (0)
+#else
+#define DN_T(slot) do {} while (0)
+#endif
+constexpr int kDnCols = VSLAM_SGBM_DN_COLS, kDnThreads = (kDnCols + 8) * 16; // one pixel-cost item per (tile column, 16-lane slot)
+struct DnRowIn { uint8_t l[6]; unsigned long long r[6]; };   // left {val, lo, hi} x 2 channels (raw loads: nothing is computed on them at fetch time,
+                                                              // or the wave would wait for its own prefetch), right planes as 8-byte windows
+
+__global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, const uint8_t* __restrict__ pre, int16_t* __restrict__ C, uint16_t* __restrict__ T) {
+    const int b = blockIdx.y, j0 = blockIdx.x * kDnCols;
+    const int W1 = dm.width1, w = dm.w, h = dm.h;
+    __shared__ alignas(16) uint8_t tile[2][(kDnCols + 8) * 128]; // [row parity][tile column][16 lanes x 8 bytes (6 costs + 2 pad)]
+    const int t = threadIdx.x >> 4, r = threadIdx.x & 15, d = 6 * r;
+    const int jj = min(max(j0 - 4 + t, 0), W1 - 1), x = dm.minX1 + jj; // pixel-cost column of this item (clamped to the volume)
+    const uint8_t* Lb = pre + ((size_t)(2 * b) * h * 6) * w;
+    const uint8_t* Rb = pre + ((size_t)(2 * b + 1) * h * 6) * w;
+    // per-lane byte offsets inside one prefiltered row (6 planes of w bytes), constant over the rows: the row base is wave-uniform, so
+    // the twelve loads of a row need no per-row address arithmetic (scalar base + 32-bit lane offset)
+    uint32_t offL[6], offR[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { offL[q] = (uint32_t)(q * w + x); offR[q] = (uint32_t)(q * w + x - d - 5); } // byte 5 - i of a window <-> disparity d + i
+    // buffer loads: descriptor (scalar) + per-lane offset (constant) + row offset (scalar): no vector address arithmetic per row
+    // (+ 8 bytes: the last window of the last plane row reaches 2 bytes past the view -- bytes 6, 7 of a window are never used, but the
+    // range check is per dword and would zero bytes 4, 5 with them; what follows is the next view / the next scratch region)
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Lb), 0, h * 6 * w + 8, 0x00020000);
+    const auto rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Rb), 0, h * 6 * w + 8, 0x00020000);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    auto fetch = [&](int y, DnRowIn& in) {
+        const int row = y * 6 * w; // uniform
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            in.l[q] = __builtin_amdgcn_raw_buffer_load_b8(rsL, (int)offL[q], row, 0);
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsR, (int)offR[q], row, 0);
+            in.r[q] = (unsigned long long)v.x | (unsigned long long)v.y << 32;
+        }
+    };
+    // path lane: column j = j0 + t (t < kDnCols), disparities 6 r .. 6 r + 5
+    const bool path_lane = t < kDnCols;
+    const int j = j0 + t;
+    const bool live = path_lane && j < W1;
+    const bool frozen = j == 0; // the reference never updates column 0 after the first row
+    const size_t vbase = ((size_t)b * h * W1 + j) * 96 + 6 * r; // (row 0, column j)
+    const size_t rstride = (size_t)W1 * 96;
+    short2v ring[9][3], acc[3] = {short2v{0, 0}, short2v{0, 0}, short2v{0, 0}};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { ring[q][0] = ring[q][1] = ring[q][2] = short2v{0, 0}; }
+    int l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, minPrev = 0;
+    const int P1 = dm.P1, P2 = dm.P2;
+    // The operands of row i + 1 are fetched while row i is processed.  The two operand sets alternate BY NAME (the body is unrolled 18 =
+    // 2 x 9 times: set = step parity, ring slot = step mod 9): a register copy "cur = nxt" would make the compiler wait for every
+    // outstanding memory operation -- the C / T stores of the row before included -- once per row.
+    DnRowIn in[2];
+    fetch(0, in[0]);
+#ifdef VSLAM_SGBM_PROFILE
+    const bool dbg__ = blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0;
+    long long acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0__ = clock64();
+#endif
+    for (int i0 = 0; i0 < h + dm.SH2; i0 += 18) {
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            constexpr int kDummy = 0; (void)kDummy;
+            const int sidx = step % 9;
+            DnRowIn& cur = in[step & 1];
+            DnRowIn& nxt = in[(step + 1) & 1];
+            const int i = i0 + step; // hsum row produced in this step (while i < h); emitted row y = i - SH2
+            if (i >= h + dm.SH2) continue; // uniform (no break: the ring index must stay a compile-time constant)
+            { // straight-line on purpose (row indices clamped instead of branches): with the fetch inside a conditional the compiler's
+              // wait-count insertion falls back to vmcnt(0) right after issuing the prefetch
+                fetch(min(i + 1, h - 1), nxt);
+                // (1) pixel cost of (column jj, disparities d .. d + 5), both channels, two disparities per packed-i16 operation:
+                // byte 5 - k of a right-view window is disparity d + k, so v_perm pulls the pairs (d, d+1), (d+2, d+3), (d+4, d+5) out of
+                // the two window dwords; cost = min(max(0, u - v1, v0 - u), max(0, v - u1, u0 - v)), channel 1 (raw / 4) shifted before the add
+                short2v cost[3];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const short2v U = {(short)cur.l[3 * c], (short)cur.l[3 * c]}, U0 = {(short)cur.l[3 * c + 1], (short)cur.l[3 * c + 1]};
+                    const short2v U1 = {(short)cur.l[3 * c + 2], (short)cur.l[3 * c + 2]};
+                    const uint32_t vl = (uint32_t)cur.r[3 * c], vh = (uint32_t)(cur.r[3 * c] >> 32);
+                    const uint32_t v0l = (uint32_t)cur.r[3 * c + 1], v0h = (uint32_t)(cur.r[3 * c + 1] >> 32);
+                    const uint32_t v1l = (uint32_t)cur.r[3 * c + 2], v1h = (uint32_t)(cur.r[3 * c + 2] >> 32);
+                    const short2v zero = {0, 0};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t sel = k == 0 ? 0x0c040c05u : (k == 1 ? 0x0c020c03u : 0x0c000c01u);
+                        const short2v V = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(vh, vl, sel));
+                        const short2v V0 = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(v0h, v0l, sel));
+                        const short2v V1 = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(v1h, v1l, sel));
+                        const short2v c0 = __builtin_elementwise_max(__builtin_elementwise_max(U - V1, zero), V0 - U);
+                        const short2v c1 = __builtin_elementwise_max(__builtin_elementwise_max(V - U1, zero), U0 - V);
+                        const short2v m = __builtin_elementwise_min(c0, c1);
+                        if (c == 0) cost[k] = m;
+                        else cost[k] = cost[k] + __builtin_bit_cast(short2v, (__builtin_bit_cast(uint32_t, m) >> 2) & 0x3FFF3FFFu);
+                    }
+                }
+                uint2 o;
+                o.x = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, cost[1]), __builtin_bit_cast(uint32_t, cost[0]), 0x06040200u);
+                o.y = __builtin_amdgcn_perm(0u, __builtin_bit_cast(uint32_t, cost[2]), 0x0c0c0200u);
+                *reinterpret_cast<uint2*>(&tile[i & 1][t * 128 + r * 8]) = o;
+            }
+            DN_T(0);
+            __syncthreads();
+            DN_T(1);
+            if (path_lane) {
+                if (i < h) {
+                    // (2) hsum(i) of column j: nine tile columns t .. t + 8 (= volume columns j - 4 .. j + 4, clamped)
+                    uint32_t e0 = 0, o0 = 0, e1 = 0, o1 = 0;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(&tile[i & 1][(t + q) * 128 + r * 8]);
+                        e0 += v.x & 0x00FF00FFu; o0 += (v.x >> 8) & 0x00FF00FFu;
+                        e1 += v.y & 0x000000FFu; o1 += (v.y >> 8) & 0x000000FFu;
+                    }
+                    short2v hs[3];
+                    hs[0] = __builtin_bit_cast(short2v, (e0 & 0xFFFFu) | (o0 << 16));
+                    hs[1] = __builtin_bit_cast(short2v, (e0 >> 16) | (o0 & 0xFFFF0000u));
+                    hs[2] = __builtin_bit_cast(short2v, e1 | (o1 << 16));
+                    if (i == 0) { // rows above the image replicate row 0: C(0) = 5 hsum(0) + hsum(1..4); every ring slot starts as hsum(0)
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) { ring[q][0] = hs[0]; ring[q][1] = hs[1]; ring[q][2] = hs[2]; }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc[k] = hs[k] + hs[k] + hs[k] + hs[k] + hs[k];
+                    } else if (i <= dm.SH2) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { ring[sidx][k] = hs[k]; acc[k] = acc[k] + hs[k]; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const short2v old = ring[sidx][k]; // hsum(max(i - 9, 0))
+                            ring[sidx][k] = hs[k];
+                            if (!frozen) acc[k] = acc[k] + hs[k] - old;
+                        }
+                    }
+                }
+                DN_T(2);
+                if (i >= dm.SH2) {
+                    // (3) row y = i - SH2: C = acc (frozen over the last SH2 rows: no hsum arrives any more), vertical path, T
+                    const int y = i - dm.SH2;
+                    U3 c;
+                    c.a = __builtin_bit_cast(uint32_t, acc[0]); c.b = __builtin_bit_cast(uint32_t, acc[1]); c.c = __builtin_bit_cast(uint32_t, acc[2]);
+                    const int lm = dpp_mov<0x111>(kSent, l5);
+                    const int lp = dpp_mov<0x101>(kSent, l0);
+                    const int delta = minPrev + P2;
+                    const int n0 = lo16s(c.a) - delta + min(min(l0, min(lm, l1) + P1), delta);
+                    const int n1 = hi16s(c.a) - delta + min(min(l1, min(l0, l2) + P1), delta);
+                    const int n2 = lo16s(c.b) - delta + min(min(l2, min(l1, l3) + P1), delta);
+                    const int n3 = hi16s(c.b) - delta + min(min(l3, min(l2, l4) + P1), delta);
+                    const int n4 = lo16s(c.c) - delta + min(min(l4, min(l3, l5) + P1), delta);
+                    const int n5 = hi16s(c.c) - delta + min(min(l5, min(l4, lp) + P1), delta);
+                    l0 = n0; l1 = n1; l2 = n2; l3 = n3; l4 = n4; l5 = n5;
+                    minPrev = row16_min(min(min(min(n0, n1), min(n2, n3)), min(n4, n5)));
+                    if (live) {
+                        U3 o;
+                        o.a = pack16(n0 + kTOffset, n1 + kTOffset); o.b = pack16(n2 + kTOffset, n3 + kTOffset); o.c = pack16(n4 + kTOffset, n5 + kTOffset);
+                        *(U3*)(C + vbase + (size_t)y * rstride) = c;
+                        *(U3*)(T + vbase + (size_t)y * rstride) = o;
+                    }
+                }
+                DN_T(3);
+            }
+        }
+    }
+#ifdef VSLAM_SGBM_PROFILE
+    if (dbg__) for (int q = 0; q < 4; ++q) g_sgbm_dbg[q] = acc__[q];
+#endif
+}
+
 // stand-alone winner-take-all over a stored S volume (MODE 3): one DPP row per pixel
 __global__ __launch_bounds__(256) void sgbm_wta_kernel(SgbmDims dm, const uint16_t* __restrict__ S, int4* __restrict__ rec) {
     const int b = blockIdx.y;
@@ -453,7 +635,7 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     const size_t o_pre = need; need += al((size_t)2 * B * h * 6 * w);
     const size_t o_hs = need; need += al((size_t)B * vol * 2);
     const size_t o_C = need; need += al((size_t)B * vol * 2);
-    const size_t o_T = o_hs; // hsum is dead once C exists: T reuses its storage
+    const size_t o_T = o_hs; // hsum is dead once C exists: T reuses its storage (the fused top-down pass never materialises hsum at all)
     const size_t o_rec = need; need += al((size_t)B * npix * 16);
     const size_t o_d0 = need; need += al((size_t)B * npix * 2);
     const size_t o_d1 = need; need += al((size_t)B * npix * 2);
@@ -472,10 +654,12 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     int16_t* d0 = (int16_t*)(base + o_d0); int16_t* d1 = (int16_t*)(base + o_d1); int* par = (int*)(base + o_par); int* cnt = (int*)(base + o_cnt);
     const int vblocks = (dm.width1 * dm.D + 255) / 256;
     { ProfScope p(stream, "sgbm_prefilter_kernel"); hipLaunchKernelGGL(sgbm_prefilter_kernel, dim3((w + 255) / 256, h, 2 * B), dim3(256), 0, stream, dm, d_left, d_right, pre); }
-    { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3((dm.width1 + kHsSeg - 1) / kHsSeg, h, B), dim3(kHsBlock), 0, stream, dm, pre, hsum); }
-    { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3((dm.width1 * 12 + 255) / 256, (h + kVsChunk - 1) / kVsChunk, B), dim3(256), 0, stream, dm, hsum, C); }
+    static const bool unfused = getenv("VSLAM_SGBM_UNFUSED") != nullptr; // tuning aid: the separate hsum / vsum / path<0,1> kernels, for A/B runs
+    if (!unfused) { ProfScope p(stream, "sgbm_down_kernel"); hipLaunchKernelGGL(sgbm_down_kernel, dim3((dm.width1 + kDnCols - 1) / kDnCols, B), dim3(kDnThreads), 0, stream, dm, pre, C, T); }
+    if (unfused) { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3((dm.width1 + kHsSeg - 1) / kHsSeg, h, B), dim3(kHsBlock), 0, stream, dm, pre, hsum); }
+    if (unfused) { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3((dm.width1 * 12 + 255) / 256, (h + kVsChunk - 1) / kVsChunk, B), dim3(256), 0, stream, dm, hsum, C); }
     { const int nv = dm.width1, nd = dm.width1 + h - 1;
-      { ProfScope p(stream, "sgbm_path_kernel<0,1>"); hipLaunchKernelGGL((sgbm_path_kernel<0, 1, 0, 8>), dim3((nv + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nv, (int4*)nullptr); }
+      if (unfused) { ProfScope p(stream, "sgbm_path_kernel<0,1>"); hipLaunchKernelGGL((sgbm_path_kernel<0, 1, 0, 8>), dim3((nv + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nv, (int4*)nullptr); }
       { ProfScope p(stream, "sgbm_path_kernel<1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 1, 1, 8>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd, (int4*)nullptr); }
       { ProfScope p(stream, "sgbm_path_kernel<-1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 1, 1, 8>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd, (int4*)nullptr); }
       { ProfScope p(stream, "sgbm_path_kernel<1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 0, 2, 16>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h, (int4*)nullptr); }
@@ -496,6 +680,10 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
       hipLaunchKernelGGL(sgbm_ccl_count_kernel, dim3(pblocks, B), dim3(256), 0, stream, w, h, maxDiff, newVal, d1, par, cnt);
       hipLaunchKernelGGL(sgbm_ccl_apply_kernel, dim3(pblocks, B), dim3(256), 0, stream, w, h, newVal, maxSize, par, cnt, d1, d_disp_f32, d_disp_i16); }
     VS_HIP(hipGetLastError());
+#ifdef VSLAM_SGBM_PROFILE
+    { long long hdbg[8]; (void)hipStreamSynchronize(stream); (void)hipMemcpyFromSymbol(hdbg, HIP_SYMBOL(g_sgbm_dbg), sizeof(hdbg));
+      fprintf(stderr, "[sgbm_down profile] cycles of one wave over %d rows: pixel cost %lld, barrier %lld, hsum+ring %lld, path+stores %lld\n", h, hdbg[0], hdbg[1], hdbg[2], hdbg[3]); }
+#endif
     return VSLAM_OK;
 }
 
