@@ -448,12 +448,12 @@ def main():
         kern = sorted(prof.items(), key=lambda kv: -kv[1][0])
         dom, (dom_ms, dom_launches, dom_calls) = kern[0]
         alg, formula = algorithmic_bytes(dom, pipe, args.anms)
-        if dom.startswith("sgbm_"):
+        if args.depth == "sgbm" and any(k.startswith("sgbm_") for k, _ in kern):
             # --depth sgbm: the roofline line is the SGBM FAMILY (one bracket = one vslam_disparity_map_dev call = B pairs): compulsory bytes of a
             # fully fused design = the (w - 96) x h x 96 x i16 cost volume once + both images in + the f32 map out, per pair
             fam = [(k, v) for k, v in kern if k.startswith("sgbm_")]
             dom = "sgbm_* (family: %s)" % ", ".join(k for k, _ in fam)
-            dom_ms = sum(v[0] for _, v in fam); dom_launches = sum(v[1] for _, v in fam); dom_calls = args.steps
+            dom_ms = sum(v[0] for _, v in fam); dom_launches = sum(v[1] for _, v in fam); dom_calls = n_prof_steps
             cv = (pipe.w - 96) * pipe.h * 96 * 2
             alg = B * (cv + 2 * pipe.w * pipe.h + 4 * pipe.w * pipe.h)
             formula = "B pairs x ((w-96)*h*96*2 B cost volume once + 2*w*h B images in + 4*w*h B f32 disparity out)"

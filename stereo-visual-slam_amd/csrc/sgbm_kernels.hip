@@ -212,10 +212,14 @@ __device__ inline void wta_row16(const SgbmDims& dm, int s0, int s1, int s2, int
     }
 }
 
+#ifndef VSLAM_SGBM_PATH_BLOCK
+#define VSLAM_SGBM_PATH_BLOCK 64
+#endif
+constexpr int kPathBlock = VSLAM_SGBM_PATH_BLOCK, kPathLines = kPathBlock / 16; // lines per workgroup (adjacent lines: one contiguous run of the volume per step)
 template <int DX, int DY, int MODE, int kPathPF>
-__global__ __launch_bounds__(64) void sgbm_path_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* T, int nlines, int4* __restrict__ rec) {
+__global__ __launch_bounds__(kPathBlock) void sgbm_path_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* T, int nlines, int4* __restrict__ rec) {
     const int b = blockIdx.y;
-    const int line = blockIdx.x * 4 + (threadIdx.x >> 4), r = threadIdx.x & 15;
+    const int line = blockIdx.x * kPathLines + (threadIdx.x >> 4), r = threadIdx.x & 15;
     if (line >= nlines) return; // whole DPP row leaves
     const int W1 = dm.width1, h = dm.h;
     int x0, y0, len;
@@ -659,13 +663,13 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     if (unfused) { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3((dm.width1 + kHsSeg - 1) / kHsSeg, h, B), dim3(kHsBlock), 0, stream, dm, pre, hsum); }
     if (unfused) { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3((dm.width1 * 12 + 255) / 256, (h + kVsChunk - 1) / kVsChunk, B), dim3(256), 0, stream, dm, hsum, C); }
     { const int nv = dm.width1, nd = dm.width1 + h - 1;
-      if (unfused) { ProfScope p(stream, "sgbm_path_kernel<0,1>"); hipLaunchKernelGGL((sgbm_path_kernel<0, 1, 0, 8>), dim3((nv + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nv, (int4*)nullptr); }
-      { ProfScope p(stream, "sgbm_path_kernel<1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 1, 1, 8>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd, (int4*)nullptr); }
-      { ProfScope p(stream, "sgbm_path_kernel<-1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 1, 1, 8>), dim3((nd + 3) / 4, B), dim3(64), 0, stream, dm, C, T, nd, (int4*)nullptr); }
-      { ProfScope p(stream, "sgbm_path_kernel<1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 0, 2, 16>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h, (int4*)nullptr); }
-      if (B >= 4) { ProfScope p(stream, "sgbm_path_kernel<-1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 4, 16>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h, rec); }
+      if (unfused) { ProfScope p(stream, "sgbm_path_kernel<0,1>"); hipLaunchKernelGGL((sgbm_path_kernel<0, 1, 0, 8>), dim3((nv + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, nv, (int4*)nullptr); }
+      { ProfScope p(stream, "sgbm_path_kernel<1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 1, 1, 8>), dim3((nd + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, nd, (int4*)nullptr); }
+      { ProfScope p(stream, "sgbm_path_kernel<-1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 1, 1, 8>), dim3((nd + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, nd, (int4*)nullptr); }
+      { ProfScope p(stream, "sgbm_path_kernel<1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 0, 2, 16>), dim3((h + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, h, (int4*)nullptr); }
+      if (B >= 4) { ProfScope p(stream, "sgbm_path_kernel<-1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 4, 16>), dim3((h + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, h, rec); }
       else {
-        { ProfScope p(stream, "sgbm_path_kernel<-1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 3, 16>), dim3((h + 3) / 4, B), dim3(64), 0, stream, dm, C, T, h, (int4*)nullptr); }
+        { ProfScope p(stream, "sgbm_path_kernel<-1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 3, 16>), dim3((h + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, h, (int4*)nullptr); }
         { ProfScope p(stream, "sgbm_wta_kernel"); hipLaunchKernelGGL(sgbm_wta_kernel, dim3((unsigned)(((size_t)h * dm.width1 + 15) / 16), B), dim3(256), 0, stream, dm, T, rec); }
       } }
     { ProfScope p(stream, "sgbm_lrcheck_kernel");

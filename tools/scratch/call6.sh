@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-( timeout 600 python -m pytest tests/test_gpu_sgbm.py -q -m gpu ) 2>&1 | tail -2
-( timeout 300 python tests/fuzz_parity.py --seconds 120 --seed 9 --only sgbm ) 2>&1 | tail -1
+for v in pb128 pb256 pb512; do
+  echo $v; ( VSLAM_LIB=build/libvslam_hip_$v.so timeout 300 python tools/bench_sgbm.py --batch 32 --reps 4 ) 2>&1 | grep -v amdgpu.ids | cut -c1-260 | head -2
+done
