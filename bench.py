@@ -265,6 +265,14 @@ def host_input_region(pipe, args, timed_region, one_step, torch):
             "how": "pinned host ring of 2 batches; hipMemcpyAsync of step k+1 on a copy stream overlapped with step k; the upload is inside the timed region"}
 
 
+def _rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:
+        return "unknown (%r)" % (e,)
+
+
 def host_info():
     """lscpu-style identification of the host the cpu_baseline ran on + run-time probe for the reference's own libraries"""
     model = None
@@ -472,7 +480,7 @@ def main():
             "metric": "stereo keyframes/sec (ORB+match+tri+local-BA), KITTI-00 1241x376",
             "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "world_size": (dist.get_world_size() if dist is not None else 1),
-            "collective": ("RCCL %s over torch.distributed backend nccl" % ".".join(str(x) for x in torch.cuda.nccl.version())) if dist is not None else "none (1 rank)",
+            "collective": ("RCCL %s over torch.distributed backend nccl" % _rccl_version(torch)) if dist is not None else "none (1 rank)",
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if seq_mode else "weak", "vs_baseline": None,
             "dtype": "u8+f64", "data": "synthetic",
             "config": {"workload": ("stereo keyframe hot path, north_star stages (NOT the reference's SGBM depth / solvePnPRansac pose, which are built "

@@ -51,6 +51,16 @@ namespace vslam {
 #ifndef VSLAM_LM_MIN_WAVES
 #define VSLAM_LM_MIN_WAVES 2 // waves per SIMD the register allocation must leave room for
 #endif
+// VSLAM_LM_PRIO = n > 0 (tuning aid): the two waves of a SIMD (wave w and w + 4 of the 8-wave workgroup) alternate their issue
+// priority every n rows of the hot loops, so that the older wave does not finish its share 25-30 % before its partner
+#ifndef VSLAM_LM_PRIO
+#define VSLAM_LM_PRIO 0
+#endif
+#if VSLAM_LM_PRIO > 0
+#define LM_PRIO_TICK(cnt) do { if ((((cnt) / VSLAM_LM_PRIO) ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); ++(cnt); } while (0)
+#else
+#define LM_PRIO_TICK(cnt) do {} while (0)
+#endif
 constexpr int kLmBlock = VSLAM_LM_BLOCK;
 constexpr int kLmWaves = kLmBlock / 64;
 constexpr int kMaxKf = VSLAM_MAX_KF;
@@ -399,6 +409,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     __shared__ LmShared sm;
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // tell the compiler it is wave-uniform: wave-indexed control flow goes scalar
+    int prio_cnt = 0; (void)prio_cnt;
     const int nk = a.n_kf, np = 6 * nk;
     int lm0, nl, e0, ne;
     if (IMPL) { nl = min(max(ka.pnp_n[w], 0), ka.capacity); lm0 = w * ka.capacity; e0 = lm0; ne = nl; }
@@ -812,6 +823,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             // queues are rotated with register moves instead of static indices)
 #pragma unroll 1
             for (int row = ra;; ++row) {
+                LM_PRIO_TICK(prio_cnt);
                 const bool done = row >= rb;
                 if (done || cur.k != kacc) {
                     flush(kacc);
@@ -1032,6 +1044,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         loadD(ln, Da, Db, Dc);
                         double g0 = PC(bl, 0, ln), g1 = PC(bl, 1, ln), g2 = PC(bl, 2, ln);
                         for (; j < jend; j += 64) {
+                            LM_PRIO_TICK(prio_cnt);
                             double2 Dan, Dbn, Dcn;
                             loadD_row(lnn, Dan, Dbn, Dcn); // (first: see loadD_row -- nothing of THIS row's prefetch is in flight yet)
                             const int lnnn = kf_lm[min(j + 128, jend - 1)];
@@ -1103,6 +1116,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         double2 Da, Db, Dc;
                         loadD(h.y, Da, Db, Dc);
                         for (; j < jend; j += 64) {
+                            LM_PRIO_TICK(prio_cnt);
                             double2 Dan, Dbn, Dcn;
                             loadD_row(hn.y, Dan, Dbn, Dcn); // (first: see loadD_row)
                             const int2 hnn = hits[min(j + 128, jend - 1)];
