@@ -469,8 +469,10 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
                 const s16x2 c12 = as_s16x2(h ? __builtin_amdgcn_perm(D1, D0, 0x0c040c03u) : __builtin_amdgcn_perm(0u, D0, 0x0c020c01u)); // x - 3
                 // "two adjacent compass pixels both brighter than v + t": the largest of the four pairwise minima exceeds v + t;
                 // "both darker than v - t": the smallest of the four pairwise maxima is below v - t
-                const s16x2 brightest_pair = pk_max(pk_max(pk_min(c0, c4), pk_min(c4, c8)), pk_max(pk_min(c8, c12), pk_min(c12, c0)));
-                const s16x2 darkest_pair = pk_min(pk_min(pk_max(c0, c4), pk_max(c4, c8)), pk_min(pk_max(c8, c12), pk_max(c12, c0)));
+                // (every adjacent pair takes one pixel of {c0, c8} and one of {c4, c12}, and all four combinations are adjacent pairs:
+                //  max over pairs of min(a, b) = min(max(c0, c8), max(c4, c12)) -- three operations instead of seven; likewise the dark side)
+                const s16x2 brightest_pair = pk_min(pk_max(c0, c8), pk_max(c4, c12));
+                const s16x2 darkest_pair = pk_max(pk_min(c0, c8), pk_min(c4, c12));
                 const s16x2 m = pk_max(brightest_pair - (v + vthr), (v - vthr) - darkest_pair);
                 mask |= (uint32_t)(m.x > 0) << (2 * h) | (uint32_t)(m.y > 0) << (2 * h + 1);
             }
