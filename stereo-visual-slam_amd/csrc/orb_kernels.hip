@@ -1451,10 +1451,20 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
     if (a.dst_base) {
         const int dx_lo = a.tile_dx[tx], dx_hi = a.tile_dx[tx + 1], dy_lo = a.tile_dy[ty], dy_hi = a.tile_dy[ty + 1]; // uniform
         const int dx0 = (dx_lo & ~3) + 4 * lane; // this lane's aligned quad of output columns
-        if (dx0 < dx_hi && dy_lo < dy_hi) {
+        // the row tables of ALL rows of this wave are fetched once, one row per lane (<= 16 rows per wave: 64 source rows / 1.2 / 4 waves),
+        // by every lane (v_readlane below reads lanes that own no output column), and handed out with v_readlane: a table load per row
+        // would be a dependent memory round trip at the head of every row
+        const int my_dy = min(dy_lo + wave + 4 * lane, a.dh - 1);
+        const int my_sy = a.yofs[my_dy];
+        const uint32_t my_beta = *reinterpret_cast<const uint32_t*>(a.ibeta + 2 * my_dy); // (b0, b1) as two shorts
+        // EVERY lane runs the loop below (lanes past the tile's last quad compute on clamped table entries and store nothing): the row
+        // hand-out reads lanes 0..15 with v_readlane, and a lane that a divergent branch has switched off holds no defined value for it
+        // (the compiler may sink its loads into the branch)
+        if (dy_lo < dy_hi) { // uniform
             uint8_t* dst = a.dst_base + (size_t)b * a.dst_img_stride;
-            const int4 xo = *reinterpret_cast<const int4*>(a.xofs + dx0);          // tables are padded to whole quads
-            const uint4 al = *reinterpret_cast<const uint4*>(a.ialpha + 2 * dx0);
+            const int dxl = min(dx0, (dx_hi + 3) & ~3);                              // tables are padded to whole quads (+ one more)
+            const int4 xo = *reinterpret_cast<const int4*>(a.xofs + dxl);
+            const uint4 al = *reinterpret_cast<const uint4*>(a.ialpha + 2 * dxl);
             const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
             const uint32_t alw[4] = {al.x, al.y, al.z, al.w};
             // window = 8 bytes from tile column c0 on: the four outputs interpolate source columns xo.x .. xo.w + 1 <= xo.x + 5.  A quad that
@@ -1466,10 +1476,12 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) sel[k] = 0x0c010c00u + __umul24((uint32_t)(sxs[k] - (ox - 4) - c0) & 7u, 0x00010001u); // rel = 0..7 (garbage for unowned columns)
             const uint32_t* rawd = reinterpret_cast<const uint32_t*>(raw);
-            for (int dy = dy_lo + wave; dy < dy_hi; dy += 4) { // wave-uniform
-                const int sy = a.yofs[dy];
+            int it = 0;
+            for (int dy = dy_lo + wave; dy < dy_hi; dy += 4, ++it) { // wave-uniform
+                const int sy = __builtin_amdgcn_readlane(my_sy, it);
+                const uint32_t beta = (uint32_t)__builtin_amdgcn_readlane((int)my_beta, it);
                 const int r0 = min(max(sy, 0), H - 1) - (oy - 3), r1 = min(max(sy + 1, 0), H - 1) - (oy - 3);
-                const uint32_t b0 = (uint32_t)(int)a.ibeta[2 * dy], b1 = (uint32_t)(int)a.ibeta[2 * dy + 1];
+                const uint32_t b0 = (uint32_t)(int)(short)(beta & 0xFFFFu), b1 = (uint32_t)(int)(short)(beta >> 16);
                 const uint32_t* p0 = rawd + r0 * (kBlurRawPitch / 4) + i0;
                 const uint32_t* p1 = rawd + r1 * (kBlurRawPitch / 4) + i0;
                 const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], c0w = p1[0], c1w = p1[1], c2w = p1[2];
