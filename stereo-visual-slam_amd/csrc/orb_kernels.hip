@@ -1624,11 +1624,14 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
     struct Geo { int cx, cy, l, W, H, bpitch; bool inside; const uint8_t* blur; };
     auto geometry = [&](const vslam_keypoint& kp) -> Geo {
         Geo g;
-        g.l = min(max(kp.octave, 0), kNLevels - 1);
+        // (every lane holds the same keypoint record: pinning level and centre in scalar registers makes the patch origin a scalar
+        // base, so the patch loads are scalar base + 32-bit lane offset instead of seven 64-bit address computations per keypoint)
+        g.l = __builtin_amdgcn_readfirstlane(min(max(kp.octave, 0), kNLevels - 1));
         g.W = T.w[g.l]; g.H = T.h[g.l]; g.bpitch = T.pitch[g.l];
         g.blur = d_blur + (size_t)b * blur_bytes + T.blur_off[g.l];
         const float inv_scale = __fdiv_rn(1.f, LT.scale[g.l]);
-        g.cx = __float2int_rn(__fmul_rn(kp.x, inv_scale)); g.cy = __float2int_rn(__fmul_rn(kp.y, inv_scale));
+        g.cx = __builtin_amdgcn_readfirstlane(__float2int_rn(__fmul_rn(kp.x, inv_scale)));
+        g.cy = __builtin_amdgcn_readfirstlane(__float2int_rn(__fmul_rn(kp.y, inv_scale)));
         // Fast path (every keypoint the detector emits: edgeThreshold 31 > the rotated pattern radius 19): the wave stages the
         // 39 x 40 byte neighbourhood of the blurred level in LDS with coalesced unaligned-dword row loads and gathers the 512
         // samples from there -- scattered byte loads from global memory are bound by the texture-address line rate.
@@ -1637,10 +1640,10 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
     };
     auto patch_fetch = [&](const Geo& g, uint32_t (&pv)[kDescPatchIters]) {
         if (!g.inside) return;
-        const uint8_t* org = g.blur + (size_t)(g.cy - kDescR) * g.bpitch + (g.cx - kDescR);
+        const uint8_t* org = g.blur + (size_t)(g.cy - kDescR) * g.bpitch + (g.cx - kDescR); // wave-uniform
 #pragma unroll
-        for (int it = 0; it < kDescPatchIters; ++it)
-            if (prow[it] < kDescRows) __builtin_memcpy(&pv[it], org + (size_t)prow[it] * g.bpitch + pcol[it], 4);
+        for (int it = 0; it < kDescPatchIters; ++it) // (24-bit multiply: full rate; rows < 39, pitch < 4160)
+            if (prow[it] < kDescRows) __builtin_memcpy(&pv[it], org + (__umul24((uint32_t)prow[it], (uint32_t)g.bpitch) + (uint32_t)pcol[it]), 4);
     };
     vslam_keypoint kp = kps[j];
     float2 cs = css[j];
