@@ -42,7 +42,7 @@ def algorithmic_bytes(kernel, pipe, anms_num):
     if kernel.startswith("match_"):
         # (Nq+Nt)*32 + Nq*8 per item
         return B * ((anms_num + anms_num) * 32 + anms_num * 8), "B x ((Nq+Nt)*32 + Nq*8) B"
-    if kernel.startswith("lm_window_kernel<pnp>"):
+    if kernel.startswith("lm_window_kernel<pnp>") or kernel.startswith("pnp_wave_kernel"):
         return (B - 1) * 10 * 20 * 500, "(B-1) x 10 its x 20 B/point x ~500 points"
     if kernel.startswith("lm_window_kernel"):
         E, L, K = pipe.edges_per_window, pipe.lms_per_window, pipe.n_kf

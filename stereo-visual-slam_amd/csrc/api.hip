@@ -169,7 +169,7 @@ const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tes
            "match_train_nearest_kernel match_finalize_kernel sgbm_prefilter_kernel sgbm_down_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel "
            "sgbm_wta_kernel sgbm_lrcheck_kernel sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel "
            "sgbm_ccl_apply_kernel sgbm_ccl_kernels triangulate_kernel find3d_disparity_kernel gather_uv_kernel build_pnp_inputs_kernel lm_window_kernel "
-           "lm_window_kernel<pnp> pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel";
+           "lm_window_kernel<pnp> pnp_wave_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel";
 }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
@@ -606,7 +606,7 @@ int vslam_pnp_motion_only(vslam_ctx* ctx, const float* xyz_w, const float* uv, i
     memset(&p, 0, sizeof(p));
     p.xyz = d_x; p.uv = d_u; p.n = d_n; p.capacity = n; p.B = 1; p.T = d_T; p.iters = iters;
     fill_K(c, p.K); p.huber_delta = c->p.huber_delta; p.reproj_thr = c->p.pnp_reproj_thr;
-    p.inlier = d_in; p.n_inliers = d_n + 1; p.stats = d_st;
+    p.inlier = d_in; p.n_inliers = d_n + 1; p.stats = d_st; p.n_hint = n;
     if ((rc = launch_pnp(p, &c->lm, c->stream))) return rc;
     int32_t ni = 0;
     VS_HIP(hipMemcpyAsync(T_c_w, d_T, 56, hipMemcpyDeviceToHost, c->stream));
@@ -727,7 +727,7 @@ static int pnp_ransac_impl(vslam_ctx* ctx, const float* xyz_w, const float* uv, 
     PnpArgs p;
     memset(&p, 0, sizeof(p));
     p.xyz = d_ix; p.uv = d_iu; p.n = d_n1; p.capacity = m; p.B = 1; p.T = d_T; p.iters = lm_iters;
-    fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err;
+    fill_K(c, p.K); p.huber_delta = 1e300; p.reproj_thr = reproj_err; p.n_hint = m;
     if ((rc = launch_pnp(p, &c->lm, c->stream))) return rc;
     VS_HIP(hipMemcpyAsync(T_c_w, d_T, 56, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));

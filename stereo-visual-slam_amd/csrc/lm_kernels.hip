@@ -1490,6 +1490,151 @@ __global__ __launch_bounds__(256) void pnp_inlier_kernel(const float* __restrict
     if (threadIdx.x == 0 && n_inl) n_inl[b] = cnt;
 }
 
+// ------------------------------------------------------------------------------------------- lean motion-only LM
+// pnp_wave_kernel: ONE WAVE per single-pose problem (the motion-only stage of VO::motion_estimation, and the refinement of the RANSAC
+// pose on its inliers).  The window kernel above spends a 512-thread workgroup, its list builders and ~25 barriers per iteration on a
+// problem with one 6x6 block and a few hundred points (~40 k cycles per iteration, almost all of it barriers and serial code); here the
+// points are dealt to the 64 lanes, the 27 sums of the normal equations come out of one halving butterfly, every lane then holds all of
+// them (v_readlane from the lane the butterfly left each sum in) and factors the 6x6 system redundantly -- no LDS, no barrier.  Same
+// algorithm as the window kernel in mode 1 with one keyframe (g2o Levenberg: lambda0 = 1e-5 max diag H, <= 10 trials per iteration,
+// rho = (chi2 - chi2_trial) / (dx (lambda dx + b) + 1e-3), accept: lambda *= max(1/3, min(2/3, 1 - (2 rho - 1)^3)), reject:
+// lambda *= ni, ni *= 2), same residual / Jacobian helpers, fixed summation order; followed by the reprojection-error inlier test.
+__global__ __launch_bounds__(64) void pnp_wave_kernel(const float* __restrict__ xyz, const float* __restrict__ uv, const int32_t* __restrict__ d_n, int capacity,
+                                                     double* __restrict__ d_T, int iters, double K0, double K1, double K2, double K3, double delta,
+                                                     double thr2, uint8_t* __restrict__ inlier, int32_t* __restrict__ n_inl, vslam_lm_stats* __restrict__ stats) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = min(max(d_n[b], 0), capacity);
+    const float* px = xyz + 3 * (size_t)b * capacity;
+    const float2* pz = reinterpret_cast<const float2*>(uv) + (size_t)b * capacity;
+    const double K[4] = {K0, K1, K2, K3};
+    const CamK ck = make_camk(K);
+    vslam_lm_stats* st = stats ? stats + b : nullptr;
+    double T[7], Rt[12];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) T[i] = d_T[7 * (size_t)b + i];
+    expand_pose(T, Rt);
+    const int slot27 = wave_slot<27>(lane);
+    // robust cost at pose R; with LIN also H (upper triangle, 21) and b (6) of the normal equations, left in every lane
+    auto evaluate = [&](const double* R, bool lin, double (&H)[36], double (&g)[6]) -> double {
+        double part = 0, acc[27];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) acc[i] = 0;
+        for (int i0 = 0; i0 < n; i0 += 128) { // two points per lane in flight
+            const int ia = i0 + lane, ib = i0 + 64 + lane;
+            const int ja = min(ia, n - 1), jb = min(ib, n - 1);
+            const double ax = px[3 * ja], ay = px[3 * ja + 1], az = px[3 * ja + 2], bx = px[3 * jb], by = px[3 * jb + 1], bz = px[3 * jb + 2];
+            const float2 za = pz[ja], zb = pz[jb];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if ((u ? ib : ia) >= n) continue;
+                double x, y, ri, wgt, ex, ey, c, rho;
+                cam_norm(R, u ? bx : ax, u ? by : ay, u ? bz : az, x, y, ri);
+                eval_obs(ck, x, y, u ? zb : za, delta, ex, ey, c, rho, wgt);
+                part += rho;
+                if (lin) {
+                    double A[12], wA[12];
+                    jac_norm(x, y, ri, A);
+                    const double l0 = wgt * ck.fx2, l1 = wgt * ck.fy2;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { wA[i] = l0 * A[i]; wA[6 + i] = l1 * A[6 + i]; }
+                    int idx = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int cc = r; cc < 6; ++cc) { acc[idx] = a_fma_pair(wA, r, A, cc, acc[idx]); ++idx; }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc[21 + r] = a_fma2(wA, r, -ex, -ey, acc[21 + r]);
+                }
+            }
+        }
+        const double total = wave_sum(part);
+        if (lin) {
+            wave_reduce_scatter<27>(acc, lane); // acc[0] = sum number slot27 (lane)
+            double v[27];
+#pragma unroll
+            for (int sidx = 0; sidx < 27; ++sidx) {
+                const int src = __ffsll((long long)__ballot(slot27 == sidx)) - 1; // wave-uniform
+                v[sidx] = readlane_f64(acc[0], src);
+            }
+            int idx = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = r; cc < 6; ++cc) { H[6 * r + cc] = v[idx]; H[6 * cc + r] = v[idx]; ++idx; }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) g[r] = v[21 + r];
+        }
+        return total;
+    };
+    double H[36], g[6], lambda = 0, ni = 2, currentChi = 0;
+    int it = 0, total_trials = 0;
+    for (it = 0; it < iters; ++it) {
+        currentChi = evaluate(Rt, true, H, g);
+        if (it == 0) {
+            if (st && lane == 0) st->chi2_init = currentChi;
+            double md = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) md = fmax(fabs(H[7 * a]), md);
+            lambda = 1e-5 * md;
+            ni = 2;
+        }
+        double rho_gain = 0;
+        int qmax = 0;
+        bool again = true;
+        while (again) {
+            double x[6], E[7], Tt[7], Rtt[12], Hd[36], gd[6];
+            const bool ok2 = chol6_solve(H, lambda, g, x);
+            if (!ok2) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) x[i] = 0;
+            }
+            se3::exp(x, E);
+            se3::mul(E, T, Tt);
+            expand_pose(Tt, Rtt);
+            double tempChi = evaluate(Rtt, false, Hd, gd);
+            if (!ok2) tempChi = 1.7976931348623157e308;
+            double scale = 1e-3;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) scale += x[i] * (lambda * x[i] + g[i]);
+            rho_gain = (currentChi - tempChi) / scale;
+            if (rho_gain > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow(2 * rho_gain - 1, 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) T[i] = Tt[i];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) Rt[i] = Rtt[i];
+            } else {
+                lambda *= ni;
+                ni *= 2;
+            }
+            ++qmax;
+            again = (rho_gain < 0) && qmax < 10;
+        }
+        total_trials += qmax;
+        if (st && lane == 0 && it < VSLAM_LM_MAX_ITERS) { st->chi2_iter[it] = currentChi; st->lambda_iter[it] = lambda; st->trials_iter[it] = qmax; }
+        if (qmax == 10 || rho_gain == 0) { ++it; break; }
+    }
+    if (st && lane == 0) { st->iterations = it; st->total_trials = total_trials; st->chi2_final = currentChi; st->lambda_final = lambda; }
+    if (lane < 7) d_T[7 * (size_t)b + lane] = T[lane];
+    // inliers at the estimate: reprojection error <= reproj_thr (the contract of pnp_inlier_kernel)
+    int mine = 0;
+    for (int i = lane; i < n; i += 64) {
+        const size_t gi = (size_t)b * capacity + i;
+        double X, Y, Z, ex, ey;
+        project_err(Rt, K, (double)px[3 * i], (double)px[3 * i + 1], (double)px[3 * i + 2], uv[2 * gi], uv[2 * gi + 1], X, Y, Z, ex, ey);
+        const double c = ex * ex + ey * ey;
+        const bool ok = isfinite(c) && c <= thr2;
+        if (inlier) inlier[gi] = ok;
+        mine += ok;
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0 && n_inl) n_inl[b] = mine;
+}
+
 // (LmScratch, owned by the context and grown on demand, is declared in vslam_internal.h)
 static int ensure(void** p, size_t* have, size_t need) {
     if (*have >= need) return VSLAM_OK;
@@ -1595,6 +1740,16 @@ int lm_fetch_status(const LmScratch* scratch, int n_windows, int32_t* h_status, 
 
 int launch_pnp(const PnpArgs& p, LmScratch* scratch, hipStream_t stream) {
     if (p.B <= 0) return VSLAM_OK;
+    // one wave per problem unless the caller knows the problems are large (n_hint points: the window kernel's 512 lanes pay from ~1000
+    // points on); VSLAM_PNP_WINDOW=1 (tuning aid) forces the window kernel
+    static const bool force_window = getenv("VSLAM_PNP_WINDOW") != nullptr;
+    if (!force_window && p.n_hint <= 1024) {
+        ProfScope prof__(stream, "pnp_wave_kernel");
+        hipLaunchKernelGGL(pnp_wave_kernel, dim3(p.B), dim3(64), 0, stream, p.xyz, p.uv, p.n, p.capacity, p.T, p.iters, p.K[0], p.K[1], p.K[2], p.K[3],
+                           p.huber_delta, p.reproj_thr * p.reproj_thr, p.inlier, p.n_inliers, p.stats);
+        VS_HIP(hipGetLastError());
+        return VSLAM_OK;
+    }
     LmKernelArgs ka;
     memset(&ka, 0, sizeof(ka));
     ka.a.n_windows = p.B; ka.a.n_kf = 1;

@@ -208,6 +208,7 @@ struct PnpArgs {
     const float* xyz; const float* uv; const int32_t* n; int capacity; int B;
     double* T; int iters; double K[4]; double huber_delta; double reproj_thr;
     uint8_t* inlier; int32_t* n_inliers; vslam_lm_stats* stats;
+    int n_hint; // points per problem when the host knows it (0 = unknown): picks the kernel in launch_pnp
 };
 int launch_pnp(const PnpArgs& a, LmScratch* scratch, hipStream_t stream);
 // pnp_kernels.hip: EPnP of H 5-point subsets (one wave each) -> R|t (H x 12), pose (H x 7), ok flag; f32 inlier scoring of hypotheses
