@@ -100,6 +100,11 @@ static int dev_alloc(Ctx* c, T** p, size_t n) {
     return VSLAM_OK;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
 static int orb_status_check(Ctx* c, int B) {
     std::vector<int32_t> st(B);
     VS_HIP(hipMemcpyAsync(st.data(), c->orb.d_status, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
@@ -115,10 +120,11 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
     if (B <= 0) return VSLAM_OK;
     if (B > c->p.max_batch) { set_error("batch %d exceeds context max_batch %d", B, c->p.max_batch); return VSLAM_ERR_ARG; }
     int rc;
-    // with descriptors wanted, every level is staged once for both its successor and its blurred copy (orb_pyrblur_kernel);
-    // VSLAM_ORB_UNFUSED=1 (tuning aid) keeps the separate resize / blur kernels for A/B measurements
-    static const bool unfused = getenv("VSLAM_ORB_UNFUSED") != nullptr;
-    const bool fused = describe && !unfused;
+    // With descriptors wanted and a LARGE batch, every level is staged once for both its successor and its blurred copy
+    // (orb_pyrblur_kernel: 3 % faster at 512 images, a third less pyramid traffic).  Small batches keep the separate kernels: eight
+    // dependent launches that each do resize AND blur are slower than seven short resize launches + one blur launch over all levels
+    // (0.37 vs 0.47 ms for two images, break-even at ~300 images).  VSLAM_ORB_FUSE_MIN overrides the threshold (tests run both paths).
+    const bool fused = describe && B >= env_int("VSLAM_ORB_FUSE_MIN", 384);
     if (fused) { if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc; }
     else if ((rc = launch_orb_pyramid(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->stream))) return rc;
     if ((rc = launch_orb_fast(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->p.fast_threshold, c->orb.d_corners,
@@ -360,7 +366,12 @@ int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stri
     VS_HIP(hipMemcpyAsync(d_in, kps, sizeof(vslam_keypoint) * n, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
-    if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
+    const bool fused = 1 >= env_int("VSLAM_ORB_FUSE_MIN", 384); // (one image: the separate kernels unless a test forces the fused one)
+    if (fused) { if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc; }
+    else {
+        if ((rc = launch_orb_pyramid(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->stream))) return rc;
+        if ((rc = launch_orb_blur(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;
+    }
     if ((rc = launch_anms_flat(1, d_in, d_n, kc, 0, 1, w, h, d_kps, c->orb.d_cs, nullptr, kc, d_cnt, c->orb.d_status, c->orb.d_rad, c->stream))) return rc;
     if ((rc = launch_orb_describe(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, d_kps, c->orb.d_cs, nullptr, kc, d_cnt, d_desc, c->stream))) return rc;
     int32_t m = 0;

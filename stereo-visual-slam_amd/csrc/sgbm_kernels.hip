@@ -658,7 +658,11 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     int16_t* d0 = (int16_t*)(base + o_d0); int16_t* d1 = (int16_t*)(base + o_d1); int* par = (int*)(base + o_par); int* cnt = (int*)(base + o_cnt);
     const int vblocks = (dm.width1 * dm.D + 255) / 256;
     { ProfScope p(stream, "sgbm_prefilter_kernel"); hipLaunchKernelGGL(sgbm_prefilter_kernel, dim3((w + 255) / 256, h, 2 * B), dim3(256), 0, stream, dm, d_left, d_right, pre); }
-    static const bool unfused = getenv("VSLAM_SGBM_UNFUSED") != nullptr; // tuning aid: the separate hsum / vsum / path<0,1> kernels, for A/B runs
+    // The fused top-down kernel sweeps the rows sequentially with 48 workgroups per pair: it pays from 8 pairs per call on (2.65 vs 4.08 ms
+    // at 32 pairs); below that the three massively parallel kernels it replaces are faster (0.99 vs 1.31 ms for one pair).
+    // VSLAM_SGBM_FUSE_MIN overrides the threshold (tests run both paths).
+    const char* fuse_env = getenv("VSLAM_SGBM_FUSE_MIN");
+    const bool unfused = B < ((fuse_env && *fuse_env) ? atoi(fuse_env) : 8);
     if (!unfused) { ProfScope p(stream, "sgbm_down_kernel"); hipLaunchKernelGGL(sgbm_down_kernel, dim3((dm.width1 + kDnCols - 1) / kDnCols, B), dim3(kDnThreads), 0, stream, dm, pre, C, T); }
     if (unfused) { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3((dm.width1 + kHsSeg - 1) / kHsSeg, h, B), dim3(kHsBlock), 0, stream, dm, pre, hsum); }
     if (unfused) { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3((dm.width1 * 12 + 255) / 256, (h + kVsChunk - 1) / kVsChunk, B), dim3(256), 0, stream, dm, hsum, C); }

@@ -19,8 +19,11 @@ def kps_equal(x, y):
 
 def one_case(kind, rng, vo, pkg, O, synth):
     def fail(what, **kw):
-        raise Mismatch("MISMATCH %s %r" % (what, kw))
+        raise Mismatch("MISMATCH %s %r (fuse_min %s)" % (what, kw, os.environ.get("VSLAM_ORB_FUSE_MIN")))
     seed = int(rng.integers(1 << 30))
+    # the fused ORB / SGBM kernels are picked by batch size (large batches only); the fuzz cases are single items, so half of them force the fused path
+    forced = "1" if rng.random() < 0.5 else "1000000"
+    os.environ["VSLAM_ORB_FUSE_MIN"] = forced; os.environ["VSLAM_SGBM_FUSE_MIN"] = forced
     if kind == "match":
         nq, nt = int(rng.integers(1, 2200)), int(rng.integers(1, 2200))
         if rng.random() < 0.2: nq = int(rng.integers(1, 70))
@@ -102,6 +105,7 @@ def run(seconds=120.0, seed=0, only="", vo=None, max_cases=None, schedule=None):
             n[kind] += 1
             i += 1
     finally:
+        os.environ.pop("VSLAM_ORB_FUSE_MIN", None); os.environ.pop("VSLAM_SGBM_FUSE_MIN", None)
         if own:
             vo.close()
     return n

@@ -1,0 +1,90 @@
+"""The two fused kernels of round 3 (orb_pyrblur_kernel, sgbm_down_kernel) are chosen by batch size (large batches only: below ~300 images /
+8 stereo pairs the separate kernels are faster).  The parity suite runs small batches, so every check here is executed TWICE: with the
+thresholds forced down to 1 (fused kernels) and forced up (separate kernels) through VSLAM_ORB_FUSE_MIN / VSLAM_SGBM_FUSE_MIN, which
+the library reads on every call."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["1", "1000000"], ids=["fused", "separate"])
+def fuse_mode(request, monkeypatch):
+    monkeypatch.setenv("VSLAM_ORB_FUSE_MIN", request.param)
+    monkeypatch.setenv("VSLAM_SGBM_FUSE_MIN", request.param)
+    return request.param
+
+
+def _kps_equal(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_feature_detection_both_paths(fuse_mode, pkg, oracle, synth):
+    seq = synth.stereo_sequence(3, seed=0)
+    for img in (synth.noise_image(3), seq[1][0], seq[2][1]):
+        ctx = pkg.VO(device=0, max_batch=1, anms_num=1500)
+        try:
+            gk, gd = ctx.feature_detection(img)
+            wk, wd = oracle.feature_detection(img, 3000, 1500)
+            _kps_equal(gk, wk)
+            assert np.array_equal(gd, wd)
+        finally:
+            ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(257, 333), (200, 1324), (376, 1034)])
+def test_odd_sizes_both_paths(fuse_mode, pkg, oracle, synth, shape):
+    h, w = shape
+    img = synth.noise_image(17, w, h)
+    ctx = pkg.VO(device=0, max_batch=1, img_w=w, img_h=h, orb_nfeatures=1000, anms_num=300)
+    try:
+        gk, gd = ctx.feature_detection(img)
+        wk, wd = oracle.feature_detection(img, 1000, 300)
+        _kps_equal(gk, wk)
+        assert np.array_equal(gd, wd)
+        # user keypoints near the level borders (the descriptor's slow path reads the blurred level right up to its edge)
+        kps = oracle.orb_detect(img, 1000)[:48].copy()
+        kps["x"] = np.linspace(31, w - 32, len(kps)).astype(np.float32)
+        kps["y"] = np.where(np.arange(len(kps)) % 2 == 0, 31.0, h - 32.0).astype(np.float32)
+        kps["octave"] = np.arange(len(kps)) % 8
+        kps["angle"] = np.linspace(0, 359, len(kps)).astype(np.float32)
+        gk, gd = ctx.orb_compute(img, kps)
+        wk, wd = oracle.orb_compute(img, kps)
+        _kps_equal(gk, wk)
+        assert np.array_equal(gd, wd)
+    finally:
+        ctx.close()
+
+
+def test_sgbm_both_paths(fuse_mode, vo, oracle, synth):
+    for (w, h, sh) in ((640, 200, 11), (333, 97, 5), (1241, 120, 30)):
+        L = synth.noise_image(w % 97, w + 40, h)
+        Lc = np.ascontiguousarray(L[:, :w]); R = np.ascontiguousarray(L[:, sh:sh + w])
+        gf, gi, graw = vo.disparity_map(Lc, R, return_i16=True)
+        wi, wraw = oracle.sgbm_compute(Lc, R, return_raw=True)
+        assert np.array_equal(graw, wraw) and np.array_equal(gi, wi)
+
+
+def test_sgbm_batched_both_paths(fuse_mode, pkg, oracle, synth):
+    import torch
+    w, h, pitch, B = 400, 120, 448, 3
+    buf = np.zeros((2, B, h, pitch), np.uint8)
+    pairs = []
+    for b in range(B):
+        L = synth.noise_image(30 + b, w + 40, h)
+        Lc = np.ascontiguousarray(L[:, :w]); R = np.ascontiguousarray(L[:, 7 + b:7 + b + w])
+        buf[0, b, :, :w] = Lc; buf[1, b, :, :w] = R
+        pairs.append((Lc, R))
+    ctx = pkg.VO(device=0, max_batch=B)
+    try:
+        d = torch.from_numpy(buf).cuda()
+        out = torch.empty((B, h, w), dtype=torch.float32, device="cuda")
+        ctx.disparity_map_dev(d[0].data_ptr(), d[1].data_ptr(), h * pitch, pitch, w, h, B, out.data_ptr())
+        ctx.sync()
+        got = out.cpu().numpy()
+        for b, (Lc, R) in enumerate(pairs):
+            assert np.array_equal(got[b], oracle.disparity_map(Lc, R)), b
+    finally:
+        ctx.close()
