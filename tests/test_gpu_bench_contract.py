@@ -1,0 +1,48 @@
+"""GPU: bench.py prints ONE JSON line that carries the driver's contract fields, `roofline` and `cpu_baseline` (small batch so that
+the whole run takes well under a minute); `--depth sgbm` reports the SGBM family as its roofline line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]        # exactly one JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    r = _bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "16", "--unique-frames", "8")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["world_size"] == 1 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["unit"] == "keyframes/s" and r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - 16 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-3           # value = units / time
+    rf = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernel"] == "lm_window_kernel"
+    assert rf["copy_ceiling_gbs"] > 3000
+    cb = r["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["value"] > 0 and "cpu_model" in cb["host"] and "reference_libs_timing" in cb
+    assert r["pose_rmse_vs_oracle"]["integer_mismatches"] == 0
+    assert r["inputs_from_host"]["value"] > 0 and r["inputs_from_host"]["h2d_ms_per_step"] > 0
+    assert r["stats"]["orb_status_nonzero"] == 0 and r["stats"]["ba_status_nonzero"] == 0
+
+
+def test_bench_sgbm_depth_line():
+    r = _bench("--depth", "sgbm", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "8", "--unique-frames", "8", "--no-cpu-baseline", "--inputs", "resident")
+    assert r["roofline"]["kernel"].startswith("sgbm_* (family") and r["roofline"]["frac"] > 0
+    assert "sgbm_down_kernel" in r["kernels_ms_per_step"]        # 8 pairs per call: the fused top-down kernel
+    assert "SGBM" in r["config"]["workload"]
