@@ -1429,6 +1429,9 @@ int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes
 //   (2) the blurred level l (the register-streaming pass of orb_blur_kernel, unchanged).
 // The tile is staged with reflect-101 coordinates (what the blur needs); the resize clamps its row index itself and its column
 // tables never weight a pixel beyond the image, so the reflected halo is never interpolated.
+#ifndef VSLAM_ORB_BLUR_NT
+#define VSLAM_ORB_BLUR_NT 1 // non-temporal stores of the blurred pyramid (pyramid + blur 1.04 -> 1.02 ms, FAST 0.90 -> 0.89 ms per 512 images)
+#endif
 struct PyrBlurArgs {
     const uint8_t* src_base; size_t src_img_stride; int spitch, sw, sh;      // level l (raw)
     uint8_t* blur_base; size_t blur_img_stride; int bpitch;                  // blurred level l
@@ -1535,7 +1538,11 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
             const us2_t p01 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u)), lim);
             const us2_t p23 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u)), lim);
             const uint32_t px = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
+#if VSLAM_ORB_BLUR_NT
+            if (x < W) __builtin_nontemporal_store(px, reinterpret_cast<uint32_t*>(out + (size_t)(t - 6) * a.bpitch)); // read again only by the descriptor kernel, five kernels later
+#else
             if (x < W) *reinterpret_cast<uint32_t*>(out + (size_t)(t - 6) * a.bpitch) = px;
+#endif
         }
     }
 }
