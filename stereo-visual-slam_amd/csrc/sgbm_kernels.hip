@@ -218,6 +218,9 @@ __device__ inline void wta_row16(const SgbmDims& dm, int s0, int s1, int s2, int
 constexpr int kPathBlock = VSLAM_SGBM_PATH_BLOCK, kPathLines = kPathBlock / 16; // lines per workgroup (adjacent lines: one contiguous run of the volume per step)
 // Non-temporal loads / stores on the streamed volumes (every byte is touched once per kernel): the two diagonal paths gain 7-12 %
 // (1.90 -> 1.67, 1.74 -> 1.61 ms per 32 pairs), the two horizontal ones lose 3 % -- so NT is a property of the direction.
+#ifndef VSLAM_SGBM_H_NTST
+#define VSLAM_SGBM_H_NTST 1 // non-temporal STORES (not loads) on the horizontal paths: 1.69 -> 1.65 ms for the left-to-right path
+#endif
 template <bool NT>
 __device__ inline U3 ld_u3(const void* p) {
     if constexpr (NT) {
@@ -235,7 +238,8 @@ __device__ inline void st_u3(void* p, U3 v) {
 template <int DX, int DY, int MODE, int kPathPF>
 __global__ __launch_bounds__(kPathBlock) void sgbm_path_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* T, int nlines, int4* __restrict__ rec) {
     const int b = blockIdx.y;
-    constexpr bool kNT = DX != 0 && DY != 0;
+    constexpr bool kNT = DX != 0 && DY != 0;            // loads (and stores) of the diagonal paths
+    constexpr bool kNTst = kNT || (VSLAM_SGBM_H_NTST != 0); // stores of the horizontal paths (tuning macro)
     const int line = blockIdx.x * kPathLines + (threadIdx.x >> 4), r = threadIdx.x & 15;
     if (line >= nlines) return; // whole DPP row leaves
     const int W1 = dm.width1, h = dm.h;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(kPathBlock) void sgbm_path_kernel(SgbmDims dm, cons
                     else // last path: S is complete -- pick the winner here instead of storing it
                         wta_row16(dm, f0, f1, f2, f3, f4, f5, r, ((size_t)b * h + y0) * dm.w + dm.minX1 + x0 + (s + k) * DX, rec, s + k < len);
                 }
-                if (MODE != 4 && s + k < len) st_u3<kNT>(tp + (ptrdiff_t)(s + k) * step, o);
+                if (MODE != 4 && s + k < len) st_u3<kNTst>(tp + (ptrdiff_t)(s + k) * step, o);
             }
         }
     }
