@@ -501,7 +501,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_gbs": round(copy_gbs, 1), "copy_probe": copy_probe, "copy_ceiling_guide_gbs": 6290.0, "frac_of_copy_ceiling": round(achieved / copy_gbs, 6) if copy_gbs > 0 else None,
                          "algorithmic_bytes_per_launch_set": int(alg), "formula": formula,
-                         "avg_ms_per_launch_set": round(1e3 * per_bracket_s, 4), "kernel_launches_per_set": dom_launches // max(dom_calls, 1)},
+                         "avg_ms_per_launch_set": round(1e3 * per_bracket_s, 4), "kernel_launches_per_set": dom_launches // max(dom_calls, 1),
+                         "launch_set": ("one BA schedule = 3 x lm_window_kernel (optimize_map, 5 + 5 + 10 iterations) + 1 x pose_only_wave_kernel (10 iterations)"
+                                        if dom == "lm_window_kernel" else "one stage bracket")},
             "kernels_ms_per_step": {k: round(v[0] / n_prof_steps, 4) for k, v in kern},
             "other_rooflines": other_rooflines(prof, pipe, args, n_prof_steps, copy_gbs),
             "stats": {"keypoints_per_image": float(out["cnt"].mean()), "lr_matches": float(out["nlr"].mean()), "lr_matches_min": int(out["nlr"].min()),

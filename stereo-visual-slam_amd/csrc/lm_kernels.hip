@@ -1635,6 +1635,332 @@ __global__ __launch_bounds__(64) void pnp_wave_kernel(const float* __restrict__ 
     if (lane == 0 && n_inl) n_inl[b] = mine;
 }
 
+// ------------------------------------------------------------------------------------------- lean pose-only pass of the schedule
+// pose_only_wave_kernel: optimize_pose_only (optimization.cpp:290-436) as the LAST pass of the per-keyframe schedule (run_vslam.cpp:67-70),
+// one workgroup per window, ONE WAVE PER KEYFRAME.  With the landmarks fixed the keyframes only share lambda, the gain ratio and the
+// accept / reject decision; the window kernel nevertheless ran its general machinery for it (keyframe-major lists with the Schur hit lists'
+// bookkeeping, 8 waves dealt over rows of all keyframes, per-(keyframe, wave) partial sums, ~10 barriers per iteration: 0.57 ms of the
+// 4.15 ms schedule).  Here a setup of two ballot scans cuts the window's active edges (landmark still an inlier, :334) into per-keyframe
+// runs -- edge id, observation and the landmark position (f32 at rest, constant in this pass) copied keyframe-major, so the iteration
+// streams 24 contiguous bytes per edge and gathers nothing -- and wave k then runs keyframe k's motion-only problem exactly like
+// pnp_wave_kernel: 27 sums through one butterfly straight into LDS, 6x6 solve in every lane, trial evaluation that also linearises (an
+// accepted trial needs no second pass).  Per trial two barriers: the "some 6x6 factorisation failed" flag, and the per-keyframe chi2 /
+// scale partials, summed in keyframe order by every wave.  Then the chi2 classification (:224-266) -- at the state of the last EVALUATED
+// trial, g2o's quirk, like the window kernel.  Runs only behind the three optimize_map passes of a schedule: they have validated the graph
+// (status word) and nothing here needs the landmark CSR.
+constexpr int kPoBlock = 64 * kMaxKf;
+struct PoShared {
+    double H[2][kMaxKf][36], g[2][kMaxKf][6];
+    double part[2][kMaxKf], spart[2][kMaxKf];
+    int cnt[kMaxKf][kMaxKf];
+    int kbeg[kMaxKf + 1];
+    int flag[2];
+    int cin[2][kMaxKf], cout[2][kMaxKf];
+    double T[2][kMaxKf][7], R[3][kMaxKf][12];
+};
+__global__ __launch_bounds__(kPoBlock) void pose_only_wave_kernel(LmKernelArgs ka, int iters, int update_poses) {
+    const LmWindowArgs& a = ka.a;
+    __shared__ PoShared sm;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (ka.status[w] != VSLAM_OK) return; // uniform: the first pass of the schedule rejected this window
+    long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + 16 * (size_t)w : nullptr; // tuning aid (VSLAM_LM_PROFILE=1): slots 0..6 of this pass
+    long long t_ph = cyc ? clock64() : 0;
+#define POH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); cyc[i] += t1__ - t_ph; t_ph = t1__; } } while (0)
+    const int nk = a.n_kf;
+    const int lm0 = a.lm_off[w], e0 = a.edge_off[w], ne = a.edge_off[w + 1] - e0;
+    const int32_t* kfi = a.kf_idx + e0;
+    const int32_t* lmi = a.lm_idx + e0;
+    const float2* uv2 = reinterpret_cast<const float2*>(a.uv) + e0;
+    const float* xyz = a.xyz + 3 * (size_t)lm0;
+    uint8_t* inl = a.lm_inlier + lm0;
+    int32_t* list = a.kf_edges + e0;                                   // keyframe-major position -> edge id
+    float2* uvk = reinterpret_cast<float2*>(ka.uvk) + e0;              // ... -> observation
+    float4* posk = reinterpret_cast<float4*>(a.lin) + e0;              // ... -> landmark position (16 B of the 16 B-per-edge linearisation scratch)
+    double* chik = ka.chi2k + e0;                                      // ... -> chi2 at the final state
+    const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
+    const CamK ck = make_camk(K);
+    const double delta = a.huber_delta;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // ---- setup: per-keyframe runs of the active edges (ascending edge id inside a keyframe), two ballot scans over this wave's chunk
+    const int per = (((ne + kMaxKf - 1) / kMaxKf) + 63) & ~63;
+    const int c0 = min(wave * per, ne), c1 = min(c0 + per, ne);
+    {
+        int cnt[kMaxKf];
+#pragma unroll
+        for (int k = 0; k < kMaxKf; ++k) cnt[k] = 0;
+        for (int base = c0; base < c1; base += 256) { // four rows per trip: ids first, then the flags they point at (two dependent round trips per TRIP)
+            int kq[4], lq[4]; bool vq[4]; uint8_t iq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = base + 64 * u + lane; vq[u] = e < c1; const int es = min(e, ne - 1); kq[u] = kfi[es]; lq[u] = lmi[es]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) iq[u] = inl[lq[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool act = vq[u] && iq[u] != 0;
+#pragma unroll
+                for (int kk = 0; kk < kMaxKf; ++kk) cnt[kk] += __popcll(__ballot(act && kq[u] == kk));
+            }
+        }
+        if (lane < kMaxKf) {
+            int v = 0;
+#pragma unroll
+            for (int kk = 0; kk < kMaxKf; ++kk) if (lane == kk) v = cnt[kk];
+            sm.cnt[wave][lane] = v;
+        }
+        if (tid < 2) sm.flag[tid] = 0;
+    }
+    __syncthreads();
+    int off[kMaxKf]; // write offset of this wave's chunk inside every keyframe's run
+    {
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxKf; ++k) {
+            int before = 0, tot = 0;
+#pragma unroll
+            for (int c = 0; c < kMaxKf; ++c) { const int v = sm.cnt[c][k]; tot += v; if (c < wave) before += v; }
+            off[k] = run + before;
+            if (tid == 0) sm.kbeg[k] = run;
+            run += tot;
+        }
+        if (tid == 0) sm.kbeg[kMaxKf] = run;
+    }
+    for (int base = c0; base < c1; base += 256) {
+        int kq[4], lq[4], eq[4]; bool vq[4]; uint8_t iq[4]; float2 zq[4]; float Xq[4], Yq[4], Zq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = base + 64 * u + lane; vq[u] = e < c1; eq[u] = e;
+            const int es = min(e, ne - 1);
+            kq[u] = kfi[es]; lq[u] = lmi[es]; zq[u] = uv2[es];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { iq[u] = inl[lq[u]]; Xq[u] = xyz[3 * lq[u]]; Yq[u] = xyz[3 * lq[u] + 1]; Zq[u] = xyz[3 * lq[u] + 2]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool act = vq[u] && iq[u] != 0;
+#pragma unroll
+            for (int kk = 0; kk < kMaxKf; ++kk) {
+                const unsigned long long m = __ballot(act && kq[u] == kk);
+                if (act && kq[u] == kk) {
+                    const int pos = off[kk] + __popcll(m & lt_mask);
+                    list[pos] = eq[u]; uvk[pos] = zq[u]; posk[pos] = make_float4(Xq[u], Yq[u], Zq[u], 0.f);
+                }
+                off[kk] += __popcll(m);
+            }
+        }
+    }
+    __syncthreads();
+    POH(0);
+    const int ntot = sm.kbeg[kMaxKf];
+    const bool mine = wave < nk;                          // this wave owns keyframe `wave`
+    const int kb = mine ? sm.kbeg[wave] : 0, ke = mine ? sm.kbeg[wave + 1] : 0;
+    // poses live in LDS (current / trial / last evaluated trial per keyframe) and reach the evaluation loop through scalar registers:
+    // held in VGPRs next to the 27 accumulators they spilled (168 registers per lane at 12 waves per workgroup)
+    {
+        double T[7], Rt[12];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) T[i] = a.T[((size_t)w * nk + min(wave, nk - 1)) * 7 + i];
+        expand_pose(T, Rt);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sm.T[0][wave][i] = T[i];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { sm.R[0][wave][i] = Rt[i]; sm.R[2][wave][i] = Rt[i]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int slot27 = wave_slot<27>(lane);
+    // robust cost of this keyframe's edges at pose R; LIN: its 6x6 block and right-hand side into sm.H[buf][wave], sm.g[buf][wave];
+    // CHI: chi2 per edge into chik (keyframe-major)
+    auto evaluate = [&](const double* Rlds, bool lin, int buf, bool store_chi) -> double {
+        double R[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) R[i] = uniform_f64(Rlds[i]);
+        double part = 0, acc[27];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) acc[i] = 0;
+        // two edges per lane per trip; the operands of the NEXT trip are requested before this trip's arithmetic (three waves per SIMD
+        // do not cover a memory round trip per trip on their own)
+        float4 pp[2], pn[2]; float2 zz[2], zn[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int j = min(kb + 64 * u + lane, max(ke - 1, 0)); pp[u] = posk[j]; zz[u] = uvk[j]; }
+        for (int j0 = kb; j0 < ke; j0 += 128) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int j = min(j0 + 128 + 64 * u + lane, ke - 1); pn[u] = posk[j]; zn[u] = uvk[j]; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + 64 * u + lane;
+                if (j >= ke) continue;
+                double x, y, ri, wgt, ex, ey, c, rho;
+                cam_norm(R, (double)pp[u].x, (double)pp[u].y, (double)pp[u].z, x, y, ri);
+                eval_obs(ck, x, y, zz[u], delta, ex, ey, c, rho, wgt);
+                part += rho;
+                if (store_chi) chik[j] = c;
+                if (lin) {
+                    double A[12], wA[12];
+                    jac_norm(x, y, ri, A);
+                    const double l0 = wgt * ck.fx2, l1 = wgt * ck.fy2;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { wA[i] = l0 * A[i]; wA[6 + i] = l1 * A[6 + i]; }
+                    int idx = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int cc = r; cc < 6; ++cc) { acc[idx] = a_fma_pair(wA, r, A, cc, acc[idx]); ++idx; }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc[21 + r] = a_fma2(wA, r, -ex, -ey, acc[21 + r]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { pp[u] = pn[u]; zz[u] = zn[u]; }
+        }
+        const double total = wave_sum(part);
+        if (lin && mine) {
+            wave_reduce_scatter<27>(acc, lane);
+            if (slot27 >= 0 && slot27 < 21) {
+                int r = 0, rem = slot27;
+                while (rem >= 6 - r) { rem -= 6 - r; ++r; }
+                const int cc = r + rem;
+                sm.H[buf][wave][6 * r + cc] = acc[0]; sm.H[buf][wave][6 * cc + r] = acc[0];
+            } else if (slot27 >= 21) sm.g[buf][wave][slot27 - 21] = acc[0];
+        }
+        return total;
+    };
+    auto sum_kf = [&](const double* v) -> double { // keyframe order: the same sum in every wave
+        double t = 0;
+        for (int k = 0; k < nk; ++k) t += v[k];
+        return t;
+    };
+    vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
+    double lambda = 0, ni = 2, currentChi = 0;
+    int pc = 0; // which of sm.T / sm.R [0], [1] holds the current pose; sm.R[2] = the last evaluated trial (g2o's edge errors reflect it)
+    int cur = 0, it = 0, total_trials = 0, pb = 0, fb = 0;
+    if (iters > 0) { // the initial state goes through the same evaluation + linearisation
+        const double c = evaluate(sm.R[pc][wave], true, cur, false);
+        if (lane == 0 && mine) sm.part[pb][wave] = c;
+        __syncthreads();
+        currentChi = sum_kf(sm.part[pb]);
+        pb ^= 1;
+        double md = 0;
+        for (int k = 0; k < nk; ++k)
+#pragma unroll
+            for (int d = 0; d < 6; ++d) md = fmax(md, fabs(sm.H[cur][k][7 * d]));
+        lambda = 1e-5 * md;
+        if (st && tid == 0) st->chi2_init = currentChi;
+    }
+    POH(1);
+    for (it = 0; it < iters; ++it) {
+        double rho_gain = 0;
+        int qmax = 0;
+        bool again = true;
+        while (again) {
+            double x[6] = {0, 0, 0, 0, 0, 0};
+            if (mine) {
+                double Hk[36], gk[6];
+#pragma unroll
+                for (int i = 0; i < 36; ++i) Hk[i] = sm.H[cur][wave][i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) gk[i] = sm.g[cur][wave][i];
+                if (!chol6_solve(Hk, lambda, gk, x) && lane == 0) sm.flag[fb] = 1;
+            }
+            POH(2);
+            __syncthreads();
+            POH(3);
+            const bool ok2 = sm.flag[fb] == 0;
+            if (tid == 0) sm.flag[fb ^ 1] = 0; // (last read before the previous trial's second barrier, next written after this trial's)
+            fb ^= 1;
+            if (!ok2) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) x[i] = 0;
+            }
+            {
+                double E[7], Tc[7], Tt[7], Rtt[12];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) Tc[i] = sm.T[pc][wave][i];
+                se3::exp(x, E);
+                se3::mul(E, Tc, Tt);
+                expand_pose(Tt, Rtt);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) sm.T[pc ^ 1][wave][i] = Tt[i];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) { sm.R[pc ^ 1][wave][i] = Rtt[i]; sm.R[2][wave][i] = Rtt[i]; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            POH(4);
+            const double c = evaluate(sm.R[pc ^ 1][wave], true, cur ^ 1, false);
+            POH(5);
+            double sc = 0;
+            if (mine) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) sc += x[i] * (lambda * x[i] + sm.g[cur][wave][i]);
+            }
+            if (lane == 0 && mine) { sm.part[pb][wave] = c; sm.spart[pb][wave] = sc; }
+            __syncthreads();
+            POH(6);
+            double tempChi = sum_kf(sm.part[pb]);
+            const double scale = sum_kf(sm.spart[pb]) + 1e-3;
+            pb ^= 1;
+            if (!ok2) tempChi = 1.7976931348623157e308;
+            rho_gain = (currentChi - tempChi) / scale;
+            if (rho_gain > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow(2 * rho_gain - 1, 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                pc ^= 1;
+                cur ^= 1;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+            }
+            ++qmax;
+            again = (rho_gain < 0) && qmax < 10;
+        }
+        total_trials += qmax;
+        if (st && tid == 0 && it < VSLAM_LM_MAX_ITERS) { st->chi2_iter[it] = currentChi; st->lambda_iter[it] = lambda; st->trials_iter[it] = qmax; }
+        if (qmax == 10 || rho_gain == 0) { ++it; break; }
+    }
+    if (st && tid == 0) { st->iterations = it; st->total_trials = total_trials; st->chi2_final = currentChi; st->lambda_final = lambda; }
+    POH(7);
+    // ---- chi2 of every active edge at the last evaluated state, then the adaptive threshold (optimization.cpp:224-252)
+    evaluate(sm.R[2][wave], false, 0, true);
+    double th = delta; // :154: chi2_th is both the Huber delta and the initial classification threshold
+    int cb = 0;
+    for (int iteration = 0; iteration < 5; ++iteration) {
+        int cin = 0, cout = 0;
+        for (int j = kb + lane; j < ke; j += 64) { if (chik[j] > th) ++cout; else ++cin; }
+        for (int o = 32; o > 0; o >>= 1) { cin += __shfl_xor(cin, o); cout += __shfl_xor(cout, o); }
+        if (lane == 0) { sm.cin[cb][wave] = mine ? cin : 0; sm.cout[cb][wave] = mine ? cout : 0; }
+        __syncthreads();
+        int tin = 0, tout = 0;
+        for (int k = 0; k < nk; ++k) { tin += sm.cin[cb][k]; tout += sm.cout[cb][k]; }
+        cb ^= 1;
+        const double ratio = (double)tin / (double)(tin + tout);
+        if (ratio > 0.5) break; // uniform
+        th *= 2;
+    }
+    if (ka.want_chi2) { // chi2 in the caller's edge order, 0 for the edges of excluded landmarks (the flags are still the pass's input here)
+        double* chi2 = a.chi2 + e0;
+        for (int e = tid; e < ne; e += kPoBlock) if (!inl[lmi[e]]) chi2[e] = 0.0;
+        for (int j = kb + lane; j < ke; j += 64) chi2[list[j]] = chik[j];
+    }
+    __syncthreads();
+    // the last edge of a landmark decides its flag (:254-266, ascending edge order; the edges are sorted by landmark)
+    for (int j = kb + lane; j < ke; j += 64) {
+        const int e = list[j];
+        if (e == ne - 1 || lmi[e + 1] != lmi[e]) inl[lmi[e]] = !(chik[j] > th);
+    }
+    if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
+    if (update_poses && mine && lane < 7) a.T[((size_t)w * nk + wave) * 7 + lane] = sm.T[pc][wave][lane];
+    POH(8);
+    (void)ntot;
+#undef POH
+}
+
 // (LmScratch, owned by the context and grown on demand, is declared in vslam_internal.h)
 static int ensure(void** p, size_t* have, size_t need) {
     if (*have >= need) return VSLAM_OK;
@@ -1712,7 +2038,13 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0);
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 1); // (the landmark CSR of the first launch is still valid)
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 10, 1, 0, 1, 1);
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1);
+        // the pose-only pass: one wave per keyframe (pose_only_wave_kernel); VSLAM_POSE_ONLY_WINDOW=1 (tuning aid) keeps the window kernel
+        static const bool po_window = getenv("VSLAM_POSE_ONLY_WINDOW") != nullptr;
+        if (po_window) hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1);
+        else {
+            if (ka.dbg_cycles && getenv("VSLAM_PO_PROFILE")) hipMemsetAsync(ka.dbg_cycles, 0, sizeof(long long) * 16 * a.n_windows, stream); // show only this pass
+            hipLaunchKernelGGL(pose_only_wave_kernel, dim3(a.n_windows), dim3(kPoBlock), 0, stream, ka, 10, 1);
+        }
     } else {
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, mode, iters, update_poses, update_lms, 1, 0);
     }
