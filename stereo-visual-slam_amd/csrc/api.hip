@@ -172,7 +172,7 @@ const char* vslam_version(void) { return "vslam_hip 0.3 (gfx950, ABI 3)"; }
 int vslam_abi_version(void) { return VSLAM_ABI_VERSION; }
 const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tests/test_abi.py checks the list against the sources)
     return "orb_resize_kernel orb_pyrblur_kernel orb_fast_kernel orb_select_kernel orb_anms_kernel orb_orient_kernel orb_blur_kernel orb_describe_kernel "
-           "match_train_nearest_kernel match_finalize_kernel sgbm_prefilter_kernel sgbm_down_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel "
+           "match_train_nearest_kernel match_finalize_kernel sgbm_prefilter_kernel sgbm_down_kernel sgbm_forward_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel "
            "sgbm_wta_kernel sgbm_lrcheck_kernel sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel "
            "sgbm_ccl_apply_kernel sgbm_ccl_kernels triangulate_kernel find3d_disparity_kernel gather_uv_kernel build_pnp_inputs_kernel lm_window_kernel pose_only_wave_kernel "
            "lm_window_kernel<pnp> pnp_wave_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel";

@@ -309,6 +309,197 @@ __global__ __launch_bounds__(kPathBlock) void sgbm_path_kernel(SgbmDims dm, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------- fused forward pass (4 of the 5 paths)
+// sgbm_forward_kernel: the four paths whose predecessor lies earlier in raster order -- (1,0), (1,1), (0,1), (-1,1) -- in ONE sweep that
+// reads C once and writes S1 = sat16(L0 + L1 + L2 + L3) once.  The per-path kernels are HBM-bound (4.9 TB/s of a 5.8 TB/s copy ceiling)
+// and each of them re-reads C and reads + writes the running sum: 26.5 GB per 32 pairs for these four paths against 5.3 GB here.
+//
+// Parallelism is the skewed wavefront t = x + 2 y: pixel (x, y) needs (x-1, y) [step t-1], (x+1, y-1) [t-1], (x, y-1) [t-2] and
+// (x-1, y-1) [t-3], so all pixels of one t are independent.  A workgroup owns a slab of 64 image rows, one 16-lane DPP row per image
+// row (6 disparities per lane, as in the line kernels): the (1,0) path lives in the row's own registers; after every step a row leaves
+// its three downward L vectors (36 B per lane) in an LDS slot, the row below picks them up one step later and delays (0,1) by one and
+// (1,1) by two more steps in registers.  One barrier per step, two LDS slots per row.
+//
+// Slabs of one pair are chained through memory: the last row of slab k writes its downward vectors per pixel into a boundary buffer and
+// publishes its progress every 32 pixels (release fence + flag); slab k+1 stages the records 32 at a time into LDS, one chunk ahead,
+// with device-scope loads, after its first lane has seen the flag pass the chunk.  A workgroup only ever waits for the workgroup with
+// the next lower index, workgroups are dispatched in index order, so the lowest unfinished one is always resident and never waits:
+// no co-residency requirement, no deadlock.  (A spin limit turns a violated assumption into a trap instead of a hang.)
+#ifndef VSLAM_SGBM_FW_CHUNK
+#define VSLAM_SGBM_FW_CHUNK 32
+#endif
+#ifndef VSLAM_SGBM_FW_PF
+#define VSLAM_SGBM_FW_PF 4
+#endif
+constexpr int kFwChunk = VSLAM_SGBM_FW_CHUNK, kFwPF = VSLAM_SGBM_FW_PF;
+constexpr int kFwRecDw = 16 * 9;                       // boundary record of one pixel: 16 lanes x 3 paths x 3 dwords
+template <int kFwRows>
+struct FwShared {
+    uint32_t slot[2][kFwRows][16 * 9]; // [step parity][row][lane][path (-1,1), (0,1), (1,1)][3 dwords]
+    uint32_t bnd[2][kFwChunk * kFwRecDw];
+};
+// The recurrence in packed 16-bit arithmetic (two disparities per register: L in [-P2, Cmax], delta <= Cmax + P2, kSent + P1 < 2^15 --
+// nothing leaves int16).  The vectors arrive packed from the volume and from the row above and leave packed: no unpacking at all.
+struct FwVec { short2v p[3]; }; // disparities (6r, 6r+1), (6r+2, 6r+3), (6r+4, 6r+5)
+__device__ inline short2v fw_s2(uint32_t v) { return __builtin_bit_cast(short2v, v); }
+__device__ inline uint32_t fw_u(short2v v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline FwVec fw_vec(uint32_t a, uint32_t b, uint32_t c) { return FwVec{{fw_s2(a), fw_s2(b), fw_s2(c)}}; }
+template <int CTRL>
+__device__ inline int fw_min_dpp(int v) { // v = min(v, v of the DPP-selected lane) (every lane has a source: quad_perm / mirrors)
+    return min(v, __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true));
+}
+// nb_lo / nb_hi: the registers the neighbour lanes' edge disparities are shifted into.  Lane 0 (15) has no source for row_shr (row_shl)
+// and keeps what it held: the registers start as kSent pairs and are only ever written by these shifts, so the edge lanes read kSent
+// for ever -- without re-materialising the constant before every shift.
+__device__ inline FwVec fw_path(const FwVec& l, const FwVec& c, short2v P1v, int P2, uint32_t& nb_lo, uint32_t& nb_hi) {
+    const short2v m2 = __builtin_elementwise_min(__builtin_elementwise_min(l.p[0], l.p[1]), l.p[2]);
+    int m = (int)min(m2.x, m2.y);
+    m = fw_min_dpp<0xB1>(m); m = fw_min_dpp<0x4E>(m); m = fw_min_dpp<0x141>(m); m = fw_min_dpp<0x140>(m);
+    const short dl = (short)(m + P2);
+    const short2v delta = {dl, dl};
+    nb_lo = (uint32_t)dpp_mov<0x111>((int)nb_lo, (int)fw_u(l.p[2])); // lane r - 1's (d4, d5): its high half is disparity 6r - 1
+    nb_hi = (uint32_t)dpp_mov<0x101>((int)nb_hi, (int)fw_u(l.p[0])); // lane r + 1's (d0, d1): its low half is disparity 6r + 6
+    const short2v dn0 = fw_s2(__builtin_amdgcn_alignbit(fw_u(l.p[0]), nb_lo, 16));           // (d-1, d0)
+    const short2v dn1 = fw_s2(__builtin_amdgcn_alignbit(fw_u(l.p[1]), fw_u(l.p[0]), 16));    // (d1, d2)
+    const short2v dn2 = fw_s2(__builtin_amdgcn_alignbit(fw_u(l.p[2]), fw_u(l.p[1]), 16));    // (d3, d4)
+    const short2v up2 = fw_s2(__builtin_amdgcn_alignbit(nb_hi, fw_u(l.p[2]), 16));           // (d5, d6)
+    FwVec n;
+    n.p[0] = (c.p[0] - delta) + __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_min(dn0, dn1) + P1v, l.p[0]), delta);
+    n.p[1] = (c.p[1] - delta) + __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_min(dn1, dn2) + P1v, l.p[1]), delta);
+    n.p[2] = (c.p[2] - delta) + __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_min(dn2, up2) + P1v, l.p[2]), delta);
+    return n;
+}
+template <int kFwRows> // image rows per slab = DPP rows per workgroup: 64 for throughput, 32 when the batch alone cannot fill the chip (shorter steps, twice the workgroups)
+__global__ __launch_bounds__(kFwRows * 16) void sgbm_forward_kernel(SgbmDims dm, const int16_t* __restrict__ C, int16_t* __restrict__ S1,
+                                                                     uint32_t* bndg, int* flags, int nslab) {
+    constexpr int kFwThreads = kFwRows * 16;
+    constexpr int kFwStage = (kFwChunk * kFwRecDw + kFwThreads - 1) / kFwThreads; // dwords per thread of one staged chunk
+    __shared__ FwShared<kFwRows> sm;
+    const int b = blockIdx.x / nslab, slab = blockIdx.x - b * nslab;
+    const int tid = threadIdx.x, row_l = tid >> 4, r = tid & 15;
+    const int W1 = dm.width1, h = dm.h;
+    const int y = slab * kFwRows + row_l;
+    const bool rowok = y < h;
+    const int P1 = dm.P1, P2 = dm.P2;
+    const size_t rowbase = (((size_t)b * h + min(y, h - 1)) * W1) * 96 + 6 * r;
+    const int16_t* cp = C + rowbase;
+    int16_t* sp = S1 + rowbase;
+    const bool has_pred = slab > 0, has_succ = slab + 1 < nslab;
+    // Boundary records: pixel x >= 1 of a slab's last row lives at index x - 1 of a run padded to whole chunks (pixel 0, which the row
+    // below needs once, before its first step, sits in a chunk of its own behind the run), so that chunk c of the reader (pixels 32 c + 1 .. 32 c + 32) is a run of WHOLE cache lines (32 x 576 B =
+    // 144 lines).  The reader's L2 may keep what it fetched: a line shared by two chunks would be fetched with the first, before the
+    // second's records exist, and served stale afterwards (device-scope loads do not re-fetch lines another XCD has written since).
+    const size_t bnd_rec0 = (size_t)((W1 + kFwChunk - 1) / kFwChunk) * kFwChunk * kFwRecDw, bnd_run = bnd_rec0 + (size_t)kFwChunk * kFwRecDw;
+    const uint32_t* bnd_in = bndg + ((size_t)b * (nslab - 1) + max(slab - 1, 0)) * bnd_run;
+    uint32_t* bnd_out = bndg + ((size_t)b * (nslab - 1) + max(min(slab, nslab - 2), 0)) * bnd_run + r * 9;
+    int* flag_in = flags + blockIdx.x - 1;
+    int* flag_out = flags + blockIdx.x;
+    const bool writer = has_succ && row_l == kFwRows - 1; // (only the last slab has fewer than 64 image rows, and it has no successor)
+    // wait until the slab above has published `need` pixels of its last row (first lane only; the workgroup follows through a barrier)
+    auto wait_pred = [&](int need) {
+        if (has_pred && tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1 << 24)) __builtin_trap(); // ~10 s: the dispatch-order assumption does not hold
+            }
+        }
+        __syncthreads();
+    };
+    // records first .. first + 31 of the slab above (device-scope loads: they were written by another workgroup, possibly through another L2)
+    uint32_t stage[kFwStage];
+    auto stage_load = [&](int first) {
+#pragma unroll
+        for (int q = 0; q < kFwStage; ++q) {
+            const int dw = tid + q * kFwThreads;
+            const int rec = first + dw / kFwRecDw;
+            stage[q] = 0;
+            if (has_pred && dw < kFwChunk * kFwRecDw && rec < W1)
+                stage[q] = __hip_atomic_load(bnd_in + (size_t)(first - 1) * kFwRecDw + dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < kFwStage; ++q) { const int dw = tid + q * kFwThreads; if (dw < kFwChunk * kFwRecDw) sm.bnd[buf][dw] = stage[q]; }
+    };
+    for (int i = tid; i < 2 * kFwRows * 16 * 9; i += kFwThreads) (&sm.slot[0][0][0])[i] = 0;
+    // chunk 0 = records 1 .. 32 (row 0 at step t reads the record of pixel t + 1)
+    wait_pred(min(W1, 1 + kFwChunk));
+    stage_load(1);
+    stage_store(0);
+    __syncthreads();
+    U3 cq[kFwPF];
+#pragma unroll
+    for (int k = 0; k < kFwPF; ++k) cq[k] = ld_u3<true>(cp + (size_t)min(max(k - 2 * row_l, 0), W1 - 1) * 96);
+    FwVec l10 = {{short2v{0, 0}, short2v{0, 0}, short2v{0, 0}}};
+    const short2v P1v = {(short)dm.P1, (short)dm.P1};
+    uint32_t nb_lo = (uint32_t)kSent | ((uint32_t)kSent << 16), nb_hi = nb_lo;
+    uint32_t h01[3] = {0, 0, 0}, h11a[3] = {0, 0, 0}, h11b[3] = {0, 0, 0};
+    if (has_pred && row_l == 0) { // pixel 0 of the row above: what an inner row picks up in the two steps before its own first pixel
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            h01[q] = __hip_atomic_load(bnd_in + bnd_rec0 + r * 9 + 3 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h11a[q] = __hip_atomic_load(bnd_in + bnd_rec0 + r * 9 + 6 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const int nsteps = W1 + 2 * (kFwRows - 1);
+    for (int t0 = 0; t0 < nsteps; t0 += kFwChunk) {
+        const int chunk = t0 / kFwChunk;
+        wait_pred(min(W1, 1 + (chunk + 2) * kFwChunk));        // records of chunk + 1: pixels 32 (chunk + 1) + 1 .. + 32
+        stage_load(1 + (chunk + 1) * kFwChunk);
+        for (int u0 = 0; u0 < kFwChunk; u0 += kFwPF) {
+#pragma unroll
+            for (int k = 0; k < kFwPF; ++k) {
+                const int t = t0 + u0 + k, x = t - 2 * row_l;
+                const bool act = rowok && x >= 0 && x < W1;
+                const U3 c3 = cq[k];
+                cq[k] = ld_u3<true>(cp + (size_t)min(max(x + kFwPF, 0), W1 - 1) * 96);
+                // what the row above left behind one step ago: its L of pixel x + 1
+                const uint32_t* src = row_l == 0 ? &sm.bnd[chunk & 1][(t & (kFwChunk - 1)) * kFwRecDw + r * 9] : &sm.slot[(t + 1) & 1][row_l - 1][r * 9];
+                uint32_t a[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) a[q] = src[q];
+                const FwVec cv = fw_vec(c3.a, c3.b, c3.c);
+                FwVec n10 = fw_path(l10, cv, P1v, P2, nb_lo, nb_hi);
+                const FwVec nm = fw_path(fw_vec(a[0], a[1], a[2]), cv, P1v, P2, nb_lo, nb_hi);           // (-1, 1): from (x + 1, y - 1), one step old
+                const FwVec n01 = fw_path(fw_vec(h01[0], h01[1], h01[2]), cv, P1v, P2, nb_lo, nb_hi);    // (0, 1):  from (x, y - 1), two steps old
+                const FwVec n11 = fw_path(fw_vec(h11b[0], h11b[1], h11b[2]), cv, P1v, P2, nb_lo, nb_hi); // (1, 1):  from (x - 1, y - 1), three steps old
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { h01[q] = a[3 + q]; h11b[q] = h11a[q]; h11a[q] = a[6 + q]; }
+                uint32_t* dst = &sm.slot[t & 1][row_l][r * 9];
+                if (act) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { dst[q] = fw_u(nm.p[q]); dst[3 + q] = fw_u(n01.p[q]); dst[6 + q] = fw_u(n11.p[q]); }
+                    l10 = n10;
+                    // sat16 of the four-term sum: the two pair sums cannot overflow int16 (|L| < 2^14), one saturating add finishes
+                    U3 s3;
+                    s3.a = fw_u(__builtin_elementwise_add_sat(n10.p[0] + nm.p[0], n01.p[0] + n11.p[0]));
+                    s3.b = fw_u(__builtin_elementwise_add_sat(n10.p[1] + nm.p[1], n01.p[1] + n11.p[1]));
+                    s3.c = fw_u(__builtin_elementwise_add_sat(n10.p[2] + nm.p[2], n01.p[2] + n11.p[2]));
+                    st_u3<true>(sp + (size_t)x * 96, s3);
+                    if (writer) {
+                        uint32_t* wp = bnd_out + (x > 0 ? (size_t)(x - 1) * kFwRecDw : bnd_rec0);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { wp[q] = fw_u(nm.p[q]); wp[3 + q] = fw_u(n01.p[q]); wp[6 + q] = fw_u(n11.p[q]); }
+                        if ((x & (kFwChunk - 1)) == 0 || x == W1 - 1) { // progress = x + 1 pixels: 32 k + 1 is exactly what the slab below waits for
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            if (r == 0) __hip_atomic_store(flag_out, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                } else { // outside the volume every path restarts from zero
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) dst[q] = 0;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) l10.p[q] = short2v{0, 0};
+                }
+                __syncthreads();
+            }
+        }
+        stage_store((chunk + 1) & 1);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------- fused top-down pass
 // sgbm_down_kernel = pixel cost + horizontal box + vertical box + the vertical path (0, 1) in ONE sweep: a workgroup owns kDnCols
 // columns of the cost volume and walks down the rows.  Per row: (1) the Birchfield-Tomasi cost of its columns plus the 4-column
@@ -334,6 +525,7 @@ constexpr int kDnCols = VSLAM_SGBM_DN_COLS, kDnThreads = (kDnCols + 8) * 16; // 
 struct DnRowIn { uint8_t l[6]; unsigned long long r[6]; };   // left {val, lo, hi} x 2 channels (raw loads: nothing is computed on them at fetch time,
                                                               // or the wave would wait for its own prefetch), right planes as 8-byte windows
 
+template <bool WITH_PATH> // false: C only (the vertical path runs inside sgbm_forward_kernel)
 __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, const uint8_t* __restrict__ pre, int16_t* __restrict__ C, uint16_t* __restrict__ T) {
     const int b = blockIdx.y, j0 = blockIdx.x * kDnCols;
     const int W1 = dm.width1, w = dm.w, h = dm.h;
@@ -465,6 +657,7 @@ __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, cons
                     const int y = i - dm.SH2;
                     U3 c;
                     c.a = __builtin_bit_cast(uint32_t, acc[0]); c.b = __builtin_bit_cast(uint32_t, acc[1]); c.c = __builtin_bit_cast(uint32_t, acc[2]);
+                    if constexpr (WITH_PATH) {
                     const int lm = dpp_mov<0x111>(kSent, l5);
                     const int lp = dpp_mov<0x101>(kSent, l0);
                     const int delta = minPrev + P2;
@@ -482,6 +675,7 @@ __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, cons
                         st_u3<VSLAM_SGBM_DN_NT != 0>(C + vbase + (size_t)y * rstride, c);
                         st_u3<VSLAM_SGBM_DN_NT != 0>(T + vbase + (size_t)y * rstride, o);
                     }
+                    } else if (live) st_u3<VSLAM_SGBM_DN_NT != 0>(C + vbase + (size_t)y * rstride, c);
                 }
                 DN_T(3);
             }
@@ -669,6 +863,13 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     const size_t o_d1 = need; need += al((size_t)B * npix * 2);
     const size_t o_par = need; need += al((size_t)B * npix * 4);
     const size_t o_cnt = need; need += al((size_t)B * npix * 4);
+    // forward sweep: 64-row slabs from 24 pairs on, 32-row slabs below that (twice the workgroups, shorter steps: 4.84 vs 5.46 ms at 16 pairs,
+    // 7.50 vs 7.16 ms at 32); VSLAM_SGBM_FW_ROWS overrides
+    const char* rows_env = getenv("VSLAM_SGBM_FW_ROWS");
+    const int fw_rows = (rows_env && *rows_env) ? (atoi(rows_env) == 32 ? 32 : 64) : (B >= 24 ? 64 : 32);
+    const int nslab = (h + fw_rows - 1) / fw_rows;
+    const size_t o_bnd = need; need += al((size_t)B * (nslab > 1 ? nslab - 1 : 1) * ((dm.width1 + kFwChunk - 1) / kFwChunk + 1) * kFwChunk * kFwRecDw * 4);
+    const size_t o_flag = need; need += al((size_t)B * nslab * 4);
     if (*scratch_bytes < need) {
         VS_HIP(hipStreamSynchronize(stream));
         if (*scratch) { (void)hipFree(*scratch); *dev_bytes -= *scratch_bytes; }
@@ -687,14 +888,25 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     // VSLAM_SGBM_FUSE_MIN overrides the threshold (tests run both paths).
     const char* fuse_env = getenv("VSLAM_SGBM_FUSE_MIN");
     const bool unfused = B < ((fuse_env && *fuse_env) ? atoi(fuse_env) : 8);
-    if (!unfused) { ProfScope p(stream, "sgbm_down_kernel"); hipLaunchKernelGGL(sgbm_down_kernel, dim3((dm.width1 + kDnCols - 1) / kDnCols, B), dim3(kDnThreads), 0, stream, dm, pre, C, T); }
+    // ... and from there on the four forward paths run as one wavefront sweep (sgbm_forward_kernel) instead of one kernel per path.
+    // The slabs of a pair are a chain (about 2200 sequential steps): it pays from 16 pairs per call on.  VSLAM_SGBM_FWD_MIN overrides.
+    const char* fwd_env = getenv("VSLAM_SGBM_FWD_MIN");
+    const bool fwd = !unfused && B >= ((fwd_env && *fwd_env) ? atoi(fwd_env) : 16);
+    if (!unfused && !fwd) { ProfScope p(stream, "sgbm_down_kernel"); hipLaunchKernelGGL(sgbm_down_kernel<true>, dim3((dm.width1 + kDnCols - 1) / kDnCols, B), dim3(kDnThreads), 0, stream, dm, pre, C, T); }
+    if (fwd) {
+        { ProfScope p(stream, "sgbm_down_kernel"); hipLaunchKernelGGL(sgbm_down_kernel<false>, dim3((dm.width1 + kDnCols - 1) / kDnCols, B), dim3(kDnThreads), 0, stream, dm, pre, C, T); }
+        VS_HIP(hipMemsetAsync(base + o_flag, 0, (size_t)B * nslab * 4, stream));
+        ProfScope p(stream, "sgbm_forward_kernel");
+        if (fw_rows == 64) hipLaunchKernelGGL(sgbm_forward_kernel<64>, dim3(B * nslab), dim3(64 * 16), 0, stream, dm, C, (int16_t*)T, (uint32_t*)(base + o_bnd), (int*)(base + o_flag), nslab);
+        else hipLaunchKernelGGL(sgbm_forward_kernel<32>, dim3(B * nslab), dim3(32 * 16), 0, stream, dm, C, (int16_t*)T, (uint32_t*)(base + o_bnd), (int*)(base + o_flag), nslab);
+    }
     if (unfused) { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3((dm.width1 + kHsSeg - 1) / kHsSeg, h, B), dim3(kHsBlock), 0, stream, dm, pre, hsum); }
     if (unfused) { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3((dm.width1 * 12 + 255) / 256, (h + kVsChunk - 1) / kVsChunk, B), dim3(256), 0, stream, dm, hsum, C); }
     { const int nv = dm.width1, nd = dm.width1 + h - 1;
       if (unfused) { ProfScope p(stream, "sgbm_path_kernel<0,1>"); hipLaunchKernelGGL((sgbm_path_kernel<0, 1, 0, 8>), dim3((nv + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, nv, (int4*)nullptr); }
-      { ProfScope p(stream, "sgbm_path_kernel<1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 1, 1, 8>), dim3((nd + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, nd, (int4*)nullptr); }
-      { ProfScope p(stream, "sgbm_path_kernel<-1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 1, 1, 8>), dim3((nd + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, nd, (int4*)nullptr); }
-      { ProfScope p(stream, "sgbm_path_kernel<1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 0, 2, 16>), dim3((h + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, h, (int4*)nullptr); }
+      if (!fwd) { ProfScope p(stream, "sgbm_path_kernel<1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 1, 1, 8>), dim3((nd + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, nd, (int4*)nullptr); }
+      if (!fwd) { ProfScope p(stream, "sgbm_path_kernel<-1,1>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 1, 1, 8>), dim3((nd + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, nd, (int4*)nullptr); }
+      if (!fwd) { ProfScope p(stream, "sgbm_path_kernel<1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<1, 0, 2, 16>), dim3((h + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, h, (int4*)nullptr); }
       if (B >= 4) { ProfScope p(stream, "sgbm_path_kernel<-1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 4, 16>), dim3((h + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, h, rec); }
       else {
         { ProfScope p(stream, "sgbm_path_kernel<-1,0>"); hipLaunchKernelGGL((sgbm_path_kernel<-1, 0, 3, 16>), dim3((h + kPathLines - 1) / kPathLines, B), dim3(kPathBlock), 0, stream, dm, C, T, h, (int4*)nullptr); }

@@ -1,18 +1,22 @@
-"""The two fused kernels of round 3 (orb_pyrblur_kernel, sgbm_down_kernel) are chosen by batch size (large batches only: below ~300 images /
-8 stereo pairs the separate kernels are faster).  The parity suite runs small batches, so every check here is executed TWICE: with the
-thresholds forced down to 1 (fused kernels) and forced up (separate kernels) through VSLAM_ORB_FUSE_MIN / VSLAM_SGBM_FUSE_MIN, which
-the library reads on every call."""
+"""The fused kernels of round 3 (orb_pyrblur_kernel, sgbm_down_kernel, sgbm_forward_kernel) are chosen by batch size (large batches only:
+below ~300 images / 8-16 stereo pairs the separate kernels are faster).  The parity suite runs small batches, so every check here is
+executed with the thresholds forced down to 1 (fused kernels; the SGBM forward sweep once with 64-row and once with 32-row slabs) and
+forced up (separate kernels) through VSLAM_ORB_FUSE_MIN / VSLAM_SGBM_FUSE_MIN / VSLAM_SGBM_FWD_MIN / VSLAM_SGBM_FW_ROWS, which the library
+reads on every call."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["1", "1000000"], ids=["fused", "separate"])
+@pytest.fixture(params=[("1", "64"), ("1", "32"), ("1000000", "64")], ids=["fused-slab64", "fused-slab32", "separate"])
 def fuse_mode(request, monkeypatch):
-    monkeypatch.setenv("VSLAM_ORB_FUSE_MIN", request.param)
-    monkeypatch.setenv("VSLAM_SGBM_FUSE_MIN", request.param)
-    return request.param
+    thr, rows = request.param
+    monkeypatch.setenv("VSLAM_ORB_FUSE_MIN", thr)
+    monkeypatch.setenv("VSLAM_SGBM_FUSE_MIN", thr)
+    monkeypatch.setenv("VSLAM_SGBM_FWD_MIN", thr)
+    monkeypatch.setenv("VSLAM_SGBM_FW_ROWS", rows)
+    return thr
 
 
 def _kps_equal(a, b):
@@ -59,12 +63,24 @@ def test_odd_sizes_both_paths(fuse_mode, pkg, oracle, synth, shape):
 
 
 def test_sgbm_both_paths(fuse_mode, vo, oracle, synth):
-    for (w, h, sh) in ((640, 200, 11), (333, 97, 5), (1241, 120, 30)):
+    rng = np.random.default_rng(5)
+    for (w, h, sh, noise) in ((640, 200, 11, 0), (333, 97, 5, 0), (1241, 120, 30, 0), (640, 200, 11, 15), (140, 186, 4, 15)):
         L = synth.noise_image(w % 97, w + 40, h)
         Lc = np.ascontiguousarray(L[:, :w]); R = np.ascontiguousarray(L[:, sh:sh + w])
+        if noise:  # a right view that is not an exact shift: no zero-cost disparity, every path carries real values across the slab boundaries
+            R = np.clip(R.astype(int) + rng.integers(-noise, noise + 1, R.shape), 0, 255).astype(np.uint8)
         gf, gi, graw = vo.disparity_map(Lc, R, return_i16=True)
         wi, wraw = oracle.sgbm_compute(Lc, R, return_raw=True)
         assert np.array_equal(graw, wraw) and np.array_equal(gi, wi)
+
+
+def test_sgbm_full_size_both_paths(fuse_mode, vo, oracle, synth):
+    """BASELINE image size: six 64-row (twelve 32-row) slabs chained through the boundary buffer, the last one partly empty"""
+    left, right = synth.stereo_sequence(1, seed=4)[0][:2]
+    gf, gi, graw = vo.disparity_map(left, right, return_i16=True)
+    wi, wraw = oracle.sgbm_compute(left, right, return_raw=True)
+    assert np.array_equal(graw, wraw) and np.array_equal(gi, wi)
+    assert (gi >= 0).mean() > 0.5
 
 
 def test_sgbm_batched_both_paths(fuse_mode, pkg, oracle, synth):
