@@ -28,7 +28,7 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     print("== %s (sum over dispatches, units of 1 KiB) ==" % name)
     for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
-        if "vslam" in k or "lm_" in k or "orb_" in k or "match_" in k:
+        if "_kernel" in k and "at::" not in k and "rocclr" not in k:
             print("%-38s dispatches %5d  total %12.1f KiB  per dispatch %10.1f KiB" % (k, n, v, v / max(n, 1)))
         out.setdefault(k, {})[name] = dict(total_kib=v, dispatches=n)
 json.dump(out, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
