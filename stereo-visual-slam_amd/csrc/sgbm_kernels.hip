@@ -322,8 +322,8 @@ __global__ __launch_bounds__(kPathBlock) void sgbm_path_kernel(SgbmDims dm, cons
 //
 // Slabs of one pair are chained through memory: the last row of slab k writes its downward vectors per pixel into a boundary buffer and
 // publishes its progress every 32 pixels (release fence + flag); slab k+1 stages the records 32 at a time into LDS, one chunk ahead,
-// with device-scope loads, after its first lane has seen the flag pass the chunk.  A workgroup only ever waits for the workgroup with
-// the next lower index, workgroups are dispatched in index order, so the lowest unfinished one is always resident and never waits:
+// with device-scope loads, after its first lane has seen the flag pass the chunk.  A workgroup only ever waits for ONE workgroup with
+// a lower index, workgroups are dispatched in index order, so the lowest unfinished one is always resident and never waits:
 // no co-residency requirement, no deadlock.  (A spin limit turns a violated assumption into a trap instead of a hang.)
 #ifndef VSLAM_SGBM_FW_CHUNK
 #define VSLAM_SGBM_FW_CHUNK 32
@@ -375,7 +375,11 @@ __global__ __launch_bounds__(kFwRows * 16) void sgbm_forward_kernel(SgbmDims dm,
     constexpr int kFwThreads = kFwRows * 16;
     constexpr int kFwStage = (kFwChunk * kFwRecDw + kFwThreads - 1) / kFwThreads; // dwords per thread of one staged chunk
     __shared__ FwShared<kFwRows> sm;
-    const int b = blockIdx.x / nslab, slab = blockIdx.x - b * nslab;
+    // slab-major order: all first slabs of the batch, then all second slabs ... -- a slab still only waits for a lower index, and in a batch
+    // that does not fit the chip at once a slab is dispatched when its predecessor is long under way (pair-major order made every workgroup
+    // sit out the ~190 steps until the slab above has its first boundary pixels)
+    const int nb = gridDim.x / nslab;
+    const int slab = blockIdx.x / nb, b = blockIdx.x - slab * nb;
     const int tid = threadIdx.x, row_l = tid >> 4, r = tid & 15;
     const int W1 = dm.width1, h = dm.h;
     const int y = slab * kFwRows + row_l;
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(kFwRows * 16) void sgbm_forward_kernel(SgbmDims dm,
     const size_t bnd_rec0 = (size_t)((W1 + kFwChunk - 1) / kFwChunk) * kFwChunk * kFwRecDw, bnd_run = bnd_rec0 + (size_t)kFwChunk * kFwRecDw;
     const uint32_t* bnd_in = bndg + ((size_t)b * (nslab - 1) + max(slab - 1, 0)) * bnd_run;
     uint32_t* bnd_out = bndg + ((size_t)b * (nslab - 1) + max(min(slab, nslab - 2), 0)) * bnd_run + r * 9;
-    int* flag_in = flags + blockIdx.x - 1;
+    int* flag_in = flags + max((int)blockIdx.x - nb, 0);
     int* flag_out = flags + blockIdx.x;
     const bool writer = has_succ && row_l == kFwRows - 1; // (only the last slab has fewer than 64 image rows, and it has no successor)
     // wait until the slab above has published `need` pixels of its last row (first lane only; the workgroup follows through a barrier)
