@@ -526,40 +526,58 @@ __device__ long long g_sgbm_dbg[8];
 #define DN_T(slot) do {} while (0)
 #endif
 constexpr int kDnCols = VSLAM_SGBM_DN_COLS, kDnThreads = (kDnCols + 8) * 16; // one pixel-cost item per (tile column, 16-lane slot)
-struct DnRowIn { uint8_t l[6]; unsigned long long r[6]; };   // left {val, lo, hi} x 2 channels (raw loads: nothing is computed on them at fetch time,
-                                                              // or the wave would wait for its own prefetch), right planes as 8-byte windows
+struct DnStage { uint32_t a, b; uint8_t l; };             // one row's share of the operand strips on its way from memory to LDS (raw loads: nothing is
+                                                          // computed on them at fetch time, or the wave would wait for its own prefetch)
+constexpr int kStripDw = 34;                              // dwords per (plane, byte shift) copy of the right-view strip: window starts 0 .. 121, 8 bytes each
 
 template <bool WITH_PATH> // false: C only (the vertical path runs inside sgbm_forward_kernel)
 __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, const uint8_t* __restrict__ pre, int16_t* __restrict__ C, uint16_t* __restrict__ T) {
     const int b = blockIdx.y, j0 = blockIdx.x * kDnCols;
     const int W1 = dm.width1, w = dm.w, h = dm.h;
-    __shared__ alignas(16) uint8_t tile[2][(kDnCols + 8) * 128]; // [row parity][tile column][16 lanes x 8 bytes (6 costs + 2 pad)]
+    // [row parity][disparity][tile column] bytes (pitch 40: the 16 lanes of a DPP row hit 16 different banks): a dword holds ONE disparity of four
+    // adjacent columns, so the 9-tap horizontal sum is three v_dot4_u32_u8 with 0/1 byte masks instead of nine unpack-and-add steps
+    constexpr int kTilePitch = kDnCols + 8 + 8;
+    __shared__ alignas(16) uint8_t tile[2][96 * kTilePitch];
     const int t = threadIdx.x >> 4, r = threadIdx.x & 15, d = 6 * r;
     const int jj = min(max(j0 - 4 + t, 0), W1 - 1), x = dm.minX1 + jj; // pixel-cost column of this item (clamped to the volume)
     const uint8_t* Lb = pre + ((size_t)(2 * b) * h * 6) * w;
     const uint8_t* Rb = pre + ((size_t)(2 * b + 1) * h * 6) * w;
-    // per-lane byte offsets inside one prefiltered row (6 planes of w bytes), constant over the rows: the row base is wave-uniform, so
-    // the twelve loads of a row need no per-row address arithmetic (scalar base + 32-bit lane offset)
-    uint32_t offL[6], offR[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { offL[q] = (uint32_t)(q * w + x); offR[q] = (uint32_t)(q * w + x - d - 5); } // byte 5 - i of a window <-> disparity d + i
-    // buffer loads: descriptor (scalar) + per-lane offset (constant) + row offset (scalar): no vector address arithmetic per row
-    // (+ 8 bytes: the last window of the last plane row reaches 2 bytes past the view -- bytes 6, 7 of a window are never used, but the
-    // range check is per dword and would zero bytes 4, 5 with them; what follows is the next view / the next scratch region)
+    // Operands through LDS.  A workgroup row needs 32 left pixels and a 130-byte strip of the right view per plane; fetched per lane (six byte
+    // loads + six unaligned 8-byte windows) that was 24.6 KB of requests for 0.9 KB of data, and the kernel was bound by the texture addresser
+    // (TA busy 85-90 % of the kernel, VALU 41 %; profiles/r03_sgbm_detail_summary.txt).  Now the strips are staged once per row: the right view as FOUR
+    // copies shifted by 0..3 bytes (loaded at byte offsets s + 4 i -- global loads may be unaligned, LDS reads may not), so that a lane whose
+    // window starts at byte o reads two aligned dwords of copy o & 3; the left view as 8-byte records {val, lo, hi} x 2 channels per column.
+    // <= 2 dword loads + 1 byte load per thread and row instead of 12 loads.
+    __shared__ uint32_t rstrip[2][6 * 4 * kStripDw];
+    __shared__ alignas(8) uint8_t lstrip[2][(kDnCols + 8) * 8];
+    const int X0 = dm.minX1 + j0 - 4 - 95; // first byte of the strip (may be negative at the left border: those bytes are never consumed)
     const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Lb), 0, h * 6 * w + 8, 0x00020000);
     const auto rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Rb), 0, h * 6 * w + 8, 0x00020000);
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    auto fetch = [&](int y, DnRowIn& in) {
+    constexpr int kStripAll = 6 * 4 * kStripDw;
+    const int tid = threadIdx.x;
+    const int i0s = tid, i1s = min(tid + kDnThreads, kStripAll - 1);
+    const bool has_b = tid + kDnThreads < kStripAll, has_l = tid < (kDnCols + 8) * 6;
+    auto strip_off = [&](int idx) { const int q = idx / (4 * kStripDw), rem = idx - q * 4 * kStripDw, sft = rem / kStripDw, ii = rem - sft * kStripDw; return q * w + X0 + sft + 4 * ii; };
+    const int offA = strip_off(i0s), offB = strip_off(i1s);   // (a negative offset is a huge unsigned one: out of range, reads 0)
+    const int lq = tid / (kDnCols + 8), lt = tid - lq * (kDnCols + 8);
+    const int offLs = min(lq, 5) * w + dm.minX1 + min(max(j0 - 4 + lt, 0), W1 - 1);
+    auto fetch = [&](int y, DnStage& in) {
         const int row = y * 6 * w; // uniform
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            in.l[q] = __builtin_amdgcn_raw_buffer_load_b8(rsL, (int)offL[q], row, 0);
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsR, (int)offR[q], row, 0);
-            in.r[q] = (unsigned long long)v.x | (unsigned long long)v.y << 32;
-        }
+        in.a = __builtin_amdgcn_raw_buffer_load_b32(rsR, offA, row, 0);
+        in.b = __builtin_amdgcn_raw_buffer_load_b32(rsR, offB, row, 0);
+        in.l = __builtin_amdgcn_raw_buffer_load_b8(rsL, offLs, row, 0);
     };
+    auto stage = [&](int par, const DnStage& in) {
+        rstrip[par][i0s] = in.a;
+        if (has_b) rstrip[par][i1s] = in.b;
+        if (has_l) lstrip[par][lt * 8 + lq] = in.l;
+    };
+    // this lane's windows: byte o = (column offset in the tile) + 90 - 6 r of the strip, in every plane
+    const int wo = (jj - (j0 - 4)) + 90 - d;
+    const int roff = (wo & 3) * kStripDw + (wo >> 2), loff = (jj - (j0 - 4)) * 8;
     // path lane: column j = j0 + t (t < kDnCols), disparities 6 r .. 6 r + 5
     const bool path_lane = t < kDnCols;
+    const uint32_t hm0 = 0x01010101u << (8 * (t & 3)), hm2 = 0x01010101u >> (8 * (3 - (t & 3))); // 0/1 byte masks of the 9-column window
     const int j = j0 + t;
     const bool live = path_lane && j < W1;
     const bool frozen = j == 0; // the reference never updates column 0 after the first row
@@ -573,8 +591,11 @@ __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, cons
     // The operands of row i + 1 are fetched while row i is processed.  The two operand sets alternate BY NAME (the body is unrolled 18 =
     // 2 x 9 times: set = step parity, ring slot = step mod 9): a register copy "cur = nxt" would make the compiler wait for every
     // outstanding memory operation -- the C / T stores of the row before included -- once per row.
-    DnRowIn in[2];
+    DnStage in[2];
     fetch(0, in[0]);
+    stage(0, in[0]);
+    fetch(min(1, h - 1), in[0]);
+    __syncthreads();
 #ifdef VSLAM_SGBM_PROFILE
     const bool dbg__ = blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0;
     long long acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0__ = clock64();
@@ -584,24 +605,28 @@ __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, cons
         for (int step = 0; step < 18; ++step) {
             constexpr int kDummy = 0; (void)kDummy;
             const int sidx = step % 9;
-            DnRowIn& cur = in[step & 1];
-            DnRowIn& nxt = in[(step + 1) & 1];
+            DnStage& cur = in[step & 1];       // row i + 1, fetched a step ago: goes to LDS now
+            DnStage& nxt = in[(step + 1) & 1]; // row i + 2: requested now
             const int i = i0 + step; // hsum row produced in this step (while i < h); emitted row y = i - SH2
             if (i >= h + dm.SH2) continue; // uniform (no break: the ring index must stay a compile-time constant)
             { // straight-line on purpose (row indices clamped instead of branches): with the fetch inside a conditional the compiler's
               // wait-count insertion falls back to vmcnt(0) right after issuing the prefetch
-                fetch(min(i + 1, h - 1), nxt);
+                stage((i + 1) & 1, cur);
+                fetch(min(i + 2, h - 1), nxt);
+                const uint2 lv = *reinterpret_cast<const uint2*>(&lstrip[i & 1][loff]);
                 // (1) pixel cost of (column jj, disparities d .. d + 5), both channels, two disparities per packed-i16 operation:
                 // byte 5 - k of a right-view window is disparity d + k, so v_perm pulls the pairs (d, d+1), (d+2, d+3), (d+4, d+5) out of
                 // the two window dwords; cost = min(max(0, u - v1, v0 - u), max(0, v - u1, u0 - v)), channel 1 (raw / 4) shifted before the add
                 short2v cost[3];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const short2v U = {(short)cur.l[3 * c], (short)cur.l[3 * c]}, U0 = {(short)cur.l[3 * c + 1], (short)cur.l[3 * c + 1]};
-                    const short2v U1 = {(short)cur.l[3 * c + 2], (short)cur.l[3 * c + 2]};
-                    const uint32_t vl = (uint32_t)cur.r[3 * c], vh = (uint32_t)(cur.r[3 * c] >> 32);
-                    const uint32_t v0l = (uint32_t)cur.r[3 * c + 1], v0h = (uint32_t)(cur.r[3 * c + 1] >> 32);
-                    const uint32_t v1l = (uint32_t)cur.r[3 * c + 2], v1h = (uint32_t)(cur.r[3 * c + 2] >> 32);
+                    // left {val, lo, hi} of channel c: byte 3c + k of the column's record, splat into both halves
+                    auto splat = [&](int k) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(lv.y, lv.x, 0x0c000c00u | (uint32_t)k | ((uint32_t)k << 16))); };
+                    const short2v U = splat(3 * c), U0 = splat(3 * c + 1), U1 = splat(3 * c + 2);
+                    const uint32_t* rp = &rstrip[i & 1][roff];
+                    const uint32_t vl = rp[(3 * c) * 4 * kStripDw], vh = rp[(3 * c) * 4 * kStripDw + 1];
+                    const uint32_t v0l = rp[(3 * c + 1) * 4 * kStripDw], v0h = rp[(3 * c + 1) * 4 * kStripDw + 1];
+                    const uint32_t v1l = rp[(3 * c + 2) * 4 * kStripDw], v1h = rp[(3 * c + 2) * 4 * kStripDw + 1];
                     const short2v zero = {0, 0};
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
@@ -616,10 +641,11 @@ __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, cons
                         else cost[k] = cost[k] + __builtin_bit_cast(short2v, (__builtin_bit_cast(uint32_t, m) >> 2) & 0x3FFF3FFFu);
                     }
                 }
-                uint2 o;
-                o.x = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, cost[1]), __builtin_bit_cast(uint32_t, cost[0]), 0x06040200u);
-                o.y = __builtin_amdgcn_perm(0u, __builtin_bit_cast(uint32_t, cost[2]), 0x0c0c0200u);
-                *reinterpret_cast<uint2*>(&tile[i & 1][t * 128 + r * 8]) = o;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    tile[i & 1][(d + 2 * k) * kTilePitch + t] = (uint8_t)cost[k].x;
+                    tile[i & 1][(d + 2 * k + 1) * kTilePitch + t] = (uint8_t)cost[k].y;
+                }
             }
             DN_T(0);
             __syncthreads();
@@ -627,17 +653,18 @@ __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, cons
             if (path_lane) {
                 if (i < h) {
                     // (2) hsum(i) of column j: nine tile columns t .. t + 8 (= volume columns j - 4 .. j + 4, clamped)
-                    uint32_t e0 = 0, o0 = 0, e1 = 0, o1 = 0;
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) {
-                        const uint2 v = *reinterpret_cast<const uint2*>(&tile[i & 1][(t + q) * 128 + r * 8]);
-                        e0 += v.x & 0x00FF00FFu; o0 += (v.x >> 8) & 0x00FF00FFu;
-                        e1 += v.y & 0x000000FFu; o1 += (v.y >> 8) & 0x000000FFu;
-                    }
+                    // window = tile columns t .. t + 8 = bytes sh .. sh + 8 of the three aligned dwords at column t & ~3 (sh = t & 3)
                     short2v hs[3];
-                    hs[0] = __builtin_bit_cast(short2v, (e0 & 0xFFFFu) | (o0 << 16));
-                    hs[1] = __builtin_bit_cast(short2v, (e0 >> 16) | (o0 & 0xFFFF0000u));
-                    hs[2] = __builtin_bit_cast(short2v, e1 | (o1 << 16));
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        uint32_t sum[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&tile[i & 1][(d + 2 * k + e) * kTilePitch + (t & ~3)]);
+                            sum[e] = __builtin_amdgcn_udot4(w3[0], hm0, __builtin_amdgcn_udot4(w3[1], 0x01010101u, __builtin_amdgcn_udot4(w3[2], hm2, 0u, false), false), false);
+                        }
+                        hs[k] = __builtin_bit_cast(short2v, sum[0] | (sum[1] << 16));
+                    }
                     if (i == 0) { // rows above the image replicate row 0: C(0) = 5 hsum(0) + hsum(1..4); every ring slot starts as hsum(0)
 #pragma unroll
                         for (int q = 0; q < 9; ++q) { ring[q][0] = hs[0]; ring[q][1] = hs[1]; ring[q][2] = hs[2]; }
