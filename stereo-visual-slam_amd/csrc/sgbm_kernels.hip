@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kFwRows * 16) void sgbm_forward_kernel(SgbmDims dm,
             int spins = 0;
             while (__hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1 << 24)) __builtin_trap(); // ~10 s: the dispatch-order assumption does not hold
+                if (++spins > (1 << 26)) __builtin_trap(); // ~30 s: the dispatch-order assumption does not hold
             }
         }
         __syncthreads();
