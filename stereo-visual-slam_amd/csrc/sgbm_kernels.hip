@@ -894,10 +894,12 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     const size_t o_d1 = need; need += al((size_t)B * npix * 2);
     const size_t o_par = need; need += al((size_t)B * npix * 4);
     const size_t o_cnt = need; need += al((size_t)B * npix * 4);
-    // forward sweep: 64-row slabs from 24 pairs on, 32-row slabs below that (twice the workgroups, shorter steps: 4.84 vs 5.46 ms at 16 pairs,
-    // 7.50 vs 7.16 ms at 32); VSLAM_SGBM_FW_ROWS overrides
+    // forward sweep: 32-row slabs (workgroups of 512 threads, two per CU) up to 32 pairs, 64-row slabs above.  The slabs of a pair are a chain
+    // of ~2 200 (64 rows) / ~2 600 (32 rows) steps and a step's time is mostly its latency (barrier, LDS mailbox, the dependent minimum ->
+    // delta -> update chain), so shorter workgroups win until the chip is full: 16 / 24 / 32 / 40 pairs 2.33 / 2.60 / 2.93 / 3.45 ms with 32
+    // rows, 3.01 / 3.06 / 3.19 / 3.35 ms with 64 (48-row slabs: 2.64 / 2.76 / 2.92 / 3.31 -- no better anywhere).  VSLAM_SGBM_FW_ROWS overrides.
     const char* rows_env = getenv("VSLAM_SGBM_FW_ROWS");
-    const int fw_rows = (rows_env && *rows_env) ? (atoi(rows_env) == 32 ? 32 : 64) : (B >= 24 ? 64 : 32);
+    const int fw_rows = (rows_env && *rows_env) ? (atoi(rows_env) == 32 ? 32 : 64) : (B <= 32 ? 32 : 64);
     const int nslab = (h + fw_rows - 1) / fw_rows;
     const size_t o_bnd = need; need += al((size_t)B * (nslab > 1 ? nslab - 1 : 1) * ((dm.width1 + kFwChunk - 1) / kFwChunk + 1) * kFwChunk * kFwRecDw * 4);
     const size_t o_flag = need; need += al((size_t)B * nslab * 4);
