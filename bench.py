@@ -469,8 +469,9 @@ def main():
         achieved = alg / per_bracket_s / 1e9 if per_bracket_s > 0 else 0.0
         traffic, traffic_src = None, None
         try:  # measured offline with rocprofv3 PMC passes (tools/profile_round.sh); only valid for the same kernel and batch
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("kernel") == dom and tj.get("batch") == B:
+            sg = args.depth == "sgbm" and dom.startswith("sgbm_*")
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_sgbm.json" if sg else "traffic.json")))
+            if (sg and tj.get("batch") == B) or (tj.get("kernel") == dom and tj.get("batch") == B):
                 traffic = int(tj["hbm_bytes_per_launch_set"])
             traffic_src = tj.get("source")
         except Exception:
