@@ -6,19 +6,19 @@
 // border behaviours (see oracle/sgbm.c for the list); all arithmetic is 8/16/32-bit integer, so the result is bit-exact
 // against the CPU oracle.
 //
-// gfx950 mapping (batched over B stereo pairs; every stage integer, HBM/L2-bound -- the cost volume is 82.7 MB per pair):
-//   sgbm_prefilter_kernel   x-Sobel clipped to [0,126] + raw rows                              elementwise
-//   sgbm_pixcost_kernel     Birchfield-Tomasi cost per (y, x, d) -> u8 volume                   lanes along d (coalesced)
-//   sgbm_hsum_kernel        9-tap horizontal box with clamped columns -> i16                    "
-//   sgbm_vsum_kernel        9-tap vertical box (top clamped, bottom frozen, column 0 frozen)    "
-//   sgbm_vertical_kernel    paths from the previous row (3 directions): the only row-sequential stage; one workgroup per
-//                           pair walks the rows, 32-lane groups own one pixel (3 disparities per lane), the per-path
-//                           minima are 5-step xor reductions; previous-row costs ping-pong through L2
-//   sgbm_horizontal_kernel  one workgroup per image row: left->right scan, S1 = sat16(L0 + L1..3), right->left scan with
-//                           winner-take-all, uniqueness, parabola sub-pixel, disp2 bookkeeping and the left-right check
-//   sgbm_median3_kernel     3x3 median, replicated borders
-//   sgbm_ccl_*              speckle filter as connected-component labelling (atomic union-find) + size threshold
-//   sgbm_to_float_kernel    int16 / 16 -> f32 (invalid = -1)
+// gfx950 mapping (batched over B stereo pairs; every stage integer; the cost volume is 82.7 MB per pair).  Which kernels run depends on the
+// batch (launch_sgbm; thresholds overridable per call through VSLAM_SGBM_FUSE_MIN / VSLAM_SGBM_FWD_MIN / VSLAM_SGBM_FW_ROWS):
+//   sgbm_prefilter_kernel     x-Sobel clipped to [0,126] + raw rows, half-pixel min/max envelopes of both views        elementwise
+//   >= 8 pairs:  sgbm_down_kernel<WITH_PATH>   Birchfield-Tomasi cost + 9x9 box sums (+ the vertical path) in one top-down sweep per 24-column tile;
+//                                              operand strips staged through LDS once per row, 9-tap sums as v_dot4
+//   <  8 pairs:  sgbm_hsum_kernel, sgbm_vsum_kernel, sgbm_path_kernel<0,1>   the same three steps as massively parallel kernels
+//   >= 16 pairs: sgbm_forward_kernel<ROWS>     paths (1,0), (1,1), (0,1), (-1,1) as one wavefront sweep over t = x + 2y (C read once, S1 written
+//                                              once); slabs of 32 / 64 image rows chained through a boundary buffer
+//   <  16 pairs: sgbm_path_kernel<dx,dy>       one kernel per path: a 16-lane DPP row walks one image line (6 disparities per lane)
+//   sgbm_path_kernel<-1,0> MODE 4 / 3 + sgbm_wta_kernel   last path with winner-take-all + uniqueness folded in (S never stored) / separate
+//   sgbm_lrcheck_kernel       sub-pixel parabola, disp2 bookkeeping, left-right check (workgroup per row)
+//   sgbm_median3_kernel       3x3 median, replicated borders
+//   sgbm_ccl_{rows,union,count,apply}_kernel   speckle filter as connected-component labelling (atomic union-find) + size threshold, /16 -> f32
 #include "vslam_internal.h"
 
 #include <stdlib.h>
