@@ -76,6 +76,31 @@ def test_sgbm_batched_device_path(vo, oracle, synth):
         assert np.array_equal(out[b].cpu().numpy(), oracle.disparity_map(L, R))
 
 
+@pytest.mark.parametrize("B", [17, 35])
+def test_sgbm_large_batch_default_kernels(pkg, oracle, synth, B):
+    """a batch large enough that the library picks the fused kernels ITSELF (no environment override): the top-down sweep and the forward
+    wavefront sweep with 32-row slabs (17 pairs: 5 chained slabs per pair) and 64-row slabs (35 pairs: 3 slabs), noisy pairs"""
+    import torch
+    w, h, pitch = 300, 130, 320
+    pairs = [_rendered(synth, 40 + (b % 6), w, h, noise=3 + 2 * (b % 5))[:2] for b in range(B)]
+    pairs = [(L, np.roll(R, b % 3, axis=1)) for b, (L, R) in enumerate(pairs)]   # every pair different
+    buf = np.zeros((2, B, h, pitch), np.uint8)
+    for b, (L, R) in enumerate(pairs):
+        buf[0, b, :, :w] = L; buf[1, b, :, :w] = R
+    ctx = pkg.VO(device=0, max_batch=B)
+    try:
+        d = torch.from_numpy(buf).cuda()
+        out = torch.empty((B, h, w), dtype=torch.float32, device="cuda")
+        i16 = torch.empty((B, h, w), dtype=torch.int16, device="cuda")
+        ctx.disparity_map_dev(d[0].data_ptr(), d[1].data_ptr(), h * pitch, pitch, w, h, B, out.data_ptr(), i16.data_ptr())
+        ctx.sync()
+        got = i16.cpu().numpy()
+        for b, (L, R) in enumerate(pairs):
+            assert np.array_equal(got[b], oracle.sgbm_compute(np.ascontiguousarray(L), np.ascontiguousarray(R))), b
+    finally:
+        ctx.close()
+
+
 def test_sgbm_rejects_bad_arguments(vo, pkg):
     with pytest.raises(pkg.VslamError):
         vo.disparity_map(np.zeros((40, 90), np.uint8), np.zeros((40, 90), np.uint8))   # w <= 96 disparities
