@@ -30,6 +30,10 @@
 
 #include "orb_pattern.inc"
 
+#ifndef VSLAM_BLUR_TILE_H
+#define VSLAM_BLUR_TILE_H 64 // rows of a pyramid / blur tile (a wave owns a quarter: 6 halo rows of horizontal passes per wave)
+#endif
+
 namespace vslam {
 
 __device__ __constant__ signed char c_pattern[256 * 4];
@@ -254,14 +258,14 @@ int orb_tables_init(const OrbPlan* plan, OrbTables* t) {
             ibeta[2 * (t->y_off[l] + dy) + 1] = (short)lrintf(fy * 2048.f);
         }
     }
-    // tile ownership of the fused pyramid + blur kernel (256 x 64 source tiles)
+    // tile ownership of the fused pyramid + blur kernel (256 x VSLAM_BLUR_TILE_H source tiles)
     std::vector<int> tdx, tdy;
     for (int l = 0; l + 1 < kNLevels; ++l) {
         const int sw = plan->lv[l].w, sh = plan->lv[l].h, dw = plan->lv[l + 1].w, dh = plan->lv[l + 1].h;
-        const int ntx = (sw + 255) / 256, nty = (sh + 63) / 64;
+        const int ntx = (sw + 255) / 256, nty = (sh + VSLAM_BLUR_TILE_H - 1) / VSLAM_BLUR_TILE_H;
         t->tdx_off[l] = (int)tdx.size(); t->tdy_off[l] = (int)tdy.size();
         for (int tx = 0, dx = 0; tx <= ntx; ++tx) { while (dx < dw && xofs[t->x_off[l + 1] + dx] < tx * 256) ++dx; tdx.push_back(tx == ntx ? dw : dx); }
-        for (int ty = 0, dy = 0; ty <= nty; ++ty) { while (dy < dh && yofs[t->y_off[l + 1] + dy] < ty * 64) ++dy; tdy.push_back(ty == nty ? dh : dy); }
+        for (int ty = 0, dy = 0; ty <= nty; ++ty) { while (dy < dh && yofs[t->y_off[l + 1] + dy] < ty * VSLAM_BLUR_TILE_H) ++dy; tdy.push_back(ty == nty ? dh : dy); }
     }
     int rc = VSLAM_OK;
     do {
@@ -1318,7 +1322,7 @@ int launch_anms_flat(int B, const vslam_keypoint* d_in, const int32_t* d_nin, in
 // K6a orb_blur_kernel: GaussianBlur 7x7 sigma 2 (8-bit fixed point, BORDER_REFLECT_101) of every pyramid level into a
 // second pyramid, one launch for all levels.  256 x 64 output tiles: (264 x 70) raw pixels staged in LDS -- the arithmetic of
 // cv::GaussianBlur's 8U path: taps cvRound(k*256) = {18,34,49,55,49,34,18} per pass, (sum + 2^15) >> 16 after the column pass.
-constexpr int kBlurTileW = 256, kBlurTileH = 64, kBlurWaveRows = 16; // workgroup tile; a wave owns 16 output rows of all 256 columns
+constexpr int kBlurTileW = 256, kBlurTileH = VSLAM_BLUR_TILE_H, kBlurWaveRows = kBlurTileH / 4; // workgroup tile; a wave owns a quarter of the rows, all 256 columns
 constexpr int kBlurRawH = kBlurTileH + 6, kBlurRawChunks = (kBlurTileW + 8 + 15) / 16, kBlurRawPitch = 16 * kBlurRawChunks; // raw tile starts at (x0 - 4, y0 - 3); rows of 17 x 16 B
 
 struct BlurTable {
