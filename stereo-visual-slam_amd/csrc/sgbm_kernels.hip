@@ -526,9 +526,10 @@ __device__ long long g_sgbm_dbg[8];
 #define DN_T(slot) do {} while (0)
 #endif
 constexpr int kDnCols = VSLAM_SGBM_DN_COLS, kDnThreads = (kDnCols + 8) * 16; // one pixel-cost item per (tile column, 16-lane slot)
+static_assert(kDnCols % 4 == 0 && 6 * 4 * ((kDnCols + 8 + 97 + 3) / 4 + 1) <= 2 * kDnThreads, "the strip loader issues at most two dword loads per thread");
+constexpr int kStripDw = (kDnCols + 8 + 97 + 3) / 4 + 1;  // dwords per (plane, byte shift) copy of the right-view strip: window starts 0 .. kDnCols + 97, 8 bytes each
 struct DnStage { uint32_t a, b; uint8_t l; };             // one row's share of the operand strips on its way from memory to LDS (raw loads: nothing is
                                                           // computed on them at fetch time, or the wave would wait for its own prefetch)
-constexpr int kStripDw = 34;                              // dwords per (plane, byte shift) copy of the right-view strip: window starts 0 .. 121, 8 bytes each
 
 template <bool WITH_PATH> // false: C only (the vertical path runs inside sgbm_forward_kernel)
 __global__ __launch_bounds__(kDnThreads) void sgbm_down_kernel(SgbmDims dm, const uint8_t* __restrict__ pre, int16_t* __restrict__ C, uint16_t* __restrict__ T) {
