@@ -244,6 +244,8 @@ static const CopyVariant kCopyVariants[] = {
     {"U4 plain, 8 WG/CU", 4, false, 8},        {"U8 plain, 8 WG/CU", 8, false, 8},   {"U8 nontemporal, 8 WG/CU", 8, true, 8},
     {"U8 nontemporal, 16 WG/CU", 8, true, 16}, {"U8 nontemporal, 32 WG/CU", 8, true, 32}, {"U16 nontemporal, 8 WG/CU", 16, true, 8},
     {"U4 nontemporal, one chunk per WG", 4, true, 0}, {"U8 plain, one chunk per WG", 8, false, 0},
+    {"U2 nontemporal, one chunk per WG", 2, true, 0}, {"U1 plain, one float4 per thread", 1, false, 0}, {"U1 nontemporal, one float4 per thread", 1, true, 0},
+    {"U2 plain, one chunk per WG", 2, false, 0},
 };
 int hbm_copy_probe_variants() { return (int)(sizeof(kCopyVariants) / sizeof(kCopyVariants[0])); }
 const char* hbm_copy_probe_name(int v) { return (v >= 0 && v < hbm_copy_probe_variants()) ? kCopyVariants[v].name : ""; }
@@ -257,7 +259,11 @@ int launch_hbm_copy_probe(const void* src, void* dst, size_t bytes, int variant,
     if (grid < 1) grid = 1;
     const v4f* s = (const v4f*)src; v4f* d = (v4f*)dst;
 #define VS_COPY(UU, NTT) hipLaunchKernelGGL((hbm_copy_probe_kernel<UU, NTT>), dim3((unsigned)grid), dim3(256), 0, stream, s, d, n)
-    if (cv.U == 4 && !cv.nt) VS_COPY(4, false);
+    if (cv.U == 1 && !cv.nt) VS_COPY(1, false);
+    else if (cv.U == 1) VS_COPY(1, true);
+    else if (cv.U == 2 && !cv.nt) VS_COPY(2, false);
+    else if (cv.U == 2) VS_COPY(2, true);
+    else if (cv.U == 4 && !cv.nt) VS_COPY(4, false);
     else if (cv.U == 4) VS_COPY(4, true);
     else if (cv.U == 8 && !cv.nt) VS_COPY(8, false);
     else if (cv.U == 8) VS_COPY(8, true);
