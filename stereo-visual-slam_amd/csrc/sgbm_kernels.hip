@@ -218,6 +218,9 @@ __device__ inline void wta_row16(const SgbmDims& dm, int s0, int s1, int s2, int
 constexpr int kPathBlock = VSLAM_SGBM_PATH_BLOCK, kPathLines = kPathBlock / 16; // lines per workgroup (adjacent lines: one contiguous run of the volume per step)
 // Non-temporal loads / stores on the streamed volumes (every byte is touched once per kernel): the two diagonal paths gain 7-12 %
 // (1.90 -> 1.67, 1.74 -> 1.61 ms per 32 pairs), the two horizontal ones lose 3 % -- so NT is a property of the direction.
+#ifndef VSLAM_SGBM_LAST_NT
+#define VSLAM_SGBM_LAST_NT 0
+#endif
 #ifndef VSLAM_SGBM_H_NTST
 #define VSLAM_SGBM_H_NTST 1 // non-temporal STORES (not loads) on the horizontal paths: 1.69 -> 1.65 ms for the left-to-right path
 #endif
@@ -238,7 +241,7 @@ __device__ inline void st_u3(void* p, U3 v) {
 template <int DX, int DY, int MODE, int kPathPF>
 __global__ __launch_bounds__(kPathBlock) void sgbm_path_kernel(SgbmDims dm, const int16_t* __restrict__ C, uint16_t* T, int nlines, int4* __restrict__ rec) {
     const int b = blockIdx.y;
-    constexpr bool kNT = DX != 0 && DY != 0;            // loads (and stores) of the diagonal paths
+    constexpr bool kNT = (DX != 0 && DY != 0) || (MODE == 4 && VSLAM_SGBM_LAST_NT != 0); // loads (and stores) of the diagonal paths; tuning macro for the last path
     constexpr bool kNTst = kNT || (VSLAM_SGBM_H_NTST != 0); // stores of the horizontal paths (tuning macro)
     const int line = blockIdx.x * kPathLines + (threadIdx.x >> 4), r = threadIdx.x & 15;
     if (line >= nlines) return; // whole DPP row leaves
