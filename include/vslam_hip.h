@@ -266,6 +266,15 @@ int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* batch, int schedule
 
 /* per-window status of the most recent window launch on this process (VSLAM_OK or VSLAM_ERR_ARG per window) */
 int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status);
+/* Kernel-choice overrides of a context (tuning aid, and how the tests force every kernel path): name in {"orb_fuse_min", "sgbm_fuse_min",
+ * "sgbm_fwd_min" (items per call from which the fused kernel is used), "sgbm_fw_rows" (32 | 64), "pose_only_window", "pnp_window" (0 | 1)};
+ * value -1 = the library's batch-size rule.  vslam_create seeds them once from the environment variables VSLAM_<NAME> (an unparsable
+ * or out-of-range value makes vslam_create fail with VSLAM_ERR_ARG); nothing reads the environment afterwards. */
+int vslam_set_tuning(vslam_ctx* ctx, const char* name, int value);
+/* status word of the most recent vslam_disparity_map_dev launch: synchronises the stream; *h_status = 0 and VSLAM_OK, or
+ * *h_status != 0 and VSLAM_ERR_HIP when the chained forward sweep gave up waiting for a predecessor slab (its maps are void).
+ * The host-buffer call vslam_disparity_map checks it itself. */
+int vslam_sgbm_status_dev(vslam_ctx* ctx, int32_t* h_status);
 /* per-image ORB capacity flags of the most recent ORB launch (0 = ok) */
 int vslam_orb_status_dev(vslam_ctx* ctx, int B, int32_t* h_status);
 

@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
     "vslam_profile_enable", "vslam_profile_read", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
-    "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant",
+    "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant", "vslam_sgbm_status_dev", "vslam_set_tuning",
 ]
 
 
@@ -276,6 +276,17 @@ class VO:
                                                    int(h), int(B), _p(d_disp) if d_disp is not None else None,
                                                    _p(d_i16) if d_i16 is not None else None,
                                                    _p(d_raw) if d_raw is not None else None), "vslam_disparity_map_dev")
+
+    def set_tuning(self, **kw):
+        """kernel-choice overrides of this context, e.g. set_tuning(sgbm_fwd_min=1, sgbm_fw_rows=32); -1 = library default"""
+        for k, v in kw.items():
+            self._chk(self.lib.vslam_set_tuning(self.h, k.encode(), int(v)), "vslam_set_tuning")
+
+    def sgbm_status(self):
+        """status word of the most recent disparity_map_dev launch (synchronises): 0, or raises VslamError"""
+        st = C.c_int32(0)
+        self._chk(self.lib.vslam_sgbm_status_dev(self.h, C.byref(st)), "vslam_sgbm_status_dev")
+        return st.value
 
     # ------------------------------------------------------------ Frame::find_3d / VO::set_ref_3d_position
     def find_3d_disparity(self, kps, disparity, T_c_w):

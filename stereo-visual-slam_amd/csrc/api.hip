@@ -100,9 +100,37 @@ static int dev_alloc(Ctx* c, T** p, size_t n) {
     return VSLAM_OK;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
+// ---- kernel-choice overrides (struct Tuning): table of {name, environment variable, field, allowed range}
+struct TuneKey { const char* name; const char* env; int Tuning::*field; int lo, hi; };
+static const TuneKey kTuneKeys[] = {
+    {"orb_fuse_min", "VSLAM_ORB_FUSE_MIN", &Tuning::orb_fuse_min, 0, 1 << 30},
+    {"sgbm_fuse_min", "VSLAM_SGBM_FUSE_MIN", &Tuning::sgbm_fuse_min, 0, 1 << 30},
+    {"sgbm_fwd_min", "VSLAM_SGBM_FWD_MIN", &Tuning::sgbm_fwd_min, 0, 1 << 30},
+    {"sgbm_fw_rows", "VSLAM_SGBM_FW_ROWS", &Tuning::sgbm_fw_rows, 32, 64},
+    {"pose_only_window", "VSLAM_POSE_ONLY_WINDOW", &Tuning::pose_only_window, 0, 1},
+    {"pnp_window", "VSLAM_PNP_WINDOW", &Tuning::pnp_window, 0, 1},
+};
+static int tune_set(Tuning& t, const TuneKey& k, long v) {
+    if (v == -1) { t.*(k.field) = -1; return VSLAM_OK; } // back to the library's rule
+    if (v < k.lo || v > k.hi || (k.field == &Tuning::sgbm_fw_rows && v != 32 && v != 64)) {
+        set_error("tuning value %s = %ld out of range (%d..%d%s, or -1 = default)", k.name, v, k.lo, k.hi, k.field == &Tuning::sgbm_fw_rows ? ", 32 or 64" : "");
+        return VSLAM_ERR_ARG;
+    }
+    t.*(k.field) = (int)v;
+    return VSLAM_OK;
+}
+// the environment seeds the overrides ONCE, at context creation; an unparsable value is an error there, not a silent 0
+static int tune_from_env(Tuning& t) {
+    for (const TuneKey& k : kTuneKeys) {
+        const char* e = getenv(k.env);
+        if (!e || !*e) continue;
+        char* end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end == e || *end != 0) { set_error("environment variable %s = \"%s\" is not an integer", k.env, e); return VSLAM_ERR_ARG; }
+        int rc = tune_set(t, k, v);
+        if (rc) return rc;
+    }
+    return VSLAM_OK;
 }
 
 static int orb_status_check(Ctx* c, int B) {
@@ -123,8 +151,8 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
     // With descriptors wanted and a LARGE batch, every level is staged once for both its successor and its blurred copy
     // (orb_pyrblur_kernel: 3 % faster at 512 images, a third less pyramid traffic).  Small batches keep the separate kernels: eight
     // dependent launches that each do resize AND blur are slower than seven short resize launches + one blur launch over all levels
-    // (0.37 vs 0.47 ms for two images, break-even at ~300 images).  VSLAM_ORB_FUSE_MIN overrides the threshold (tests run both paths).
-    const bool fused = describe && B >= env_int("VSLAM_ORB_FUSE_MIN", 384);
+    // (0.37 vs 0.47 ms for two images, break-even at ~300 images).  Tuning::orb_fuse_min overrides the threshold (tests run both paths).
+    const bool fused = describe && B >= (c->tune.orb_fuse_min >= 0 ? c->tune.orb_fuse_min : 384);
     if (fused) { if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc; }
     else if ((rc = launch_orb_pyramid(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->stream))) return rc;
     if ((rc = launch_orb_fast(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->p.fast_threshold, c->orb.d_corners,
@@ -181,19 +209,23 @@ const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tes
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
     if (!p || !out) { set_error("null argument"); return VSLAM_ERR_ARG; }
     *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libvslam_hip has no CPU path)"); return VSLAM_ERR_NO_DEVICE; }
-    if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return VSLAM_ERR_ARG; }
+    // (the ABI guard comes first: nothing else of *p may be read from a struct of another revision, and it needs no device)
     if (p->struct_size != (int32_t)sizeof(vslam_params) || p->abi_version != VSLAM_ABI_VERSION) {
         set_error("vslam_params from a different ABI (struct_size %d / abi_version %d, library has %d / %d): rebuild the caller against include/vslam_hip.h and "
                   "fill the struct with vslam_default_params", p->struct_size, p->abi_version, (int)sizeof(vslam_params), VSLAM_ABI_VERSION);
         return VSLAM_ERR_ARG;
     }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libvslam_hip has no CPU path)"); return VSLAM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return VSLAM_ERR_ARG; }
     if (p->max_batch <= 0 || p->kp_capacity < 64 || p->kp_capacity > kMaxRows || p->orb_nfeatures <= 0) { set_error("bad params (max_batch>0, 64<=kp_capacity<=%d)", kMaxRows); return VSLAM_ERR_ARG; }
     VS_HIP(hipSetDevice(device));
     Ctx* c = new Ctx();
     memset(c, 0, sizeof(*c));
     c->p = *p; c->device = device;
+    c->tune = Tuning();
+    c->lm.tune = &c->tune;
+    { int rc_t = tune_from_env(c->tune); if (rc_t) { delete c; return rc_t; } }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return VSLAM_ERR_HIP; }
@@ -366,7 +398,7 @@ int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stri
     VS_HIP(hipMemcpyAsync(d_in, kps, sizeof(vslam_keypoint) * n, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
-    const bool fused = 1 >= env_int("VSLAM_ORB_FUSE_MIN", 384); // (one image: the separate kernels unless a test forces the fused one)
+    const bool fused = 1 >= (c->tune.orb_fuse_min >= 0 ? c->tune.orb_fuse_min : 384); // (one image: the separate kernels unless a test forces the fused one)
     if (fused) { if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc; }
     else {
         if ((rc = launch_orb_pyramid(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->stream))) return rc;
@@ -456,7 +488,7 @@ int vslam_disparity_map_dev(vslam_ctx* ctx, const uint8_t* d_left, const uint8_t
     if (!c || !d_left || !d_right || w <= 0 || h <= 0 || pitch < w || B < 0 || img_stride_bytes < (size_t)pitch * h ||
         (!d_disparity && !d_disp_i16 && !d_disp_raw_i16)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     VS_ENTER(c);
-    return launch_sgbm(d_left, d_right, img_stride_bytes, pitch, w, h, B, d_disparity, d_disp_i16, d_disp_raw_i16, &c->d_sgbm, &c->sgbm_bytes,
+    return launch_sgbm(c->tune, d_left, d_right, img_stride_bytes, pitch, w, h, B, d_disparity, d_disp_i16, d_disp_raw_i16, &c->d_sgbm, &c->sgbm_bytes,
                        &c->dev_bytes, c->stream);
 }
 
@@ -475,12 +507,34 @@ int vslam_disparity_map(vslam_ctx* ctx, const uint8_t* left, const uint8_t* righ
     float* d_f = arena_take<float>(ar, npix);
     int16_t* d_i = arena_take<int16_t>(ar, npix);
     int16_t* d_raw = arena_take<int16_t>(ar, npix);
-    if ((rc = launch_sgbm(d_l, d_r, (size_t)pl * h, pl, w, h, 1, d_f, d_i, disp_raw_i16 ? d_raw : nullptr, &c->d_sgbm, &c->sgbm_bytes, &c->dev_bytes,
+    if ((rc = launch_sgbm(c->tune, d_l, d_r, (size_t)pl * h, pl, w, h, 1, d_f, d_i, disp_raw_i16 ? d_raw : nullptr, &c->d_sgbm, &c->sgbm_bytes, &c->dev_bytes,
                           c->stream))) return rc;
     if (disparity) VS_HIP(hipMemcpyAsync(disparity, d_f, npix * 4, hipMemcpyDeviceToHost, c->stream));
     if (disp_i16) VS_HIP(hipMemcpyAsync(disp_i16, d_i, npix * 2, hipMemcpyDeviceToHost, c->stream));
     if (disp_raw_i16) VS_HIP(hipMemcpyAsync(disp_raw_i16, d_raw, npix * 2, hipMemcpyDeviceToHost, c->stream));
+    int32_t st = 0;
+    return vslam_sgbm_status_dev(ctx, &st); // synchronises; VSLAM_ERR_HIP if the forward sweep's backstop fired
+}
+
+int vslam_set_tuning(vslam_ctx* ctx, const char* name, int value) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !name) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    for (const TuneKey& k : kTuneKeys)
+        if (!strcmp(k.name, name)) return tune_set(c->tune, k, value);
+    set_error("unknown tuning key \"%s\"", name);
+    return VSLAM_ERR_ARG;
+}
+
+int vslam_sgbm_status_dev(vslam_ctx* ctx, int32_t* h_status) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !h_status) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
+    *h_status = 0;
+    if (!c->d_sgbm) { VS_HIP(hipStreamSynchronize(c->stream)); return VSLAM_OK; } // no SGBM launch yet
+    // header of the SGBM scratch: int32 [0..7] ticket pools, [8] error word of the most recent launch (sgbm_kernels.hip, launch_sgbm)
+    VS_HIP(hipMemcpyAsync(h_status, c->d_sgbm + 32, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
+    if (*h_status != 0) { set_error("sgbm_forward_kernel: a slab waited for its predecessor beyond the spin limit; the disparity maps of this call are void"); return VSLAM_ERR_HIP; }
     return VSLAM_OK;
 }
 

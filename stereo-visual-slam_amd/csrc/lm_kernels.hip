@@ -2038,8 +2038,8 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0);
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 1); // (the landmark CSR of the first launch is still valid)
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 10, 1, 0, 1, 1);
-        // the pose-only pass: one wave per keyframe (pose_only_wave_kernel); VSLAM_POSE_ONLY_WINDOW=1 (tuning aid) keeps the window kernel
-        static const bool po_window = getenv("VSLAM_POSE_ONLY_WINDOW") != nullptr;
+        // the pose-only pass: one wave per keyframe (pose_only_wave_kernel); Tuning::pose_only_window = 1 (tuning aid / cross-check test) keeps the window kernel
+        const bool po_window = scratch->tune && scratch->tune->pose_only_window > 0;
         if (po_window) hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1);
         else {
             if (ka.dbg_cycles && getenv("VSLAM_PO_PROFILE")) hipMemsetAsync(ka.dbg_cycles, 0, sizeof(long long) * 16 * a.n_windows, stream); // show only this pass
@@ -2073,8 +2073,8 @@ int lm_fetch_status(const LmScratch* scratch, int n_windows, int32_t* h_status, 
 int launch_pnp(const PnpArgs& p, LmScratch* scratch, hipStream_t stream) {
     if (p.B <= 0) return VSLAM_OK;
     // one wave per problem unless the caller knows the problems are large (n_hint points: the window kernel's 512 lanes pay from ~1000
-    // points on); VSLAM_PNP_WINDOW=1 (tuning aid) forces the window kernel
-    static const bool force_window = getenv("VSLAM_PNP_WINDOW") != nullptr;
+    // points on); Tuning::pnp_window = 1 (tuning aid / cross-check test) forces the window kernel
+    const bool force_window = scratch->tune && scratch->tune->pnp_window > 0;
     if (!force_window && p.n_hint <= 1024) {
         ProfScope prof__(stream, "pnp_wave_kernel");
         hipLaunchKernelGGL(pnp_wave_kernel, dim3(p.B), dim3(64), 0, stream, p.xyz, p.uv, p.n, p.capacity, p.T, p.iters, p.K[0], p.K[1], p.K[2], p.K[3],

@@ -326,8 +326,10 @@ __global__ __launch_bounds__(kPathBlock) void sgbm_path_kernel(SgbmDims dm, cons
 // Slabs of one pair are chained through memory: the last row of slab k writes its downward vectors per pixel into a boundary buffer and
 // publishes its progress every 32 pixels (release fence + flag); slab k+1 stages the records 32 at a time into LDS, one chunk ahead,
 // with device-scope loads, after its first lane has seen the flag pass the chunk.  A workgroup only ever waits for ONE workgroup with
-// a lower index, workgroups are dispatched in index order, so the lowest unfinished one is always resident and never waits:
-// no co-residency requirement, no deadlock.  (A spin limit turns a violated assumption into a trap instead of a hang.)
+// a lower LOGICAL index, and the logical index is a ticket drawn from a per-launch atomic counter when the workgroup starts running (not
+// blockIdx: HIP does not promise dispatch order), so every lower ticket belongs to a workgroup that is resident or finished -- the lowest
+// unfinished one never waits: no co-residency requirement, no deadlock, whatever shares the device.  A spin limit remains as a backstop
+// against a wedged predecessor: it sets the launch's error word (the API reports VSLAM_ERR_HIP), releases the successors and returns.
 #ifndef VSLAM_SGBM_FW_CHUNK
 #define VSLAM_SGBM_FW_CHUNK 32
 #endif
@@ -340,7 +342,14 @@ template <int kFwRows>
 struct FwShared {
     uint32_t slot[2][kFwRows][16 * 9]; // [step parity][row][lane][path (-1,1), (0,1), (1,1)][3 dwords]
     uint32_t bnd[2][kFwChunk * kFwRecDw];
+    int ctl[2]; // [0] this workgroup's ticket (logical index), [1] abort flag of the spin-limit backstop
 };
+#ifndef VSLAM_SGBM_FW_ACQ
+#define VSLAM_SGBM_FW_ACQ 2
+#endif
+#ifndef VSLAM_SGBM_FW_SPIN_LIMIT
+#define VSLAM_SGBM_FW_SPIN_LIMIT (1 << 26) // polls of ~0.5 us: ~30 s
+#endif
 // The recurrence in packed 16-bit arithmetic (two disparities per register: L in [-P2, Cmax], delta <= Cmax + P2, kSent + P1 < 2^15 --
 // nothing leaves int16).  The vectors arrive packed from the volume and from the row above and leave packed: no unpacking at all.
 struct FwVec { short2v p[3]; }; // disparities (6r, 6r+1), (6r+2, 6r+3), (6r+4, 6r+5)
@@ -374,16 +383,51 @@ __device__ inline FwVec fw_path(const FwVec& l, const FwVec& c, short2v P1v, int
 }
 template <int kFwRows> // image rows per slab = DPP rows per workgroup: 64 for throughput, 32 when the batch alone cannot fill the chip (shorter steps, twice the workgroups)
 __global__ __launch_bounds__(kFwRows * 16) void sgbm_forward_kernel(SgbmDims dm, const int16_t* __restrict__ C, int16_t* __restrict__ S1,
-                                                                     uint32_t* bndg, int* flags, int nslab) {
+                                                                     uint32_t* bndg, int* flags, int* ctl, int nslab) {
     constexpr int kFwThreads = kFwRows * 16;
     constexpr int kFwStage = (kFwChunk * kFwRecDw + kFwThreads - 1) / kFwThreads; // dwords per thread of one staged chunk
     __shared__ FwShared<kFwRows> sm;
     // slab-major order: all first slabs of the batch, then all second slabs ... -- a slab still only waits for a lower index, and in a batch
     // that does not fit the chip at once a slab is dispatched when its predecessor is long under way (pair-major order made every workgroup
     // sit out the ~190 steps until the slab above has its first boundary pixels)
-    const int nb = gridDim.x / nslab;
-    const int slab = blockIdx.x / nb, b = blockIdx.x - slab * nb;
     const int tid = threadIdx.x, row_l = tid >> 4, r = tid & 15;
+    // Ticket = logical index, drawn when the workgroup STARTS RUNNING.  Eight ticket pools, one per XCD (pool p hands out the indices
+    // = p mod 8, ascending): a slab's predecessor is index - nb, and with nb a multiple of 8 it comes out of the same pool -- claimed
+    // earlier, hence resident or finished (the deadlock-freedom argument, per pool), and, when the workgroup draws from its own XCD's pool,
+    // running on the same XCD: the boundary records and the flag then travel through one L2 (drawing from a single global counter put
+    // chained slabs on unrelated XCDs: 2.9 -> 4.3 ms per 32 pairs).  The XCC id only picks the pool tried first -- speed, not correctness:
+    // a workgroup whose pool is exhausted takes an index from the next one (there are exactly as many indices as workgroups).
+    const int nb = gridDim.x / nslab;
+#if defined(VSLAM_SGBM_FW_NO_TICKET) // A/B aid only: logical index = blockIdx (relies on in-order dispatch)
+    if (tid == 0) { sm.ctl[0] = (int)blockIdx.x; sm.ctl[1] = 0; }
+#else
+    if (tid == 0) {
+        const int npool = (nb % 8 == 0) ? 8 : 1, ntot = gridDim.x;
+        const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % npool; // HW_REG_XCC_ID[3:0]
+        // A courtesy wait, bounded and irrelevant to correctness: when this workgroup's blockIdx says that t other workgroups of its XCD come
+        // first (the dispatch order observed on this part), give them a few microseconds to draw before it does.  With in-order dispatch
+        // every workgroup then gets ticket t == blockIdx / 8 of its pool -- early slabs on the chip first, late slabs doubling up with early ones on a CU --
+        // the placement the sweep was tuned on (a free-for-all draw on a fully resident grid cost 3.0 -> 4.0 ms at 32 pairs).
+        // (the XCC id is a permutation of blockIdx % 8 -- observed: block b on XCC (b + 7) % 8 -- so the turn is counted per pool, whatever its id)
+        if (npool == 8) {
+            const int th = (int)(blockIdx.x >> 3);
+            for (int spin = 0; spin < 256 && __hip_atomic_load(&ctl[xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < th; ++spin) __builtin_amdgcn_s_sleep(4);
+        }
+        int got = 0; // (never stays 0 unclaimed: ntot claims exist for ntot workgroups)
+        for (int k = 0; k < npool; ++k) {
+            const int p = (xcc + k) % npool;
+            const int cand = atomicAdd(&ctl[p], 1) * npool + p;
+            if (cand < ntot) { got = cand; break; }
+        }
+        sm.ctl[0] = got; sm.ctl[1] = 0;
+#ifdef VSLAM_SGBM_FW_DEBUG
+        printf("fw blk %d xcc %d lid %d t %lld\n", (int)blockIdx.x, xcc, got, (long long)wall_clock64());
+#endif
+    }
+#endif
+    __syncthreads();
+    const int lid = sm.ctl[0];
+    const int slab = lid / nb, b = lid - slab * nb;
     const int W1 = dm.width1, h = dm.h;
     const int y = slab * kFwRows + row_l;
     const bool rowok = y < h;
@@ -399,19 +443,33 @@ __global__ __launch_bounds__(kFwRows * 16) void sgbm_forward_kernel(SgbmDims dm,
     const size_t bnd_rec0 = (size_t)((W1 + kFwChunk - 1) / kFwChunk) * kFwChunk * kFwRecDw, bnd_run = bnd_rec0 + (size_t)kFwChunk * kFwRecDw;
     const uint32_t* bnd_in = bndg + ((size_t)b * (nslab - 1) + max(slab - 1, 0)) * bnd_run;
     uint32_t* bnd_out = bndg + ((size_t)b * (nslab - 1) + max(min(slab, nslab - 2), 0)) * bnd_run + r * 9;
-    int* flag_in = flags + max((int)blockIdx.x - nb, 0);
-    int* flag_out = flags + blockIdx.x;
+    int* flag_in = flags + max(lid - nb, 0);
+    int* flag_out = flags + lid;
     const bool writer = has_succ && row_l == kFwRows - 1; // (only the last slab has fewer than 64 image rows, and it has no successor)
     // wait until the slab above has published `need` pixels of its last row (first lane only; the workgroup follows through a barrier)
-    auto wait_pred = [&](int need) {
+    // Returns false (uniformly) when the backstop fired: the caller leaves the kernel through fw_abort.
+    auto wait_pred = [&](int need) -> bool {
         if (has_pred && tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1 << 26)) __builtin_trap(); // ~30 s: the dispatch-order assumption does not hold
+                if (++spins > VSLAM_SGBM_FW_SPIN_LIMIT) { sm.ctl[1] = 1; break; }
             }
         }
+#if VSLAM_SGBM_FW_ACQ == 2
+        if (has_pred && tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // polling wave only: the L1 it invalidates is the CU's
+#endif
         __syncthreads();
+#if VSLAM_SGBM_FW_ACQ == 1
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the records published before the flag are visible to the loads below
+#endif
+        return sm.ctl[1] == 0;
+    };
+    auto fw_abort = [&]() { // error word for the host, successors released (their results are void with the word set)
+        if (tid == 0) {
+            atomicExch(&ctl[8], 1);
+            __hip_atomic_store(flag_out, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
     // records first .. first + 31 of the slab above (device-scope loads: they were written by another workgroup, possibly through another L2)
     uint32_t stage[kFwStage];
@@ -431,7 +489,7 @@ __global__ __launch_bounds__(kFwRows * 16) void sgbm_forward_kernel(SgbmDims dm,
     };
     for (int i = tid; i < 2 * kFwRows * 16 * 9; i += kFwThreads) (&sm.slot[0][0][0])[i] = 0;
     // chunk 0 = records 1 .. 32 (row 0 at step t reads the record of pixel t + 1)
-    wait_pred(min(W1, 1 + kFwChunk));
+    if (!wait_pred(min(W1, 1 + kFwChunk))) { fw_abort(); return; }
     stage_load(1);
     stage_store(0);
     __syncthreads();
@@ -452,7 +510,7 @@ __global__ __launch_bounds__(kFwRows * 16) void sgbm_forward_kernel(SgbmDims dm,
     const int nsteps = W1 + 2 * (kFwRows - 1);
     for (int t0 = 0; t0 < nsteps; t0 += kFwChunk) {
         const int chunk = t0 / kFwChunk;
-        wait_pred(min(W1, 1 + (chunk + 2) * kFwChunk));        // records of chunk + 1: pixels 32 (chunk + 1) + 1 .. + 32
+        if (!wait_pred(min(W1, 1 + (chunk + 2) * kFwChunk))) { fw_abort(); return; } // records of chunk + 1: pixels 32 (chunk + 1) + 1 .. + 32
         stage_load(1 + (chunk + 1) * kFwChunk);
         for (int u0 = 0; u0 < kFwChunk; u0 += kFwPF) {
 #pragma unroll
@@ -878,7 +936,7 @@ __global__ __launch_bounds__(256) void sgbm_ccl_apply_kernel(int w, int h, int n
 }
 
 // ------------------------------------------------------------------------------------------- host driver
-int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
+int launch_sgbm(const Tuning& tune, const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
                 int16_t* d_disp_i16, int16_t* d_disp_raw, uint8_t** scratch, size_t* scratch_bytes, size_t* dev_bytes, hipStream_t stream) {
     if (B <= 0) return VSLAM_OK;
     SgbmDims dm;
@@ -888,7 +946,7 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     if (dm.width1 <= dm.SW2 || h <= 2 * dm.SH2 + 1 || w > 4096) { set_error("image size unsupported (need 100 < w <= 4096, h > 9)"); return VSLAM_ERR_ARG; }
     const size_t vol = (size_t)h * dm.width1 * dm.D, npix = (size_t)w * h;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t need = 0;
+    size_t need = 256; // header: int32 [0..7] ticket pools of the forward sweep, [8] its error word (vslam_sgbm_status_dev)
     const size_t o_pre = need; need += al((size_t)2 * B * h * 6 * w);
     const size_t o_hs = need; need += al((size_t)B * vol * 2);
     const size_t o_C = need; need += al((size_t)B * vol * 2);
@@ -901,9 +959,8 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     // forward sweep: 32-row slabs (workgroups of 512 threads, two per CU) up to 32 pairs, 64-row slabs above.  The slabs of a pair are a chain
     // of ~2 200 (64 rows) / ~2 600 (32 rows) steps and a step's time is mostly its latency (barrier, LDS mailbox, the dependent minimum ->
     // delta -> update chain), so shorter workgroups win until the chip is full: 16 / 24 / 32 / 40 pairs 2.33 / 2.60 / 2.93 / 3.45 ms with 32
-    // rows, 3.01 / 3.06 / 3.19 / 3.35 ms with 64 (48-row slabs: 2.64 / 2.76 / 2.92 / 3.31 -- no better anywhere).  VSLAM_SGBM_FW_ROWS overrides.
-    const char* rows_env = getenv("VSLAM_SGBM_FW_ROWS");
-    const int fw_rows = (rows_env && *rows_env) ? (atoi(rows_env) == 32 ? 32 : 64) : (B <= 32 ? 32 : 64);
+    // rows, 3.01 / 3.06 / 3.19 / 3.35 ms with 64 (48-row slabs: 2.64 / 2.76 / 2.92 / 3.31 -- no better anywhere).  Tuning::sgbm_fw_rows overrides.
+    const int fw_rows = tune.sgbm_fw_rows > 0 ? tune.sgbm_fw_rows : (B <= 32 ? 32 : 64);
     const int nslab = (h + fw_rows - 1) / fw_rows;
     const size_t o_bnd = need; need += al((size_t)B * (nslab > 1 ? nslab - 1 : 1) * ((dm.width1 + kFwChunk - 1) / kFwChunk + 1) * kFwChunk * kFwRecDw * 4);
     const size_t o_flag = need; need += al((size_t)B * nslab * 4);
@@ -915,6 +972,7 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
         *scratch_bytes = need; *dev_bytes += need;
     }
     uint8_t* base = *scratch;
+    VS_HIP(hipMemsetAsync(base, 0, 64, stream)); // ticket pools + error word of this launch
     uint8_t* pre = base + o_pre; int16_t* hsum = (int16_t*)(base + o_hs); int16_t* C = (int16_t*)(base + o_C);
     uint16_t* T = (uint16_t*)(base + o_T); int4* rec = (int4*)(base + o_rec);
     int16_t* d0 = (int16_t*)(base + o_d0); int16_t* d1 = (int16_t*)(base + o_d1); int* par = (int*)(base + o_par); int* cnt = (int*)(base + o_cnt);
@@ -922,20 +980,18 @@ int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes,
     { ProfScope p(stream, "sgbm_prefilter_kernel"); hipLaunchKernelGGL(sgbm_prefilter_kernel, dim3((w + 255) / 256, h, 2 * B), dim3(256), 0, stream, dm, d_left, d_right, pre); }
     // The fused top-down kernel sweeps the rows sequentially with 48 workgroups per pair: it pays from 8 pairs per call on (2.65 vs 4.08 ms
     // at 32 pairs); below that the three massively parallel kernels it replaces are faster (0.99 vs 1.31 ms for one pair).
-    // VSLAM_SGBM_FUSE_MIN overrides the threshold (tests run both paths).
-    const char* fuse_env = getenv("VSLAM_SGBM_FUSE_MIN");
-    const bool unfused = B < ((fuse_env && *fuse_env) ? atoi(fuse_env) : 8);
+    // Tuning::sgbm_fuse_min overrides the threshold (tests run both paths).
+    const bool unfused = B < (tune.sgbm_fuse_min >= 0 ? tune.sgbm_fuse_min : 8);
     // ... and from there on the four forward paths run as one wavefront sweep (sgbm_forward_kernel) instead of one kernel per path.
-    // The slabs of a pair are a chain (about 2200 sequential steps): it pays from 16 pairs per call on.  VSLAM_SGBM_FWD_MIN overrides.
-    const char* fwd_env = getenv("VSLAM_SGBM_FWD_MIN");
-    const bool fwd = !unfused && B >= ((fwd_env && *fwd_env) ? atoi(fwd_env) : 16);
+    // The slabs of a pair are a chain (about 2200 sequential steps): it pays from 16 pairs per call on.  Tuning::sgbm_fwd_min overrides.
+    const bool fwd = !unfused && B >= (tune.sgbm_fwd_min >= 0 ? tune.sgbm_fwd_min : 16);
     if (!unfused && !fwd) { ProfScope p(stream, "sgbm_down_kernel"); hipLaunchKernelGGL(sgbm_down_kernel<true>, dim3((dm.width1 + kDnCols - 1) / kDnCols, B), dim3(kDnThreads), 0, stream, dm, pre, C, T); }
     if (fwd) {
         { ProfScope p(stream, "sgbm_down_kernel"); hipLaunchKernelGGL(sgbm_down_kernel<false>, dim3((dm.width1 + kDnCols - 1) / kDnCols, B), dim3(kDnThreads), 0, stream, dm, pre, C, T); }
         VS_HIP(hipMemsetAsync(base + o_flag, 0, (size_t)B * nslab * 4, stream));
         ProfScope p(stream, "sgbm_forward_kernel");
-        if (fw_rows == 64) hipLaunchKernelGGL(sgbm_forward_kernel<64>, dim3(B * nslab), dim3(64 * 16), 0, stream, dm, C, (int16_t*)T, (uint32_t*)(base + o_bnd), (int*)(base + o_flag), nslab);
-        else hipLaunchKernelGGL(sgbm_forward_kernel<32>, dim3(B * nslab), dim3(32 * 16), 0, stream, dm, C, (int16_t*)T, (uint32_t*)(base + o_bnd), (int*)(base + o_flag), nslab);
+        if (fw_rows == 64) hipLaunchKernelGGL(sgbm_forward_kernel<64>, dim3(B * nslab), dim3(64 * 16), 0, stream, dm, C, (int16_t*)T, (uint32_t*)(base + o_bnd), (int*)(base + o_flag), (int*)base, nslab);
+        else hipLaunchKernelGGL(sgbm_forward_kernel<32>, dim3(B * nslab), dim3(32 * 16), 0, stream, dm, C, (int16_t*)T, (uint32_t*)(base + o_bnd), (int*)(base + o_flag), (int*)base, nslab);
     }
     if (unfused) { ProfScope p(stream, "sgbm_hsum_kernel"); hipLaunchKernelGGL(sgbm_hsum_kernel, dim3((dm.width1 + kHsSeg - 1) / kHsSeg, h, B), dim3(kHsBlock), 0, stream, dm, pre, hsum); }
     if (unfused) { ProfScope p(stream, "sgbm_vsum_kernel"); hipLaunchKernelGGL(sgbm_vsum_kernel, dim3((dm.width1 * 12 + 255) / 256, (h + kVsChunk - 1) / kVsChunk, B), dim3(256), 0, stream, dm, hsum, C); }

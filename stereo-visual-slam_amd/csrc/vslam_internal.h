@@ -189,7 +189,18 @@ struct LmWindowArgs {
 };
 // mode 0 = optimize_map (EdgeProjection + Schur), 1 = optimize_pose_only.
 // sgbm_kernels.hip.  *scratch / *scratch_bytes: caller-owned growable device buffer.
-int launch_sgbm(const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
+// Kernel-choice overrides of a context (tuning aid / tests): -1 = the library's batch-size rule.  Seeded ONCE at vslam_create from the
+// VSLAM_* environment variables of the same names (validated there), changed afterwards only through vslam_set_tuning -- no getenv on
+// the call path (it races with a host that mutates its environment).
+struct Tuning {
+    int orb_fuse_min = -1;    // VSLAM_ORB_FUSE_MIN: images per call from which orb_pyrblur_kernel replaces resize + blur
+    int sgbm_fuse_min = -1;   // VSLAM_SGBM_FUSE_MIN: pairs per call from which sgbm_down_kernel replaces hsum / vsum / path<0,1>
+    int sgbm_fwd_min = -1;    // VSLAM_SGBM_FWD_MIN: pairs per call from which sgbm_forward_kernel replaces three path kernels
+    int sgbm_fw_rows = -1;    // VSLAM_SGBM_FW_ROWS: 32 or 64 image rows per slab of the forward sweep
+    int pose_only_window = -1; // VSLAM_POSE_ONLY_WINDOW: 1 = the schedule's pose-only pass on lm_window_kernel instead of pose_only_wave_kernel
+    int pnp_window = -1;      // VSLAM_PNP_WINDOW: 1 = single-pose problems on lm_window_kernel<pnp> instead of pnp_wave_kernel
+};
+int launch_sgbm(const Tuning& tune, const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
                 int16_t* d_disp_i16, int16_t* d_disp_raw, uint8_t** scratch, size_t* scratch_bytes, size_t* dev_bytes, hipStream_t stream);
 size_t sgbm_scratch_bytes(int w, int h, int B);
 
@@ -197,6 +208,7 @@ size_t sgbm_scratch_bytes(int w, int h, int B);
 struct LmScratch {
     void* buf = nullptr; size_t bytes = 0;
     int32_t* status = nullptr; int status_n = 0;
+    const Tuning* tune = nullptr; // the owning context's overrides
     bool lds_opt_in = false; // the > 64 KB dynamic-LDS attribute of lm_window_kernel has been set on this context's device
 };
 int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms, LmScratch* scratch,
@@ -233,6 +245,7 @@ struct Ctx {
     // SGBM working set (cost volumes; grown on demand by vslam_disparity_map*)
     uint8_t* d_sgbm; size_t sgbm_bytes;
     LmScratch lm;
+    Tuning tune;
     Prof* prof;           // stage profiler of this context (vslam_profile_enable); null until first enabled
 };
 

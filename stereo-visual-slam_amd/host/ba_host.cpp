@@ -121,6 +121,7 @@ bool g_backend_q1 = true;
 } // namespace
 
 void set_optimizer_backend(vslam_ctx* ctx, bool q1_quirk) { g_backend_ctx = ctx; g_backend_q1 = q1_quirk; }
+void clear_optimizer_backend(vslam_ctx* ctx) { if (g_backend_ctx == ctx) g_backend_ctx = nullptr; }
 vslam_ctx* optimizer_backend() { return g_backend_ctx; }
 
 void optimize_map(std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks, const Mat33& K,

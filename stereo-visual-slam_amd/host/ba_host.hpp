@@ -22,6 +22,7 @@ void optimize_pose_only(vslam_ctx* ctx, std::unordered_map<unsigned long, Frame>
 // backend below, which VO's constructor sets to its own context (the reference's optimisers are free functions with no state either;
 // the GPU context is this build's only addition and lives behind this accessor).
 void set_optimizer_backend(vslam_ctx* ctx, bool q1_quirk = true);
+void clear_optimizer_backend(vslam_ctx* ctx); // no-op unless ctx is the bound one; call before vslam_destroy(ctx)
 vslam_ctx* optimizer_backend();
 void optimize_map(std::unordered_map<unsigned long, Frame>& keyframes, std::unordered_map<unsigned long, Landmark>& landmarks, const Mat33& K,
                   bool if_update_map, bool if_update_landmark, int num_ite);

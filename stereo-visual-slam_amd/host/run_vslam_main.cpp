@@ -95,6 +95,7 @@ int main(int argc, char** argv) {
                 my_map.keyframes_.size(), my_map.landmarks_.size(), my_VO.num_inliers_);
     const auto t = my_VO.T_c_w_.inverse().translation();
     std::printf("final_position %.6f %.6f %.6f\n", t[0], t[1], t[2]);
+    vslam::clear_optimizer_backend(ctx); // (my_VO outlives this statement: unbind before the context goes)
     vslam_destroy(ctx);
     return 0;
 }

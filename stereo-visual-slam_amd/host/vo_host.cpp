@@ -122,10 +122,12 @@ int ImageSource::read(int id, Image& left, Image& right) const {
 
 // ---------------------------------------------------------------------------------------------- kernels behind methods
 // visual_odometry.hpp:69 `VO(std::string dataset, ros::NodeHandle&, Map&)`: the node handle's place is taken by the GPU context, which also
-// becomes the backend of the free optimize_map / optimize_pose_only functions (ba_host.hpp)
+// becomes the backend of the free optimize_map / optimize_pose_only functions (ba_host.hpp).  The LATEST VO binds (a second VO on another
+// context must not silently optimise on the first one's), and a VO that goes away unbinds its context: the pointer never outlives its owner.
 VO::VO(std::string dataset, vslam_ctx* ctx, Map& map) : my_map_(map), source_(std::move(dataset)), ctx_(ctx) {
-    if (!optimizer_backend()) set_optimizer_backend(ctx);
+    set_optimizer_backend(ctx);
 }
+VO::~VO() { clear_optimizer_backend(ctx_); }
 
 int VO::feature_detection(const Image& img, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors) {
     if (img.empty()) { std::cout << "Could not open or find the image" << std::endl; return -1; } // :73-77

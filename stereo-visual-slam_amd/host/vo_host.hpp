@@ -51,6 +51,9 @@ public:
     uint64_t last_match_hash_ = 0; // FNV-1a over (queryIdx, trainIdx, distance) of the gated frame-to-frame matches
 
     VO(std::string dataset, vslam_ctx* ctx, Map& map);
+    ~VO();
+    VO(const VO&) = delete;
+    VO& operator=(const VO&) = delete;
 
     int read_img(int id, Image& left_img, Image& right_img) { return source_.read(id, left_img, right_img); }
     int feature_detection(const Image& img, std::vector<KeyPoint>& keypoints, DescriptorMat& descriptors);

@@ -19,12 +19,12 @@ def kps_equal(x, y):
 
 def one_case(kind, rng, vo, pkg, O, synth):
     def fail(what, **kw):
-        raise Mismatch("MISMATCH %s %r (fuse_min %s fwd_min %s rows %s)" % (what, kw, os.environ.get("VSLAM_ORB_FUSE_MIN"), os.environ.get("VSLAM_SGBM_FWD_MIN"), os.environ.get("VSLAM_SGBM_FW_ROWS")))
+        raise Mismatch("MISMATCH %s %r (fuse_min %s fwd_min %s rows %s)" % (what, kw, forced, fwd, rows))
     seed = int(rng.integers(1 << 30))
     # the fused ORB / SGBM kernels are picked by batch size (large batches only); the fuzz cases are single items, so half of them force the fused path
     forced = "1" if rng.random() < 0.5 else "1000000"
-    os.environ["VSLAM_ORB_FUSE_MIN"] = forced; os.environ["VSLAM_SGBM_FUSE_MIN"] = forced
-    os.environ["VSLAM_SGBM_FWD_MIN"] = forced if rng.random() < 0.8 else "1000000"; os.environ["VSLAM_SGBM_FW_ROWS"] = "32" if rng.random() < 0.5 else "64"
+    fwd = forced if rng.random() < 0.8 else "1000000"; rows = "32" if rng.random() < 0.5 else "64"
+    vo.set_tuning(orb_fuse_min=int(forced), sgbm_fuse_min=int(forced), sgbm_fwd_min=int(fwd), sgbm_fw_rows=int(rows))
     if kind == "match":
         nq, nt = int(rng.integers(1, 2200)), int(rng.integers(1, 2200))
         if rng.random() < 0.2: nq = int(rng.integers(1, 70))
@@ -106,7 +106,8 @@ def run(seconds=120.0, seed=0, only="", vo=None, max_cases=None, schedule=None):
             n[kind] += 1
             i += 1
     finally:
-        for k in ("VSLAM_ORB_FUSE_MIN", "VSLAM_SGBM_FUSE_MIN", "VSLAM_SGBM_FWD_MIN", "VSLAM_SGBM_FW_ROWS"): os.environ.pop(k, None)
+        if not own:
+            vo.set_tuning(orb_fuse_min=-1, sgbm_fuse_min=-1, sgbm_fwd_min=-1, sgbm_fw_rows=-1)
         if own:
             vo.close()
     return n

@@ -111,3 +111,21 @@ def test_params_abi_guard():
     assert lib.vslam_abi_version() == pkg.ABI_VERSION
     p = pkg.default_params()
     assert p.struct_size == ctypes.sizeof(pkg.Params) and p.abi_version == pkg.ABI_VERSION
+
+
+def test_params_abi_guard_refuses_mismatch():
+    """vslam_create REFUSES a vslam_params of another size / revision (VSLAM_ERR_ARG), checked before a device is looked for.
+    Runs against the HIP library (argument checks need no GPU) and against the CPU shim of the same header."""
+    import stereo_visual_slam_amd as pkg
+    libs = [pkg.load_library()]
+    shim = os.path.join(ROOT, "oracle", "libvslam_cpu_shim.so")
+    if os.path.exists(shim):
+        libs.append(ctypes.CDLL(shim))
+    for lib in libs:
+        lib.vslam_create.argtypes = [ctypes.POINTER(pkg.Params), ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        for field, value in (("struct_size", ctypes.sizeof(pkg.Params) - 4), ("abi_version", pkg.ABI_VERSION - 1), ("struct_size", 0)):
+            p = pkg.default_params()
+            setattr(p, field, value)
+            h = ctypes.c_void_p()
+            assert lib.vslam_create(ctypes.byref(p), 0, None, ctypes.byref(h)) == pkg.VSLAM_ERR_ARG, (field, value)
+            assert not h.value

@@ -1,8 +1,8 @@
 """The fused kernels of round 3 (orb_pyrblur_kernel, sgbm_down_kernel, sgbm_forward_kernel) are chosen by batch size (large batches only:
 below ~300 images / 8-16 stereo pairs the separate kernels are faster).  The parity suite runs small batches, so every check here is
 executed with the thresholds forced down to 1 (fused kernels; the SGBM forward sweep once with 64-row and once with 32-row slabs) and
-forced up (separate kernels) through VSLAM_ORB_FUSE_MIN / VSLAM_SGBM_FUSE_MIN / VSLAM_SGBM_FWD_MIN / VSLAM_SGBM_FW_ROWS, which the library
-reads on every call."""
+forced up (separate kernels) through VSLAM_ORB_FUSE_MIN / VSLAM_SGBM_FUSE_MIN / VSLAM_SGBM_FWD_MIN / VSLAM_SGBM_FW_ROWS, which seed a
+context's overrides when it is CREATED (every test below creates its context after the fixture ran; vslam_set_tuning changes them later)."""
 import numpy as np
 import pytest
 

@@ -134,3 +134,65 @@ def test_pnp_ransac_too_few_points(vo, synth):
     p = synth.pnp_problem(M=4, seed=1)
     T, inl, n, it = vo.motion_estimation_ransac(p["xyz"], p["uv"], p["T0"])
     assert n == 0 and it == 0 and np.array_equal(T, p["T0"])
+
+
+def test_pnp_wave_vs_window_kernel_around_crossover(pkg, oracle, synth):
+    """the single-pose problem has two implementations (pnp_wave_kernel up to 1024 points, lm_window_kernel<pnp> above) with
+    different summation orders: cross-check them on the SAME inputs around the crossover, both against the oracle."""
+    ctx = pkg.VO(device=0, max_batch=1)
+    try:
+        for M, seed in ((1000, 21), (1024, 22), (1100, 23)):
+            p = synth.pnp_problem(M=M, seed=seed)
+            ctx.set_tuning(pnp_window=0)
+            aT, ainl, an, ast = ctx.motion_estimation(p["xyz"], p["uv"], p["T0"], iters=10)   # M <= 1024: wave kernel, above: window kernel
+            ctx.set_tuning(pnp_window=1)
+            bT, binl, bn, bst = ctx.motion_estimation(p["xyz"], p["uv"], p["T0"], iters=10)   # always the window kernel
+            ctx.set_tuning(pnp_window=-1)
+            wT, winl, wn, wst = oracle.pnp_motion_only(p["xyz"], p["uv"], p["T0"], iters=10)
+            for T, inl, n, st in ((aT, ainl, an, ast), (bT, binl, bn, bst)):
+                assert np.allclose(T, wT, rtol=RTOL, atol=1e-7)
+                assert n == wn and (inl == winl).all()
+                _stats_close(st, wst)
+            assert np.allclose(aT, bT, rtol=1e-6, atol=1e-9)   # (two summation orders of the same sums)
+    finally:
+        ctx.close()
+
+
+def test_schedule_pose_only_wave_vs_window_kernel(pkg, synth):
+    """the schedule's fourth pass runs pose_only_wave_kernel, the standalone optimize_pose_only runs lm_window_kernel (mode 1): the same
+    optimisation, two summation orders -- run the device schedule with either kernel on the same windows and compare every output"""
+    import torch
+    wins = [synth.ba_window_fast(n_kf=10, n_lm=700, seed=300 + i) for i in range(3)]
+    lm_off = np.cumsum([0] + [len(w["xyz"]) for w in wins]).astype(np.int32)
+    e_off = np.cumsum([0] + [len(w["kf_idx"]) for w in wins]).astype(np.int32)
+    ctx = pkg.VO(device=0, max_batch=1)
+    try:
+        outs = []
+        for force in (0, 1):
+            ctx.set_tuning(pose_only_window=force)
+            d = "cuda"
+            T = torch.from_numpy(np.stack([w["T0"] for w in wins])).to(d)
+            xyz = torch.from_numpy(np.concatenate([w["xyz"] for w in wins])).to(d)
+            kf = torch.from_numpy(np.concatenate([w["kf_idx"] for w in wins])).to(d)
+            lm = torch.from_numpy(np.concatenate([w["lm_idx"] for w in wins])).to(d)
+            uv = torch.from_numpy(np.concatenate([w["uv"] for w in wins])).to(d)
+            inl = torch.ones(int(lm_off[-1]), dtype=torch.uint8, device=d)
+            chi = torch.zeros(int(e_off[-1]), dtype=torch.float64, device=d)
+            t_lm, t_e = torch.from_numpy(lm_off).to(d), torch.from_numpy(e_off).to(d)
+            bb = pkg.BaBatch()
+            bb.n_windows = 3; bb.n_kf = 10
+            bb.d_lm_off = t_lm.data_ptr(); bb.d_edge_off = t_e.data_ptr(); bb.d_T_c_w = T.data_ptr(); bb.d_xyz = xyz.data_ptr()
+            bb.d_reliable = None; bb.d_lm_inlier = inl.data_ptr(); bb.d_kf_idx = kf.data_ptr(); bb.d_lm_idx = lm.data_ptr(); bb.d_uv = uv.data_ptr()
+            bb.d_chi2 = chi.data_ptr(); bb.d_stats = None; bb.total_lm = int(lm_off[-1]); bb.total_edge = int(e_off[-1])
+            torch.cuda.synchronize()
+            ctx.ba_batch_dev(bb, schedule=1)
+            ctx.sync()
+            assert (ctx.ba_status(3) == 0).all()
+            outs.append((T.cpu().numpy(), inl.cpu().numpy(), chi.cpu().numpy()))
+        (Ta, ia, ca), (Tb, ib, cb) = outs
+        assert np.allclose(Ta, Tb, rtol=1e-6, atol=1e-8), np.abs(Ta - Tb).max()
+        assert (ia == ib).all()
+        assert np.allclose(ca, cb, rtol=1e-6, atol=1e-9)
+        assert not np.allclose(Ta, np.stack([w["T0"] for w in wins]))   # the schedule moved the poses
+    finally:
+        ctx.close()
