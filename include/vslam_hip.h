@@ -39,7 +39,7 @@ extern "C" {
  * vslam_local_ba / vslam_pose_only_window; revision 3 added struct_size / abi_version to vslam_params and the alignment contract
  * of vslam_feature_matching_dev).  vslam_create refuses a vslam_params whose struct_size / abi_version do not match the library's,
  * so a caller compiled against an older header fails with VSLAM_ERR_ARG instead of having its arguments reinterpreted. */
-#define VSLAM_ABI_VERSION 3
+#define VSLAM_ABI_VERSION 4
 
 #define VSLAM_ORB_NLEVELS 8
 #define VSLAM_MAX_KF 12          /* keyframes per optimisation window (reference: Map::num_keyframes_ = 10, map.hpp:22) */
@@ -238,7 +238,8 @@ int vslam_pose_only_window(vslam_ctx* ctx, int n_kf, double* T_c_w, int n_lm, co
                            int iters, int update_poses, uint8_t* lm_inlier, double* chi2_out,
                            double* chi2_threshold_out, vslam_lm_stats* stats);
 
-/* Batched, device-resident windows (throughput mode).  All windows share n_kf.
+/* Batched, device-resident windows (throughput mode).  n_kf = keyframe slots per window (the stride of
+ * d_T_c_w); window w uses the first d_n_kf[w] of them (NULL: all windows have n_kf keyframes).
  * Window w owns landmarks [lm_off[w], lm_off[w+1]) and edges [edge_off[w], edge_off[w+1]) of the concatenated
  * arrays; edges MUST be sorted by landmark inside a window (lm_idx ascending) with lm_idx/kf_idx window-local.
  * One call runs the reference's per-keyframe schedule (run_vslam.cpp:58-71) when schedule = 1:
@@ -260,9 +261,45 @@ typedef struct vslam_ba_batch {
     vslam_lm_stats* d_stats;      /* n_windows (last pass) or NULL */
     int32_t total_lm, total_edge;
     const double* K4;             /* HOST pointer to {fx, fy, cx, cy} (the optimisers' `const cv::Mat& K`), NULL = context intrinsics */
+    const int32_t* d_n_kf;        /* n_windows: keyframes of window w (1..n_kf), e.g. the growing map at the start of a sequence; NULL = n_kf */
 } vslam_ba_batch;
 int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* batch, int schedule, int mode, int iters,
                        int update_poses, int update_lms);
+
+/* ------------------------------------------------------------------ graph construction on the device --
+ * The BA half of a throughput-mode step built from the front-end's own output: replaces, for a batch of n_frames CONSECUTIVE
+ * keyframes, the landmark / observation bookkeeping of VO::insert_key_frame (visual_odometry.cpp:363-424) and the graph build of
+ * optimize_map / optimize_pose_only (optimization.cpp:127-214, :303-361).  Frame f = batch item f.  A frame's features are its
+ * keypoints that the pose stage kept as inliers of a frame-to-frame match (they observe the landmark of the matched feature of
+ * frame f - 1, :592-599) plus every other keypoint with a valid depth (it creates a landmark, :403-421); a landmark with an
+ * unreliable depth takes the point of its first later observation with a reliable one (:391-401).  Window b = the map right after
+ * keyframe b: keyframes [max(0, b - n_kf + 1), b], every landmark they observe (position and reliable flag as of frame b, world
+ * = frame 0 through the chained relative poses), one edge per observation, edges landmark-major (landmarks ordered by their first
+ * observation inside the window: frame, then keypoint index), lm_idx / kf_idx window-local, is_inlier = 1.
+ * All pointers are device pointers. */
+typedef struct vslam_tracks_in {
+    int32_t n_frames;
+    int32_t kp_capacity, lr_capacity, match_capacity, pnp_capacity;
+    const vslam_keypoint* d_kps;   /* n_frames x kp_capacity: left keypoints */
+    const vslam_dmatch* d_lr;      /* n_frames x lr_capacity: depth association of frame f, queryIdx = left keypoint (L/R matches; the identity
+                                      list when the depth comes from the disparity map) */
+    const int32_t* d_nlr;          /* n_frames */
+    const float* d_xyz;            /* n_frames x lr_capacity x 3: point of association m in the CAMERA frame of frame f (T_c_w = identity) */
+    const uint8_t* d_valid;        /* n_frames x lr_capacity: the depth gates of set_ref_3d_position passed (:199) */
+    const uint8_t* d_reliable;     /* n_frames x lr_capacity: reliable_depth_ (:201) */
+    const vslam_dmatch* d_f2f;     /* (n_frames - 1) x match_capacity: item i = matches frame i (query) -> frame i + 1 (train) */
+    const int32_t* d_nf2f;         /* n_frames - 1 */
+    const uint8_t* d_pose_inlier;  /* (n_frames - 1) x pnp_capacity: inlier flag of input j of item i's pose problem, inputs in the order
+                                      vslam_build_pnp_inputs_dev emitted them */
+    const double* d_T_rel;         /* (n_frames - 1) x 7: T_{i+1,i}, the pose stage's estimate with frame i as the world */
+} vslam_tracks_in;
+/* Fills the device arrays of `out` (caller-allocated: d_lm_off / d_edge_off n_frames + 1, d_T_c_w n_frames x n_kf x 7, d_xyz /
+ * d_reliable / d_lm_inlier for lm_capacity landmarks, d_kf_idx / d_lm_idx / d_uv for edge_capacity edges, d_n_kf n_frames; the
+ * const members are written through) and its scalar members (n_windows = n_frames, n_kf, total_lm = lm_capacity, total_edge =
+ * edge_capacity: bounds).  d_status (1 int32): 0, or 1 when a capacity was too small -- the windows from the first one that did
+ * not fit are then emitted empty.  Asynchronous on the context stream; `out` can go straight into vslam_ba_batch_dev. */
+int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf, int lm_capacity, int edge_capacity, vslam_ba_batch* out,
+                            int32_t* d_status);
 
 /* per-window status of the most recent window launch on this process (VSLAM_OK or VSLAM_ERR_ARG per window) */
 int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status);

@@ -29,7 +29,7 @@ class OrbLayout(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orb.c", "match.c", "geom.c", "lm.c", "sgbm.c", "ransac.c", "epnp.c", "cpu_shim.c", "vo_oracle.h", "orb_pattern.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb.c", "match.c", "geom.c", "lm.c", "sgbm.c", "ransac.c", "epnp.c", "windows.c", "cpu_shim.c", "vo_oracle.h", "orb_pattern.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -391,6 +391,33 @@ def pnp_ransac(xyz, uv, T0=None, K=K_KITTI, max_iters=100, reproj_err=4.0, confi
     n = lib().vo_pnp_ransac(_p(xyz), _p(uv), len(xyz), _p(_d(K, 4)), _p(T), int(max_iters), C.c_double(reproj_err), C.c_double(confidence),
                             int(lm_iters), _p(inl), C.byref(it))
     return T, inl[:len(xyz)], n, it.value
+
+
+def build_windows(kps, lr, nlr, xyz, valid, reliable, f2f, nf2f, pose_inlier, T_rel, n_kf=10, lm_capacity=None, edge_capacity=None):
+    """windows.c: the BA windows of a batch of consecutive keyframes from the front end's per-frame results.
+    kps (F, kp_cap) KEYPOINT_DTYPE; lr (F, lr_cap) DMATCH_DTYPE; xyz (F, lr_cap, 3); valid / reliable (F, lr_cap);
+    f2f (F-1, match_cap) DMATCH_DTYPE; pose_inlier (F-1, pnp_cap); T_rel (F-1, 7).  Returns a dict of the vslam_ba_batch arrays."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); lr = np.ascontiguousarray(lr, DMATCH_DTYPE); f2f = np.ascontiguousarray(f2f, DMATCH_DTYPE)
+    F, kp_cap = kps.shape; lr_cap = lr.shape[1]
+    match_cap = f2f.shape[1] if f2f.ndim == 2 and f2f.shape[0] else 1
+    pose_inlier = np.ascontiguousarray(pose_inlier, np.uint8)
+    pnp_cap = pose_inlier.shape[1] if pose_inlier.ndim == 2 and pose_inlier.shape[0] else 1
+    nlr = np.ascontiguousarray(nlr, np.int32); nf2f = np.ascontiguousarray(nf2f, np.int32)
+    xyz = np.ascontiguousarray(xyz, np.float32); valid = np.ascontiguousarray(valid, np.uint8); reliable = np.ascontiguousarray(reliable, np.uint8)
+    T_rel = np.ascontiguousarray(T_rel, np.float64)
+    lm_capacity = lm_capacity or F * kp_cap; edge_capacity = edge_capacity or F * kp_cap * 2
+    out = dict(lm_off=np.zeros(F + 1, np.int32), edge_off=np.zeros(F + 1, np.int32), n_kf=np.zeros(F, np.int32),
+               T=np.zeros((F, n_kf, 7), np.float64), xyz=np.zeros((lm_capacity, 3), np.float32), reliable=np.zeros(lm_capacity, np.uint8),
+               lm_inlier=np.zeros(lm_capacity, np.uint8), kf_idx=np.zeros(edge_capacity, np.int32), lm_idx=np.zeros(edge_capacity, np.int32),
+               uv=np.zeros((edge_capacity, 2), np.float32))
+    rc = lib().vo_build_windows(F, kp_cap, lr_cap, match_cap, pnp_cap, _p(kps), _p(lr), _p(nlr), _p(xyz), _p(valid), _p(reliable), _p(f2f), _p(nf2f),
+                                _p(pose_inlier), _p(T_rel), int(n_kf), int(lm_capacity), int(edge_capacity), _p(out["lm_off"]), _p(out["edge_off"]),
+                                _p(out["n_kf"]), _p(out["T"]), _p(out["xyz"]), _p(out["reliable"]), _p(out["lm_inlier"]), _p(out["kf_idx"]),
+                                _p(out["lm_idx"]), _p(out["uv"]))
+    if rc < 0:
+        raise RuntimeError("vo_build_windows: inconsistent input (%d)" % rc)
+    out["status"] = rc
+    return out
 
 
 def pnp_motion_only(xyz, uv, T0, K=K_KITTI, iters=10, huber_delta=5.991, reproj_thr=4.0):

@@ -35,7 +35,7 @@ class Params(C.Structure):
                 ("struct_size", C.c_int32), ("abi_version", C.c_int32)]
 
 
-ABI_VERSION = 3  # VSLAM_ABI_VERSION of include/vslam_hip.h this binding was written against
+ABI_VERSION = 4  # VSLAM_ABI_VERSION of include/vslam_hip.h this binding was written against
 
 
 class LmStats(C.Structure):
@@ -54,7 +54,15 @@ class BaBatch(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("n_kf", C.c_int32), ("d_lm_off", C.c_void_p), ("d_edge_off", C.c_void_p),
                 ("d_T_c_w", C.c_void_p), ("d_xyz", C.c_void_p), ("d_reliable", C.c_void_p), ("d_lm_inlier", C.c_void_p),
                 ("d_kf_idx", C.c_void_p), ("d_lm_idx", C.c_void_p), ("d_uv", C.c_void_p), ("d_chi2", C.c_void_p),
-                ("d_stats", C.c_void_p), ("total_lm", C.c_int32), ("total_edge", C.c_int32), ("K4", C.c_void_p)]
+                ("d_stats", C.c_void_p), ("total_lm", C.c_int32), ("total_edge", C.c_int32), ("K4", C.c_void_p), ("d_n_kf", C.c_void_p)]
+
+
+class TracksIn(C.Structure):
+    """vslam_tracks_in: the front end's per-frame results (device pointers) that vslam_build_windows_dev turns into BA windows"""
+    _fields_ = [("n_frames", C.c_int32), ("kp_capacity", C.c_int32), ("lr_capacity", C.c_int32), ("match_capacity", C.c_int32),
+                ("pnp_capacity", C.c_int32), ("d_kps", C.c_void_p), ("d_lr", C.c_void_p), ("d_nlr", C.c_void_p), ("d_xyz", C.c_void_p),
+                ("d_valid", C.c_void_p), ("d_reliable", C.c_void_p), ("d_f2f", C.c_void_p), ("d_nf2f", C.c_void_p),
+                ("d_pose_inlier", C.c_void_p), ("d_T_rel", C.c_void_p)]
 
 
 # every symbol include/vslam_hip.h declares (checked by tests/test_abi.py)
@@ -67,7 +75,7 @@ ABI_SYMBOLS = [
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
     "vslam_profile_enable", "vslam_profile_read", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
-    "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant", "vslam_sgbm_status_dev", "vslam_set_tuning",
+    "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant", "vslam_sgbm_status_dev", "vslam_set_tuning", "vslam_build_windows_dev",
 ]
 
 
@@ -386,6 +394,12 @@ class VO:
     def ba_batch_dev(self, batch, schedule=1, mode=0, iters=10, update_poses=1, update_lms=0):
         self._chk(self.lib.vslam_ba_batch_dev(self.h, C.byref(batch), int(schedule), int(mode), int(iters), int(update_poses),
                                               int(update_lms)), "vslam_ba_batch_dev")
+
+    def build_windows_dev(self, tracks, n_kf, lm_capacity, edge_capacity, batch, d_status):
+        """optimize_map's graph build on the device (optimization.cpp:127-214 + visual_odometry.cpp:363-424) for a batch of consecutive
+        keyframes; fills the device arrays of `batch` (a BaBatch) and its scalar members"""
+        self._chk(self.lib.vslam_build_windows_dev(self.h, C.byref(tracks), int(n_kf), int(lm_capacity), int(edge_capacity), C.byref(batch),
+                                                   _p(d_status)), "vslam_build_windows_dev")
 
     def build_pnp_inputs_dev(self, d_f2f, d_nf2f, match_cap, d_lr, d_nlr, lr_cap, d_xyz_lr, d_valid_lr, d_kps_cur, kp_cap, B, d_kp2lr,
                              d_xyz_out, d_uv_out, d_nout, out_cap):

@@ -203,7 +203,8 @@ const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tes
            "match_train_nearest_kernel match_finalize_kernel sgbm_prefilter_kernel sgbm_down_kernel sgbm_forward_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel "
            "sgbm_wta_kernel sgbm_lrcheck_kernel sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel "
            "sgbm_ccl_apply_kernel sgbm_ccl_kernels triangulate_kernel find3d_disparity_kernel gather_uv_kernel build_pnp_inputs_kernel lm_window_kernel pose_only_wave_kernel "
-           "lm_window_kernel<pnp> pnp_wave_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel";
+           "lm_window_kernel<pnp> pnp_wave_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel "
+           "build_windows_kernels track_init_kernel track_pose_chain_kernel track_link_kernel track_chain_kernel window_count_kernel window_scan_kernel window_emit_kernel";
 }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
@@ -258,6 +259,7 @@ void vslam_destroy(vslam_ctx* ctx) {
     hipStreamSynchronize(c->stream);
     orb_tables_free(&c->tab);
     if (c->d_sgbm) hipFree(c->d_sgbm);
+    if (c->d_track) hipFree(c->d_track);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->lm.buf) hipFree(c->lm.buf);
     void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs, c->orb.d_order, c->orb.d_rad,
@@ -912,12 +914,35 @@ int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* b, int schedule, in
     VS_ENTER(c);
     LmWindowArgs a;
     memset(&a, 0, sizeof(a));
-    a.n_windows = b->n_windows; a.n_kf = b->n_kf; a.lm_off = b->d_lm_off; a.edge_off = b->d_edge_off; a.T = b->d_T_c_w; a.xyz = b->d_xyz;
+    a.n_windows = b->n_windows; a.n_kf = b->n_kf; a.n_kf_w = b->d_n_kf; a.lm_off = b->d_lm_off; a.edge_off = b->d_edge_off; a.T = b->d_T_c_w; a.xyz = b->d_xyz;
     a.reliable = b->d_reliable; a.lm_inlier = b->d_lm_inlier; a.kf_idx = b->d_kf_idx; a.lm_idx = b->d_lm_idx; a.uv = b->d_uv;
     a.chi2 = b->d_chi2; a.stats = b->d_stats; a.chi2_thr = nullptr;
     fill_K(c, a.K); a.huber_delta = c->p.huber_delta; a.total_lm = b->total_lm; a.total_edge = b->total_edge;
     if (b->K4) memcpy(a.K, b->K4, sizeof(a.K));
     return launch_lm_windows(a, schedule, mode, iters, update_poses, update_lms, &c->lm, c->stream);
+}
+
+int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf, int lm_capacity, int edge_capacity, vslam_ba_batch* out, int32_t* d_status) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !in || !out || !d_status || in->n_frames <= 0 || n_kf <= 0 || n_kf > VSLAM_MAX_KF || lm_capacity <= 0 || edge_capacity <= 0 ||
+        in->kp_capacity <= 0 || in->lr_capacity <= 0 || in->match_capacity <= 0 || in->pnp_capacity <= 0 || !in->d_kps || !in->d_lr || !in->d_nlr ||
+        !in->d_xyz || !in->d_valid || !in->d_reliable || (in->n_frames > 1 && (!in->d_f2f || !in->d_nf2f || !in->d_pose_inlier || !in->d_T_rel)) ||
+        !out->d_lm_off || !out->d_edge_off || !out->d_T_c_w || !out->d_xyz || !out->d_reliable || !out->d_lm_inlier || !out->d_kf_idx || !out->d_lm_idx ||
+        !out->d_uv || !out->d_n_kf) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    if ((long long)in->n_frames * in->kp_capacity > 0x7FFFFFFFll) { set_error("n_frames x kp_capacity exceeds the 31-bit node keys"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
+    const size_t need = track_scratch_bytes(in->n_frames, in->kp_capacity);
+    if (c->track_bytes < need) {
+        VS_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_track) { (void)hipFree(c->d_track); c->dev_bytes -= c->track_bytes; }
+        c->d_track = nullptr; c->track_bytes = 0;
+        if (hipMalloc((void**)&c->d_track, need) != hipSuccess) { c->d_track = nullptr; set_error("track scratch hipMalloc(%zu) failed", need); return VSLAM_ERR_HIP; }
+        c->track_bytes = need; c->dev_bytes += need;
+    }
+    out->n_windows = in->n_frames; out->n_kf = n_kf; out->total_lm = lm_capacity; out->total_edge = edge_capacity;
+    return launch_build_windows(*in, n_kf, lm_capacity, edge_capacity, c->d_track, const_cast<int32_t*>(out->d_lm_off), const_cast<int32_t*>(out->d_edge_off),
+                                const_cast<int32_t*>(out->d_n_kf), out->d_T_c_w, out->d_xyz, const_cast<uint8_t*>(out->d_reliable), out->d_lm_inlier,
+                                const_cast<int32_t*>(out->d_kf_idx), const_cast<int32_t*>(out->d_lm_idx), const_cast<float*>(out->d_uv), d_status, c->stream);
 }
 
 int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status) {

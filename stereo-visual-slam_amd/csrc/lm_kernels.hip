@@ -410,7 +410,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // tell the compiler it is wave-uniform: wave-indexed control flow goes scalar
     int prio_cnt = 0; (void)prio_cnt;
-    const int nk = a.n_kf, np = 6 * nk;
+    // keyframes of this window: a.n_kf slots (the pose stride), of which window w uses the first n_kf_w[w] (a growing map)
+    const int nk = (!IMPL && a.n_kf_w) ? min(max(a.n_kf_w[w], 1), a.n_kf) : a.n_kf, np = 6 * nk;
+    const size_t Tbase = (size_t)w * a.n_kf * 7;
     int lm0, nl, e0, ne;
     if (IMPL) { nl = min(max(ka.pnp_n[w], 0), ka.capacity); lm0 = w * ka.capacity; e0 = lm0; ne = nl; }
     else { lm0 = a.lm_off[w]; nl = a.lm_off[w + 1] - lm0; e0 = a.edge_off[w]; ne = a.edge_off[w + 1] - e0; }
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // ------------------------------------------------------------------ setup
     if (reuse_csr && ka.status[w] != VSLAM_OK) return; // a later launch of the schedule: the first one rejected this window's indices
     if (tid < 8) sm.flag[tid] = 0;
-    for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = a.T[(size_t)w * nk * 7 + i];
+    for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = a.T[Tbase + i];
     for (int i = tid; i < kLmWaves * kCntStride; i += kLmBlock) sm.cnt[i] = 0;
     if (tid < npairs) {
         int k1 = 0, rem = tid;
@@ -1451,7 +1453,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     }
     // ------------------------------------------------------------------ write-back (:272-287, :429-435)
     __syncthreads();
-    if (update_poses) for (int i = tid; i < nk * 7; i += kLmBlock) a.T[(size_t)w * nk * 7 + i] = sm.T[i];
+    if (update_poses) for (int i = tid; i < nk * 7; i += kLmBlock) a.T[Tbase + i] = sm.T[i];
     if (!IMPL && ka.want_chi2) // chi2 back to the caller's edge order (edges of excluded landmarks: 0)
         for (int e = tid; e < ne; e += kLmBlock) chi2[e] = act[lmi[e]] ? chi2k[kf_pos[e]] : 0.0;
     if (with_lm && update_lms)
@@ -1667,7 +1669,7 @@ __global__ __launch_bounds__(kPoBlock) void pose_only_wave_kernel(LmKernelArgs k
     long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + 16 * (size_t)w : nullptr; // tuning aid (VSLAM_LM_PROFILE=1): slots 0..6 of this pass
     long long t_ph = cyc ? clock64() : 0;
 #define POH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); cyc[i] += t1__ - t_ph; t_ph = t1__; } } while (0)
-    const int nk = a.n_kf;
+    const int nk = a.n_kf_w ? min(max(a.n_kf_w[w], 1), a.n_kf) : a.n_kf; // (a.n_kf: the pose stride)
     const int lm0 = a.lm_off[w], e0 = a.edge_off[w], ne = a.edge_off[w + 1] - e0;
     const int32_t* kfi = a.kf_idx + e0;
     const int32_t* lmi = a.lm_idx + e0;
@@ -1759,7 +1761,7 @@ __global__ __launch_bounds__(kPoBlock) void pose_only_wave_kernel(LmKernelArgs k
     {
         double T[7], Rt[12];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) T[i] = a.T[((size_t)w * nk + min(wave, nk - 1)) * 7 + i];
+        for (int i = 0; i < 7; ++i) T[i] = a.T[((size_t)w * a.n_kf + min(wave, nk - 1)) * 7 + i];
         expand_pose(T, Rt);
         if (lane == 0) {
 #pragma unroll
@@ -1955,7 +1957,7 @@ __global__ __launch_bounds__(kPoBlock) void pose_only_wave_kernel(LmKernelArgs k
         if (e == ne - 1 || lmi[e + 1] != lmi[e]) inl[lmi[e]] = !(chik[j] > th);
     }
     if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
-    if (update_poses && mine && lane < 7) a.T[((size_t)w * nk + wave) * 7 + lane] = sm.T[pc][wave][lane];
+    if (update_poses && mine && lane < 7) a.T[((size_t)w * a.n_kf + wave) * 7 + lane] = sm.T[pc][wave][lane];
     POH(8);
     (void)ntot;
 #undef POH

@@ -1,0 +1,326 @@
+// track_kernels.hip -- device-side graph construction for the BA half of a throughput-mode step.
+//
+// What it replaces: the landmark / observation bookkeeping of VO::insert_key_frame
+// (/root/reference/src/stereo_visual_slam_main/visual_odometry.cpp:363-424: a tracked feature adds an observation to the landmark of
+// the feature it was matched to, every other keypoint with a valid depth creates a landmark, a landmark whose depth was unreliable
+// takes the position of the first later observation with a reliable depth, :391-401) and the graph build of optimize_map /
+// optimize_pose_only (optimization.cpp:127-214, :303-361: poses = the keyframes of the window, landmarks with >= 1 observation, one
+// edge per observation) -- for a batch of B CONSECUTIVE keyframes whose front-end results are already in device memory.  Window b is the
+// map right after keyframe b was inserted: keyframes [max(0, b - n_kf + 1), b] (Map::num_keyframes_ = 10, map.hpp:22), every landmark
+// observed by one of them, positions and reliable_depth_ as of time b.  Poses: the pose stage's relative poses chained from frame 0.
+//
+// Throughput-mode simplifications (stated in DESIGN.md): every frame is a keyframe, windows are independent (is_inlier = 1 on entry:
+// the chi2 classification of window b - 1 does not feed window b), the sliding window replaces the distance-based culling of
+// Map::remove_keyframe (map.cpp:48-130).
+//
+// gfx950 mapping: the reference walks std::unordered_map<id, Landmark> with per-landmark observation vectors; here a track is a chain
+// of (frame, keypoint) nodes linked by two flat int32 tables pred / succ (B x kp_capacity) filled by one scatter pass per frame pair,
+// every keypoint slot of the batch is a thread, and a window is one workgroup that compacts the chain HEADS inside its frames in
+// (frame, keypoint) order with ballot ranks -- landmark-sorted, window-local edge lists come out directly, nothing is sorted.
+// All kernels are byte / index work on < 25 MB of tables per 256 frames: bound by launch latency, not by bandwidth.
+#include "vslam_internal.h"
+
+#include "se3_device.h"
+
+namespace vslam {
+
+struct TrackDims { int B, kp_cap, lr_cap, match_cap, pnp_cap, n_kf; };
+
+// ---- per frame: keypoint -> L/R match table; chain tables cleared
+__global__ __launch_bounds__(256) void track_init_kernel(TrackDims d, const vslam_dmatch* __restrict__ d_lr, const int32_t* __restrict__ d_nlr,
+                                                        int32_t* __restrict__ kp2lr, int32_t* __restrict__ pred, int32_t* __restrict__ succ) {
+    const int f = blockIdx.x, tid = threadIdx.x;
+    int32_t* k2 = kp2lr + (size_t)f * d.kp_cap;
+    for (int i = tid; i < d.kp_cap; i += 256) { k2[i] = -1; pred[(size_t)f * d.kp_cap + i] = -1; succ[(size_t)f * d.kp_cap + i] = -1; }
+    __syncthreads();
+    const int nlr = min(max(d_nlr[f], 0), d.lr_cap);
+    const vslam_dmatch* lr = d_lr + (size_t)f * d.lr_cap;
+    for (int m = tid; m < nlr; m += 256) {
+        const int q = lr[m].queryIdx;
+        if (q >= 0 && q < d.kp_cap) k2[q] = m;
+    }
+}
+
+// ---- global poses: G[0] = identity, G[f] = T_rel[f - 1] o G[f - 1]; inclusive scan of SE3 products (Hillis-Steele in LDS, chunks of 256
+// frames chained through a carry).  SE3 composition is associative; the scan's grouping differs from a sequential chain only in rounding.
+__global__ __launch_bounds__(256) void track_pose_chain_kernel(int B, const double* __restrict__ T_rel, double* __restrict__ G) {
+    __shared__ double buf[2][256][7];
+    __shared__ double carry[7];
+    const int tid = threadIdx.x;
+    if (tid == 0) { carry[0] = carry[1] = carry[2] = 0; carry[3] = 1; carry[4] = carry[5] = carry[6] = 0; }
+    for (int base = 0; base < B; base += 256) {
+        const int f = base + tid;
+        double X[7] = {0, 0, 0, 1, 0, 0, 0};
+        if (f > 0 && f < B)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) X[i] = T_rel[(size_t)(f - 1) * 7 + i];
+        int cur = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) buf[0][tid][i] = X[i];
+        __syncthreads();
+        for (int dd = 1; dd < 256; dd <<= 1) {
+            double Y[7];
+            if (tid >= dd) se3::mul(buf[cur][tid], buf[cur][tid - dd], Y); // later frames on the left
+            else
+#pragma unroll
+                for (int i = 0; i < 7; ++i) Y[i] = buf[cur][tid][i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) buf[cur ^ 1][tid][i] = Y[i];
+            cur ^= 1;
+            __syncthreads();
+        }
+        double Gf[7];
+        se3::mul(buf[cur][tid], carry, Gf);
+        if (f < B)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) G[(size_t)f * 7 + i] = Gf[i];
+        __syncthreads();
+        if (tid == 255)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) carry[i] = Gf[i];
+        __syncthreads();
+    }
+}
+
+// ---- per frame pair (i -> i + 1): the pose stage's inliers become chain links.  Input j of the pose stage is the j-th frame-to-frame
+// match whose query keypoint owns a valid depth (the compaction of build_pnp_inputs_kernel, geom_kernels.hip, repeated with the same
+// ballot ranks); a link needs its inlier flag (the reference erases the outliers of motion_estimation from the frame, :306).
+__global__ __launch_bounds__(256) void track_link_kernel(TrackDims d, const vslam_dmatch* __restrict__ d_f2f, const int32_t* __restrict__ d_nf2f,
+                                                        const uint8_t* __restrict__ d_valid, const uint8_t* __restrict__ d_inl,
+                                                        const int32_t* __restrict__ kp2lr, int32_t* __restrict__ pred, int32_t* __restrict__ succ) {
+    const int it = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_tot[4];
+    const int nm = min(max(d_nf2f[it], 0), d.match_cap);
+    const vslam_dmatch* m = d_f2f + (size_t)it * d.match_cap;
+    const int32_t* k2 = kp2lr + (size_t)it * d.kp_cap;
+    int written = 0;
+    for (int base = 0; base < nm; base += 256) {
+        const int k = base + tid;
+        bool ok = false; int q = -1, t = -1;
+        if (k < nm) {
+            q = m[k].queryIdx; t = m[k].trainIdx;
+            if (q >= 0 && q < d.kp_cap && t >= 0 && t < d.kp_cap) { const int li = k2[q]; ok = li >= 0 && d_valid[(size_t)it * d.lr_cap + li] != 0; }
+        }
+        const unsigned long long mask = __ballot(ok);
+        __syncthreads();
+        if (lane == 0) s_tot[wave] = __popcll(mask);
+        __syncthreads();
+        int off = written;
+        for (int w = 0; w < wave; ++w) off += s_tot[w];
+        const int j = off + __popcll(mask & ((1ull << lane) - 1ull));
+        if (ok && j < d.pnp_cap && d_inl[(size_t)it * d.pnp_cap + j] != 0) {
+            pred[(size_t)(it + 1) * d.kp_cap + t] = q;
+            succ[(size_t)it * d.kp_cap + q] = t;
+        }
+        written += s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    }
+}
+
+// ---- per keypoint slot: is it a node (a Feature of its keyframe: tracked, or owner of a valid depth), the root of its chain (where the
+// landmark was created) and the FIRST node of the chain, up to this one, with a reliable depth (-1: none yet): the landmark's position
+// at the time of this node is that node's point if there is one, the root's otherwise (visual_odometry.cpp:391-401).
+__global__ __launch_bounds__(256) void track_chain_kernel(TrackDims d, const uint8_t* __restrict__ d_valid, const uint8_t* __restrict__ d_rel,
+                                                         const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ pred,
+                                                         int32_t* __restrict__ root, int32_t* __restrict__ relsrc) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.kp_cap) return;
+    const size_t at = (size_t)f * d.kp_cap + i;
+    const int m = kp2lr[at], p = pred[at];
+    const bool own3d = m >= 0 && d_valid[(size_t)f * d.lr_cap + m] != 0;
+    int r = -1, first = -1;
+    if (own3d || p >= 0) {
+        int cf = f, ci = i;
+        for (;;) {
+            const size_t c = (size_t)cf * d.kp_cap + ci;
+            const int mm = kp2lr[c];
+            if (mm >= 0 && d_valid[(size_t)cf * d.lr_cap + mm] != 0 && d_rel[(size_t)cf * d.lr_cap + mm] != 0) first = cf * d.kp_cap + ci;
+            const int pp = pred[c];
+            if (pp < 0 || cf == 0) break;
+            --cf; ci = pp;
+        }
+        r = cf * d.kp_cap + ci;
+    }
+    root[at] = r; relsrc[at] = first;
+}
+
+// A chain HEAD of window [s, b]: a node in frame s, or a node without predecessor (a landmark created inside the window).  Every
+// landmark observed in the window has exactly one.  Returns the observations it has inside the window (0: not a head).
+__device__ inline int window_head_len(const TrackDims& d, const int32_t* __restrict__ root, const int32_t* __restrict__ pred,
+                                      const int32_t* __restrict__ succ, int s, int b, int f, int i) {
+    const size_t at = (size_t)f * d.kp_cap + i;
+    if (root[at] < 0 || (f != s && pred[at] >= 0)) return 0;
+    int len = 1, cf = f, ci = i;
+    while (cf < b) {
+        const int nx = succ[(size_t)cf * d.kp_cap + ci];
+        if (nx < 0) break;
+        ++cf; ci = nx; ++len;
+    }
+    return len;
+}
+
+__device__ inline int block_sum_i32(int v, int* red /* 4 */) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- per window: landmark and edge counts
+__global__ __launch_bounds__(256) void window_count_kernel(TrackDims d, const int32_t* __restrict__ root, const int32_t* __restrict__ pred,
+                                                          const int32_t* __restrict__ succ, int32_t* __restrict__ counts) {
+    const int b = blockIdx.x, tid = threadIdx.x, s = max(0, b - d.n_kf + 1);
+    __shared__ int red[4];
+    int nl = 0, ne = 0;
+    for (int f = s; f <= b; ++f)
+        for (int i = tid; i < d.kp_cap; i += 256) {
+            const int len = window_head_len(d, root, pred, succ, s, b, f, i);
+            nl += len > 0; ne += len;
+        }
+    nl = block_sum_i32(nl, red);
+    ne = block_sum_i32(ne, red);
+    if (tid == 0) { counts[2 * b] = nl; counts[2 * b + 1] = ne; }
+}
+
+// ---- offsets of the concatenated arrays (exclusive scan over the windows; one workgroup).  A window that would run past a capacity, and
+// every window after it, is emitted EMPTY and the status word is set: the caller sized its arrays too small.
+__global__ __launch_bounds__(256) void window_scan_kernel(TrackDims d, const int32_t* __restrict__ counts, int lm_capacity, int edge_capacity,
+                                                         int32_t* __restrict__ lm_off, int32_t* __restrict__ edge_off, int32_t* __restrict__ n_kf_out,
+                                                         int32_t* __restrict__ status) {
+    __shared__ int sl[256], se[256];
+    __shared__ int carry_l, carry_e, cut;
+    const int tid = threadIdx.x;
+    if (tid == 0) { carry_l = 0; carry_e = 0; cut = 0; lm_off[0] = 0; edge_off[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < d.B; base += 256) {
+        const int b = base + tid;
+        const int cl = b < d.B ? counts[2 * b] : 0, ce = b < d.B ? counts[2 * b + 1] : 0;
+        sl[tid] = cl; se[tid] = ce;
+        __syncthreads();
+        for (int dd = 1; dd < 256; dd <<= 1) {
+            const int a = tid >= dd ? sl[tid - dd] : 0, e = tid >= dd ? se[tid - dd] : 0;
+            __syncthreads();
+            sl[tid] += a; se[tid] += e;
+            __syncthreads();
+        }
+        const int il = carry_l + sl[tid], ie = carry_e + se[tid]; // inclusive
+        const bool over = il > lm_capacity || ie > edge_capacity;
+        if (b < d.B && over) atomicExch(&cut, 1);
+        __syncthreads();
+        if (b < d.B) {
+            // (prefixes are monotone: once a window overflows all later ones do; an overflowing window repeats the last good offset)
+            int ol = il, oe = ie;
+            if (over) { ol = -1; oe = -1; }
+            lm_off[b + 1] = ol; edge_off[b + 1] = oe;
+            n_kf_out[b] = min(b + 1, d.n_kf);
+        }
+        __syncthreads();
+        if (tid == 255) { carry_l = il; carry_e = ie; }
+        __syncthreads();
+    }
+    // second pass: replace the -1 marks by the last good offset (windows from the first overflow on are empty)
+    __syncthreads();
+    if (tid == 0) {
+        if (cut) {
+            int gl = 0, ge = 0;
+            for (int b = 0; b < d.B; ++b) {
+                if (lm_off[b + 1] < 0) { lm_off[b + 1] = gl; edge_off[b + 1] = ge; }
+                else { gl = lm_off[b + 1]; ge = edge_off[b + 1]; }
+            }
+        }
+        *status = cut ? 1 : 0;
+    }
+}
+
+// ---- per window: emit poses, landmarks (head order) and edges (landmark-major, chronological inside a landmark)
+__global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vslam_keypoint* __restrict__ d_kps, const float* __restrict__ d_xyz,
+                                                         const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ root,
+                                                         const int32_t* __restrict__ relsrc, const int32_t* __restrict__ pred,
+                                                         const int32_t* __restrict__ succ, const double* __restrict__ G,
+                                                         const int32_t* __restrict__ counts, const int32_t* __restrict__ lm_off,
+                                                         const int32_t* __restrict__ edge_off, double* __restrict__ T_out, float* __restrict__ xyz_out,
+                                                         uint8_t* __restrict__ rel_out, uint8_t* __restrict__ inl_out, int32_t* __restrict__ kf_out,
+                                                         int32_t* __restrict__ lm_out, float* __restrict__ uv_out) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = max(0, b - d.n_kf + 1), nk = b - s + 1;
+    __shared__ int s_l[4], s_e[4];
+    // poses of the window's keyframes (unused slots: identity)
+    for (int i = tid; i < d.n_kf * 7; i += 256) {
+        const int k = i / 7, c = i - 7 * k;
+        T_out[(size_t)b * d.n_kf * 7 + i] = k < nk ? G[(size_t)(s + k) * 7 + c] : (c == 3 ? 1.0 : 0.0);
+    }
+    const int l0 = lm_off[b], e0 = edge_off[b];
+    if (lm_off[b + 1] - l0 != counts[2 * b] || edge_off[b + 1] - e0 != counts[2 * b + 1]) return; // truncated by the capacity check: empty window
+    int run_l = 0, run_e = 0;
+    for (int f = s; f <= b; ++f)
+        for (int base = 0; base < d.kp_cap; base += 256) {
+            const int i = base + tid;
+            const int len = i < d.kp_cap ? window_head_len(d, root, pred, succ, s, b, f, i) : 0;
+            // ordered ranks: landmarks by ballot, edges by an in-wave inclusive scan of len
+            const unsigned long long mask = __ballot(len > 0);
+            int inc = len;
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+            __syncthreads();
+            if (lane == 63) { s_l[wave] = __popcll(mask); s_e[wave] = inc; }
+            __syncthreads();
+            int ol = run_l, oe = run_e;
+            for (int w = 0; w < wave; ++w) { ol += s_l[w]; oe += s_e[w]; }
+            if (len > 0) {
+                const int l = ol + __popcll(mask & ((1ull << lane) - 1ull));
+                int e = e0 + oe + inc - len;
+                int cf = f, ci = i;
+                for (int k = 0; k < len; ++k) {
+                    const vslam_keypoint* kp = d_kps + (size_t)cf * d.kp_cap + ci;
+                    kf_out[e] = cf - s; lm_out[e] = l;
+                    reinterpret_cast<float2*>(uv_out)[e] = make_float2(kp->x, kp->y);
+                    ++e;
+                    if (k + 1 < len) { ci = succ[(size_t)cf * d.kp_cap + ci]; ++cf; }
+                }
+                // position / reliable_depth_ as of the landmark's last observation inside the window
+                const size_t last = (size_t)cf * d.kp_cap + ci;
+                const int rs = relsrc[last];
+                const int src = rs >= 0 ? rs : root[last];
+                const int sf = src / d.kp_cap, si = src - sf * d.kp_cap;
+                const int mm = kp2lr[(size_t)sf * d.kp_cap + si];
+                const float* pc = d_xyz + 3 * ((size_t)sf * d.lr_cap + mm);
+                double Gi[7], pw[3];
+                const double p[3] = {(double)pc[0], (double)pc[1], (double)pc[2]};
+                se3::inverse(G + (size_t)sf * 7, Gi);
+                se3::act(Gi, p, pw);
+                float* o = xyz_out + 3 * (size_t)(l0 + l);
+                o[0] = (float)pw[0]; o[1] = (float)pw[1]; o[2] = (float)pw[2];
+                rel_out[l0 + l] = rs >= 0; inl_out[l0 + l] = 1;
+            }
+            run_l += s_l[0] + s_l[1] + s_l[2] + s_l[3];
+            run_e += s_e[0] + s_e[1] + s_e[2] + s_e[3];
+        }
+}
+
+size_t track_scratch_bytes(int B, int kp_cap) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return 5 * al((size_t)B * kp_cap * 4) + al((size_t)B * 7 * 8) + al((size_t)B * 2 * 4);
+}
+
+int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, uint8_t* scratch, int32_t* d_lm_off,
+                         int32_t* d_edge_off, int32_t* d_n_kf, double* d_T, float* d_xyz_out, uint8_t* d_rel_out, uint8_t* d_inl_out,
+                         int32_t* d_kf_out, int32_t* d_lm_out, float* d_uv_out, int32_t* d_status, hipStream_t stream) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    TrackDims d;
+    d.B = in.n_frames; d.kp_cap = in.kp_capacity; d.lr_cap = in.lr_capacity; d.match_cap = in.match_capacity; d.pnp_cap = in.pnp_capacity; d.n_kf = n_kf;
+    const size_t tab = al((size_t)d.B * d.kp_cap * 4);
+    int32_t* kp2lr = (int32_t*)scratch; int32_t* pred = (int32_t*)(scratch + tab); int32_t* succ = (int32_t*)(scratch + 2 * tab);
+    int32_t* root = (int32_t*)(scratch + 3 * tab); int32_t* relsrc = (int32_t*)(scratch + 4 * tab);
+    double* G = (double*)(scratch + 5 * tab); int32_t* counts = (int32_t*)(scratch + 5 * tab + al((size_t)d.B * 7 * 8));
+    ProfScope prof__(stream, "build_windows_kernels", 7);
+    hipLaunchKernelGGL(track_init_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_lr, in.d_nlr, kp2lr, pred, succ);
+    hipLaunchKernelGGL(track_pose_chain_kernel, dim3(1), dim3(256), 0, stream, d.B, in.d_T_rel, G);
+    if (d.B > 1) hipLaunchKernelGGL(track_link_kernel, dim3(d.B - 1), dim3(256), 0, stream, d, in.d_f2f, in.d_nf2f, in.d_valid, in.d_pose_inlier, kp2lr, pred, succ);
+    hipLaunchKernelGGL(track_chain_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, in.d_valid, in.d_reliable, kp2lr, pred, root, relsrc);
+    hipLaunchKernelGGL(window_count_kernel, dim3(d.B), dim3(256), 0, stream, d, root, pred, succ, counts);
+    hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(256), 0, stream, d, counts, lm_capacity, edge_capacity, d_lm_off, d_edge_off, d_n_kf, d_status);
+    hipLaunchKernelGGL(window_emit_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_kps, in.d_xyz, kp2lr, root, relsrc, pred, succ, G, counts, d_lm_off,
+                       d_edge_off, d_T, d_xyz_out, d_rel_out, d_inl_out, d_kf_out, d_lm_out, d_uv_out);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+} // namespace vslam

@@ -158,6 +158,7 @@ const char* hbm_copy_probe_name(int variant);
 // ----------------------------------------------------------------------------------------------- LM
 struct LmWindowArgs {
     int n_windows, n_kf;
+    const int32_t* n_kf_w;  // n_windows: keyframes of window w (<= n_kf, the pose stride), or null
     const int32_t* lm_off;
     const int32_t* edge_off;
     double* T;              // n_windows x n_kf x 7
@@ -228,6 +229,12 @@ int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[
 int launch_pnp_count_inliers(const float* d_xyz, const float* d_uv, int n, const double* d_Rt, const int32_t* d_ok, int hyp0, int n_hyp, const double K[4],
                              double reproj_thr, int32_t* d_counts, uint8_t* d_mask, hipStream_t stream);
 
+// track_kernels.hip: BA windows of a batch of consecutive keyframes from the front end's device-resident output
+size_t track_scratch_bytes(int B, int kp_cap);
+int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, uint8_t* scratch, int32_t* d_lm_off,
+                         int32_t* d_edge_off, int32_t* d_n_kf, double* d_T, float* d_xyz_out, uint8_t* d_rel_out, uint8_t* d_inl_out,
+                         int32_t* d_kf_out, int32_t* d_lm_out, float* d_uv_out, int32_t* d_status, hipStream_t stream);
+
 // ----------------------------------------------------------------------------------------------- context
 struct Ctx {
     vslam_params p;
@@ -244,6 +251,7 @@ struct Ctx {
     uint8_t* h_pinned; size_t pinned_bytes;
     // SGBM working set (cost volumes; grown on demand by vslam_disparity_map*)
     uint8_t* d_sgbm; size_t sgbm_bytes;
+    uint8_t* d_track; size_t track_bytes; // chain tables of vslam_build_windows_dev (grown on demand)
     LmScratch lm;
     Tuning tune;
     Prof* prof;           // stage profiler of this context (vslam_profile_enable); null until first enabled

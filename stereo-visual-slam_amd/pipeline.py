@@ -6,7 +6,10 @@ One step = the hot path BASELINE.json's metric names, over a batch of B stereo k
  -> gather matched pixels -> rectified-stereo DLT triangulation (+ depth gates of set_ref_3d_position)
  -> frame-to-frame match: keyframe b-1 (query) vs keyframe b (train)      (VO::feature_matching, :575)
  -> 3D(prev, triangulated) - 2D(cur) gather -> motion-only LM pose (10 its) (VO::motion_estimation substitute)
- -> local BA on B sliding windows (10 KF x ~3000 landmarks): schedule 5+5+10 LM + 10 pose-only (run_vslam.cpp:58-71)
+ -> BA windows built ON THE DEVICE from the step's own tracks (ba_windows="tracks": window b = keyframes [b-9, b] of the batch, the
+    landmarks / observations VO::insert_key_frame would have recorded, optimization.cpp:127-214) -- or B canned synthetic windows of the
+    BASELINE config-4 shape (ba_windows="synthetic": 10 KF x ~3000 landmarks)
+ -> local BA on the B windows: schedule 5+5+10 LM + 10 pose-only (run_vslam.cpp:58-71)
 torch is used only for device memory and the stream; every stage is a C-ABI call into libvslam_hip.so.
 """
 import ctypes as C
@@ -14,13 +17,14 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import BaBatch, DMATCH_DTYPE, KEYPOINT_DTYPE, VO, default_params
+from . import BaBatch, DMATCH_DTYPE, KEYPOINT_DTYPE, TracksIn, VO, default_params
 from . import synth
 
 
 class KeyframePipeline:
     def __init__(self, B, device=0, anms_num=1500, n_lm=3000, n_kf=10, unique_frames=64, unique_windows=None, seed=0, verbose=False,
-                 with_ba=True, depth="match", frame_range=None, render_workers=0, sequence=None):
+                 with_ba=True, depth="match", frame_range=None, render_workers=0, sequence=None, ba_windows="synthetic",
+                 lm_per_window=6144, edges_per_window=8192):
         """depth = "match": north_star stage (right-image ORB, L/R match, DLT); "sgbm": the reference's own depth path
         (VO::disparity_map + Frame::find_3d on the left keypoints; the right image is only consumed by SGBM).
         Inputs: ONE rendered sequence of `unique_frames` consecutive stereo keyframes, laid over the batch as a ping-pong
@@ -28,8 +32,9 @@ class KeyframePipeline:
         scene (driving the sequence backwards is as valid a frame-to-frame pair as driving it forwards); `unique_windows` BA
         windows (default: one per batch item).  frame_range = (first, last + 1, F): sequence mode -- the batch is the contiguous
         chunk [first, last] of an F-frame sequence (frame f shows ping-pong frame f of the SAME rendered scene on every rank)."""
-        assert depth in ("match", "sgbm")
+        assert depth in ("match", "sgbm") and ba_windows in ("synthetic", "tracks")
         self.depth = depth
+        self.ba_windows = ba_windows
         self.B = B
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -98,8 +103,39 @@ class KeyframePipeline:
         self.d_Tpnp = torch.from_numpy(ident.copy()).to(d)
         self.d_inl = torch.zeros((B, self.cap), dtype=torch.uint8, device=d)
         self.d_ninl = torch.zeros(B, dtype=torch.int32, device=d)
-        # ---- local-BA windows
-        if with_ba:
+        # ---- local-BA windows built on the device from this step's tracks (vslam_build_windows_dev)
+        if with_ba and ba_windows == "tracks":
+            self.n_kf = n_kf
+            self.lm_capacity, self.edge_capacity = B * lm_per_window, B * edges_per_window
+            self.ba_T = torch.zeros((B, n_kf, 7), dtype=torch.float64, device=d)
+            self.ba_xyz = torch.zeros((self.lm_capacity, 3), dtype=torch.float32, device=d)
+            self.ba_rel = torch.zeros(self.lm_capacity, dtype=torch.uint8, device=d)
+            self.ba_inl = torch.zeros(self.lm_capacity, dtype=torch.uint8, device=d)
+            self.ba_kf = torch.zeros(self.edge_capacity, dtype=torch.int32, device=d)
+            self.ba_lm = torch.zeros(self.edge_capacity, dtype=torch.int32, device=d)
+            self.ba_uv = torch.zeros((self.edge_capacity, 2), dtype=torch.float32, device=d)
+            self.ba_lm_off = torch.zeros(B + 1, dtype=torch.int32, device=d)
+            self.ba_e_off = torch.zeros(B + 1, dtype=torch.int32, device=d)
+            self.ba_nkf = torch.zeros(B, dtype=torch.int32, device=d)
+            self.ba_build_status = torch.zeros(1, dtype=torch.int32, device=d)
+            self.ba_chi2 = torch.zeros(1, dtype=torch.float64, device=d)
+            tr = TracksIn()
+            tr.n_frames = B; tr.kp_capacity = self.cap; tr.lr_capacity = self.cap; tr.match_capacity = self.cap; tr.pnp_capacity = self.cap
+            tr.d_kps = self.d_kps.data_ptr(); tr.d_lr = self.d_lr.data_ptr(); tr.d_nlr = self.d_nlr.data_ptr(); tr.d_xyz = self.d_xyz.data_ptr()
+            tr.d_valid = self.d_valid.data_ptr(); tr.d_reliable = self.d_rel.data_ptr(); tr.d_f2f = self.d_f2f.data_ptr()
+            tr.d_nf2f = self.d_nf2f.data_ptr(); tr.d_pose_inlier = self.d_inl.data_ptr(); tr.d_T_rel = self.d_Tpnp.data_ptr()
+            self.tracks = tr
+            bb = BaBatch()
+            bb.n_windows = B; bb.n_kf = n_kf
+            bb.d_lm_off = self.ba_lm_off.data_ptr(); bb.d_edge_off = self.ba_e_off.data_ptr(); bb.d_T_c_w = self.ba_T.data_ptr()
+            bb.d_xyz = self.ba_xyz.data_ptr(); bb.d_reliable = self.ba_rel.data_ptr(); bb.d_lm_inlier = self.ba_inl.data_ptr()
+            bb.d_kf_idx = self.ba_kf.data_ptr(); bb.d_lm_idx = self.ba_lm.data_ptr(); bb.d_uv = self.ba_uv.data_ptr()
+            bb.d_chi2 = None; bb.d_stats = None; bb.K4 = None; bb.d_n_kf = self.ba_nkf.data_ptr()
+            bb.total_lm = self.lm_capacity; bb.total_edge = self.edge_capacity
+            self.ba_batch = bb
+            self.unique_windows = B
+        # ---- canned local-BA windows
+        if with_ba and ba_windows == "synthetic":
             unique_windows = B if unique_windows is None else max(1, min(unique_windows, B))
             self.unique_windows = unique_windows
             self.window_seed0 = seed + 100
@@ -179,8 +215,16 @@ class KeyframePipeline:
         vo.motion_estimation_dev(self.d_pxyz.data_ptr(), self.d_puv.data_ptr(), self.d_pn.data_ptr(), cap, n, self.d_Tpnp.data_ptr(), 10,
                                  self.d_inl.data_ptr(), self.d_ninl.data_ptr())
 
+    def stage_build_windows(self):
+        """optimize_map's graph build (optimization.cpp:127-214) + insert_key_frame's bookkeeping (visual_odometry.cpp:363-424) on the device"""
+        self.vo.build_windows_dev(self.tracks, self.n_kf, self.lm_capacity, self.edge_capacity, self.ba_batch, self.ba_build_status.data_ptr())
+
     def stage_ba(self):
         if not self.with_ba:
+            return
+        if self.ba_windows == "tracks":
+            self.stage_build_windows()
+            self.vo.ba_batch_dev(self.ba_batch, schedule=1)
             return
         with torch.cuda.stream(self.stream):
             self.ba_T.copy_(self.ba_T0)
@@ -208,6 +252,10 @@ class KeyframePipeline:
         out["pxyz"] = self.d_pxyz.cpu().numpy(); out["puv"] = self.d_puv.cpu().numpy(); out["inl"] = self.d_inl.cpu().numpy()
         if self.with_ba:
             out["ba_T"] = self.ba_T.cpu().numpy(); out["ba_inl"] = self.ba_inl.cpu().numpy(); out["ba_chi2"] = self.ba_chi2.cpu().numpy()
+        if self.with_ba and self.ba_windows == "tracks":
+            for k, t in (("ba_lm_off", self.ba_lm_off), ("ba_e_off", self.ba_e_off), ("ba_nkf", self.ba_nkf), ("ba_xyz", self.ba_xyz), ("ba_rel", self.ba_rel),
+                         ("ba_kf", self.ba_kf), ("ba_lm", self.ba_lm), ("ba_uv", self.ba_uv), ("ba_build_status", self.ba_build_status)):
+                out[k] = t.cpu().numpy()
         return out
 
     def close(self):
