@@ -45,12 +45,43 @@ def algorithmic_bytes(kernel, pipe, anms_num):
     if kernel.startswith("lm_window_kernel<pnp>") or kernel.startswith("pnp_wave_kernel"):
         return (B - 1) * 10 * 20 * 500, "(B-1) x 10 its x 20 B/point x ~500 points"
     if kernel.startswith("lm_window_kernel"):
+        if getattr(pipe, "ba_shape", None) is not None:  # windows built from the step's tracks: their actual sizes
+            E, L, K = (np.asarray(x, np.float64) for x in pipe.ba_shape)
+            per_it = E * 16 + L * 12 + K * 56 + (6 * K) ** 2 * 8 + 6 * K * 8 + L * 12
+            return float(per_it.sum()) * 30, "sum over the B built windows of 30 LM linearisations x (E*16 + L*12 + K*56 + (6K)^2*8 + 6K*8 + L*12) B"
         E, L, K = pipe.edges_per_window, pipe.lms_per_window, pipe.n_kf
         per_it = E * 16 + L * 12 + K * 56 + (6 * K) ** 2 * 8 + 6 * K * 8 + L * 12
         return B * per_it * 30, "B windows x 30 LM linearisations x (E*16 + L*12 + K*56 + (6K)^2*8 + 6K*8 + L*12) B"
     if kernel.startswith("triangulate"):
         return B * anms_num * 30, "B x N x 30 B"
     return 0, "n/a"
+
+
+def _sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+def load_counter_json(name):
+    """a counter summary under profiles/ that was measured offline (rocprofv3 PMC passes).  It names the kernel sources it was measured on
+    (`source_sha16`: {file under csrc/: first 16 hex digits of its sha256}); if any of them has changed since, the numbers describe another
+    kernel and are NOT reported (returns (None, reason))."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        tj = json.load(open(path))
+    except Exception as e:
+        return None, "profiles/%s unreadable (%r)" % (name, e)
+    shas = tj.get("source_sha16")
+    if not shas:
+        return None, "profiles/%s carries no source_sha16 (measured before the kernels were hashed): not reported" % name
+    for f, h in shas.items():
+        cur = _sha16(os.path.join(ROOT, "stereo-visual-slam_amd", "csrc", f))
+        if cur != h:
+            return None, "profiles/%s is stale: %s changed since it was measured (%s -> %s); re-run tools/profile_round.sh" % (name, f, h, cur)
+    return tj, tj.get("source")
 
 
 def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
@@ -74,6 +105,20 @@ def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
         out.append({"kernel": "orb_* (family)", "bound": "hbm", "ms_per_step": round(orb_total_ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(orb_alg),
                     "frac_of_copy_ceiling": round(gbs / copy_gbs, 5) if copy_gbs > 0 else None})
+    # ORB is bound by VALU issue, not by bytes: the right ruler is wave-instructions per second.  SQ_INSTS_VALU per image
+    # from the counter pass (profiles/orb_valu.json, tools/profile_sq.sh); a wave64 integer / packed-16 instruction holds its SIMD ~4 cycles.
+    oj, _ = load_counter_json("orb_valu.json")
+    if oj:
+        n_img = pipe.B if pipe.depth == "sgbm" else 2 * pipe.B
+        for name, per_img in oj.get("valu_wave_insts_per_image", {}).items():
+            k = prof.get(name)
+            if not k or k[0] <= 0 or oj.get("anms") != args.anms:
+                continue
+            t = k[0] / 1e3 / n_steps
+            rate = per_img * n_img / t
+            peak = 256 * 4 * 2.4e9 / 4.0
+            out.append({"kernel": name, "bound": "valu-issue", "achieved": round(rate / 1e12, 4), "peak": round(peak / 1e12, 4), "unit": "T wave-instructions/s",
+                        "frac": round(rate / peak, 4), "note": "SQ_INSTS_VALU per image (%s) x images per step over this kernel's time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles" % oj.get("source")})
     k = prof.get("match_train_nearest_kernel")
     if k and k[0] > 0:
         n = float(args.anms)
@@ -85,12 +130,10 @@ def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
     # what actually bounds the dominant kernel: VALU issue.  Wave-instructions per window and schedule come from the SQ counter
     # pass (tools/profile_sq.sh -> profiles/traffic.json); every VALU op, f64 or not, takes a 4-cycle issue slot of its SIMD.
     k = prof.get("lm_window_kernel")
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        wi = float(tj.get("valu_wave_insts_per_window_schedule", 0))
-    except Exception:
-        wi = 0.0
-    if k and k[0] > 0 and wi > 0 and pipe.lms_per_window == 3000 and pipe.n_kf == 10:
+    tj, _ = load_counter_json("traffic.json")
+    wi = float(tj.get("valu_wave_insts_per_window_schedule", 0)) if tj else 0.0
+    config4 = getattr(pipe, "lms_per_window", None) == 3000 and pipe.n_kf == 10 and pipe.ba_windows == "synthetic"
+    if k and k[0] > 0 and wi > 0 and config4:
         sets = k[2] if len(k) > 2 and k[2] else n_steps
         t = k[0] / 1e3 / sets                                   # seconds per schedule batch
         slots = 256 * 4 * 2.4e9 * t / 4.0                       # 256 CUs x 4 SIMDs, one VALU issue per 4 cycles at 2.4 GHz
@@ -101,11 +144,8 @@ def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
     # ... and in FP64 vector terms (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of the BA schedule, tools/profile_f64.sh): the f64 pipe is the
     # unit the two big phases of the kernel saturate at two waves per SIMD (tools/scratch/valu_rate.hip: a wave64 f64 op holds its SIMD
     # ~4 cycles, an f32 / integer op ~2)
-    try:
-        fj = json.load(open(os.path.join(ROOT, "profiles", "r02_ba_valu_f64.json")))["per_window_schedule"]
-    except Exception:
-        fj = None
-    if k and k[0] > 0 and fj and pipe.lms_per_window == 3000 and pipe.n_kf == 10:
+    fj = tj.get("f64_per_window_schedule") if tj else None
+    if k and k[0] > 0 and fj and config4:
         sets = k[2] if len(k) > 2 and k[2] else n_steps
         t = k[0] / 1e3 / sets
         tflops = fj["f64_flop"] * pipe.B / t / 1e12
@@ -206,6 +246,135 @@ def cpu_baseline(pipe, out, anms_num, n_single=24, per_core=2, chunk_len=8):
     else:
         res.update(value=n1 / dt1, cores=1)
     return res, parity
+
+
+def cpu_baseline_tracks(pipe, out, anms_num, n_single=24, per_core=2):
+    """tracks mode (the default step): the CPU oracle on the SAME pipeline -- front end per frame, frame-to-frame stage per pair, the map
+    bookkeeping of oracle/windows.c, the BA schedule on every built window -- one thread in-process on the first n_single keyframes of the
+    batch (window b only depends on frames <= b, so these are exactly the GPU's first windows: parity is checked on the way), then all
+    cores with the stages as parallel maps over a process pool (no halo recomputation: a stage's results travel through the parent)."""
+    import multiprocessing as mp
+    import tempfile
+    import oracle as O
+    from oracle import cpu_keyframe as W
+    B, U, cap, n_kf = pipe.B, pipe.unique_frames, pipe.cap, pipe.n_kf
+    tmp = tempfile.NamedTemporaryFile(suffix=".npy", dir="/dev/shm" if os.path.isdir("/dev/shm") else None, delete=False)
+    tmp.close()
+    np.save(tmp.name, np.concatenate([pipe.h_imgs_unique_left, pipe.h_imgs_unique_right]))
+    init_args = (tmp.name, pipe.w, anms_num, n_kf, 0, 0)
+    try:
+        W.init(*init_args)
+        n1 = min(n_single, B)
+        stage_s = {"orb_lr_match_triangulate": 0.0, "f2f_match_motion_only_lm": 0.0, "build_windows": 0.0, "local_ba_schedule": 0.0}
+        t0 = time.perf_counter()
+        fronts, tracks, int_mismatch, pnp_o, pnp_g = [], [], 0, [], []
+        for b in range(n1):
+            ts = time.perf_counter()
+            fronts.append(W.front_end_full(pipe.frame_of[b]))
+            stage_s["orb_lr_match_triangulate"] += time.perf_counter() - ts
+            cur = fronts[-1]
+            int_mismatch += int(out["cnt"][b] != len(cur[0])) + int(out["cnt"][B + b] != cur[5]) + int(out["nlr"][b] != len(cur[2]))
+            if b > 0:
+                ts = time.perf_counter()
+                tracks.append(W.track_full(fronts[b - 1], cur))
+                stage_s["f2f_match_motion_only_lm"] += time.perf_counter() - ts
+                T, f, il = tracks[-1]
+                int_mismatch += int(out["nf2f"][b - 1] != len(f)) + int(out["pn"][b - 1] != len(il)) + int(out["ninl"][b - 1] != int(il.sum()))
+                if len(il) >= 6:
+                    pnp_o.append(T); pnp_g.append(out["Tpnp"][b - 1])
+        ts = time.perf_counter()
+        w = O.build_windows(*W.pack_tracks(fronts, tracks, cap), n_kf=n_kf)
+        stage_s["build_windows"] += time.perf_counter() - ts
+        int_mismatch += int((w["lm_off"][:n1 + 1] != out["ba_lm_off"][:n1 + 1]).sum()) + int((w["edge_off"][:n1 + 1] != out["ba_e_off"][:n1 + 1]).sum())
+        ba_o, ba_g = [], []
+        for b in range(n1):
+            ts = time.perf_counter()
+            Tb, inl = W.ba_schedule_built(W.window_slice(w, b))
+            stage_s["local_ba_schedule"] += time.perf_counter() - ts
+            nk = int(w["n_kf"][b])
+            ba_o.append(Tb); ba_g.append(out["ba_T"][b][:nk])
+            lo, hi = int(out["ba_lm_off"][b]), int(out["ba_lm_off"][b + 1])
+            int_mismatch += int((out["ba_inl"][lo:hi] != inl).sum()) if hi - lo == len(inl) else len(inl)
+        dt1 = time.perf_counter() - t0
+        pt, pq, pr = _pose_diff(np.array(pnp_g), np.array(pnp_o)) if pnp_o else (None, None, None)
+        bt, bq, br = _pose_diff(np.concatenate(ba_g), np.concatenate(ba_o))
+        parity = dict(keyframes_checked=n1, integer_mismatches=int_mismatch, pnp_translation_rmse_m=pt, pnp_quaternion_rmse=pq, pnp_max_rel_diff=pr,
+                      ba_translation_rmse_m=bt, ba_quaternion_rmse=bq, ba_max_rel_diff=br,
+                      note="GPU step vs oracle on the same inputs: counts of keypoints / LR / f2f matches / pose inputs / pose inliers, the landmark and "
+                           "edge offsets of the built windows and the BA landmark flags must be identical (integer_mismatches = 0); poses: motion-only LM "
+                           "of keyframe b-1 -> b, and every window's poses after the 5+5+10+10 schedule")
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        all_cores = None
+        if cores > 1:
+            n_all = int(min(max(per_core * cores, 64), 1024))
+            period = max(2 * (U - 1), 1)
+            frames = [(t if t < U else period - t) for t in (b % period for b in range(n_all))]
+            ctx = mp.get_context("spawn")
+            nproc = min(cores, n_all)
+            with ctx.Pool(nproc, initializer=W.init, initargs=init_args) as pool:
+                pool.map(W.warm, range(4 * nproc), chunksize=1)
+                t0 = time.perf_counter()
+                fr = pool.map(W.front_end_full, frames, chunksize=1)
+                tr = pool.map(W.track_pair, [(fr[i], fr[i + 1]) for i in range(n_all - 1)], chunksize=1)
+                wa = O.build_windows(*W.pack_tracks(fr, tr, cap), n_kf=n_kf)
+                pool.map(W.ba_schedule_built, [W.window_slice(wa, b) for b in range(n_all)], chunksize=1)
+                dta = time.perf_counter() - t0
+            all_cores = dict(value=n_all / dta, cores=nproc, keyframes=n_all, seconds=round(dta, 2))
+    finally:
+        os.unlink(tmp.name)
+    res = dict(unit="keyframes/s", kind="port",
+               single_thread=dict(value=n1 / dt1, cores=1, keyframes=n1, seconds=round(dt1, 2),
+                                  stage_ms_per_keyframe={k: round(1e3 * v / n1, 2) for k, v in stage_s.items()}),
+               sample=("oracle/libvo_oracle.so on the same pipeline as the GPU step: per stereo keyframe 2 ORB images (3000 -> ANMS %d -> rBRIEF), L/R + "
+                       "frame-to-frame match, DLT, motion-only LM; the map bookkeeping (oracle/windows.c) and the BA schedule 5+5+10+10 on the window built "
+                       "for every keyframe (up to %d keyframes); single thread: %d keyframes in %.1f s" % (anms_num, n_kf, n1, dt1)))
+    if all_cores:
+        res.update(value=all_cores["value"], cores=all_cores["cores"])
+        res["sample"] += "; all cores: %d keyframes in %.1f s, the stages as parallel maps over %d worker processes; host has %d cores" % (
+            all_cores["keyframes"], all_cores["seconds"], all_cores["cores"], os.cpu_count())
+    else:
+        res.update(value=n1 / dt1, cores=1)
+    return res, parity
+
+
+def ba_config4_measure(args, local, torch):
+    """the BA schedule alone on B canned windows of the BASELINE config-4 shape (10 keyframes x 3000 landmarks, ~10 k edges: SURVEY 8d) -- the
+    shape lm_window_kernel's roofline figures have been quoted on since round 1; the default step's windows come from real tracks and are smaller"""
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    B = args.batch
+    pipe = KeyframePipeline(B, device=local, anms_num=500, n_lm=3000, unique_frames=2, seed=0, ba_windows="synthetic")
+    try:
+        for _ in range(2):
+            pipe.stage_ba()
+        torch.cuda.synchronize(pipe.dev)
+        pipe.vo.profile_enable(True); pipe.vo.profile_read()
+        n = max(args.steps, 3)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            pipe.stage_ba()
+        torch.cuda.synchronize(pipe.dev)
+        wall = (time.perf_counter() - t0) / n
+        prof = pipe.vo.profile_read(); pipe.vo.profile_enable(False)
+        if int((pipe.vo.ba_status(B) != 0).sum()):
+            return {"error": "windows rejected"}
+        ms = prof["lm_window_kernel"][0] / n
+        alg, formula = algorithmic_bytes("lm_window_kernel", pipe, 500)
+        achieved = alg / (ms / 1e3) / 1e9
+        tj, src = load_counter_json("traffic.json")
+        traffic = int(tj["hbm_bytes_per_launch_set"]) if tj and tj.get("batch") == B and tj.get("kernel") == "lm_window_kernel" else None
+        res = {"workload": "BA schedule (5+5+10 LM + 10 pose-only) on %d unique synthetic windows, 10 KF x 3000 landmarks x %.0f edges" % (B, pipe.edges_per_window),
+               "ms_per_schedule_batch": round(ms, 4), "wall_ms_per_schedule_batch": round(1e3 * wall, 4), "windows_per_s": round(B / (ms / 1e3), 1),
+               "roofline": {"bound": "hbm", "kernel": "lm_window_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": src,
+                            "algorithmic_bytes_per_launch_set": int(alg), "formula": formula},
+               "other_rooflines": [r for r in other_rooflines(prof, pipe, args, n, 0.0) if r["kernel"] == "lm_window_kernel"]}
+        return res
+    finally:
+        pipe.close()
 
 
 def host_input_region(pipe, args, timed_region, one_step, torch):
@@ -329,6 +498,10 @@ def main():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--depth", choices=["match", "sgbm"], default="match",
                     help="stereo depth stage: north_star L/R match + DLT (default, BASELINE metric) or the reference's SGBM + find_3d")
+    ap.add_argument("--ba-windows", choices=["tracks", "synthetic"], default="tracks",
+                    help="tracks (default): the BA windows are built on the device from the step's own matches and poses (one pipeline: window b = "
+                         "keyframes [b-9, b] of the batch); synthetic: B canned windows of the BASELINE config-4 shape (10 KF x --landmarks)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the extra BA-only measurement on the config-4 shape")
     ap.add_argument("--sequence", type=int, default=0, metavar="F",
                     help="BASELINE config 5: one F-frame sequence split into contiguous chunks with a 1-frame halo across the ranks, relative poses "
                          "gathered over RCCL and chained on rank 0 (stereo-visual-slam_amd/sharding.py); 0 = independent batches per rank")
@@ -377,6 +550,7 @@ def main():
     from stereo_visual_slam_amd import sharding
     B = args.batch
     seq_mode = args.sequence > 0
+    ba_windows = "synthetic" if seq_mode else args.ba_windows  # (sequence mode: a chunk has a 1-frame halo, not the 9 frames a full first window needs)
     if seq_mode:  # config 5: this rank's contiguous chunk of ONE sequence, plus the frame before it (halo)
         assert args.sequence >= 2 * world, "--sequence needs at least two frames per rank"
         lo, hi = sharding.shard_range(args.sequence, rank, world)
@@ -384,10 +558,11 @@ def main():
         B = hi - h_lo
         pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=0, verbose=args.verbose and rank == 0,
                                 with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence),
-                                render_workers=render_workers)
+                                render_workers=render_workers, ba_windows=ba_windows)
     else:
         pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
-                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, render_workers=render_workers)
+                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, render_workers=render_workers,
+                                ba_windows=ba_windows)
     dev = pipe.dev
     chained = [None]
 
@@ -446,11 +621,22 @@ def main():
     n_img = pipe.B if args.depth == "sgbm" else 2 * pipe.B
     orb_bad = int((pipe.vo.orb_status(n_img) != 0).sum())
     ba_bad = int((pipe.vo.ba_status(pipe.B) != 0).sum()) if pipe.with_ba else 0
-    if orb_bad or ba_bad:
-        raise SystemExit("bench invalid: %d images overflowed an ORB capacity, %d BA windows were rejected" % (orb_bad, ba_bad))
+    build_bad = int(pipe.ba_build_status.item()) if (pipe.with_ba and pipe.ba_windows == "tracks") else 0
+    if orb_bad or ba_bad or build_bad:
+        raise SystemExit("bench invalid: %d images overflowed an ORB capacity, %d BA windows were rejected, window builder status %d" % (orb_bad, ba_bad, build_bad))
 
     if rank == 0:
         out = pipe.download()
+        pipe.ba_shape = None
+        win_stats = None
+        if pipe.with_ba and pipe.ba_windows == "tracks":
+            nl_w, ne_w = np.diff(out["ba_lm_off"]), np.diff(out["ba_e_off"])
+            pipe.ba_shape = (ne_w, nl_w, out["ba_nkf"])
+            n_l = int(out["ba_lm_off"][-1])
+            win_stats = {"landmarks_per_window_mean": float(nl_w.mean()), "landmarks_per_window_max": int(nl_w.max()), "edges_per_window_mean": float(ne_w.mean()),
+                         "edges_per_window_max": int(ne_w.max()), "reliable_fraction": float(out["ba_rel"][:n_l].mean()) if n_l else 0.0,
+                         "keyframes_per_window": "1..%d for the first %d windows (the growing map), then %d" % (pipe.n_kf, pipe.n_kf - 1, pipe.n_kf),
+                         "full_windows": int((out["ba_nkf"] == pipe.n_kf).sum()), "builder_status": build_bad}
         units = args.sequence if seq_mode else world * B   # keyframes all ranks processed per step (halo frames are not counted twice)
         value = units * args.steps / elapsed
         kern = sorted(prof.items(), key=lambda kv: -kv[1][0])
@@ -467,15 +653,17 @@ def main():
             formula = "B pairs x ((w-96)*h*96*2 B cost volume once + 2*w*h B images in + 4*w*h B f32 disparity out)"
         per_bracket_s = dom_ms / 1e3 / max(dom_calls, 1)
         achieved = alg / per_bracket_s / 1e9 if per_bracket_s > 0 else 0.0
-        traffic, traffic_src = None, None
-        try:  # measured offline with rocprofv3 PMC passes (tools/profile_round.sh); only valid for the same kernel and batch
-            sg = args.depth == "sgbm" and dom.startswith("sgbm_*")
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_sgbm.json" if sg else "traffic.json")))
+        # `traffic`: HBM bytes per launch set from rocprofv3 PMC passes made offline (tools/profile_round.sh).  Valid only for the same kernel
+        # SOURCES (sha256 recorded in the file), the same kernel, batch and window kind; otherwise null with the reason in traffic_source.
+        sg = args.depth == "sgbm" and dom.startswith("sgbm_*")
+        tname = "traffic_sgbm.json" if sg else ("traffic_tracks.json" if (pipe.with_ba and pipe.ba_windows == "tracks") else "traffic.json")
+        traffic = None
+        tj, traffic_src = load_counter_json(tname)
+        if tj is not None:
             if (sg and tj.get("batch") == B) or (tj.get("kernel") == dom and tj.get("batch") == B):
                 traffic = int(tj["hbm_bytes_per_launch_set"])
-            traffic_src = tj.get("source")
-        except Exception:
-            traffic = None
+            else:
+                traffic_src = "profiles/%s was measured for kernel %s at batch %s, not %s at %d" % (tname, tj.get("kernel"), tj.get("batch"), dom, B)
         nt = max(B - 1, 1)
         res = {
             "metric": "stereo keyframes/sec (ORB+match+tri+local-BA), KITTI-00 1241x376",
@@ -486,12 +674,17 @@ def main():
             "dtype": "u8+f64", "data": "synthetic",
             "config": {"workload": ("stereo keyframe hot path, north_star stages (NOT the reference's SGBM depth / solvePnPRansac pose, which are built "
                                     "and selectable: --depth sgbm, host driver): ORB(3000)->ANMS(%d)->rBRIEF on L+R 1241x376, L/R + frame-to-frame "
-                                    "BF-Hamming cross-check match, epipolar-gated DLT triangulation, motion-only LM pose (10 its), local BA 10 KF x %d "
-                                    "landmarks (5+5+10 LM + 10 pose-only)%s" % (args.anms, args.landmarks, "" if not args.no_ba else " [BA disabled]"))
+                                    "BF-Hamming cross-check match, epipolar-gated DLT triangulation, motion-only LM pose (10 its), %s, local BA "
+                                    "schedule 5+5+10 LM + 10 pose-only per window%s" % (args.anms,
+                                    ("BA windows built on the device from this step's own tracks (window b = keyframes [b-9, b]: poses = chained pose-stage estimates, "
+                                     "landmarks / observations as VO::insert_key_frame records them)" if pipe.ba_windows == "tracks" else
+                                     "%d canned synthetic windows of 10 KF x %d landmarks (config-4 shape; NOT fed by the front end of the step)" % (pipe.unique_windows, args.landmarks)),
+                                    "" if not args.no_ba else " [BA disabled]"))
                                    + (" [depth stage swapped for the reference's own: SGBM disparity + find_3d; not the BASELINE metric]" if args.depth == "sgbm" else ""),
                        "batch_keyframes_per_gpu": B, "image": "1241x376 u8",
-                       "unique_inputs": "%d rendered stereo keyframes of one sequence (ping-pong over the batch), %d unique BA windows" % (
-                           pipe.unique_frames, pipe.unique_windows if pipe.with_ba else 0),
+                       "ba_windows": pipe.ba_windows if pipe.with_ba else None,
+                       "unique_inputs": "%d rendered stereo keyframes of one sequence (ping-pong over the batch), %d BA windows (%s)" % (
+                           pipe.unique_frames, pipe.unique_windows if pipe.with_ba else 0, "built from the step's tracks" if pipe.ba_windows == "tracks" else "canned"),
                        "parallelism": ("one %d-frame sequence in %d contiguous chunks with a 1-frame halo, relative poses gathered and chained on rank 0" % (args.sequence, world))
                                       if seq_mode else "%d independent replicas, sharded keyframes" % world},
             "timing": {"repeats": len(rep_s), "ms_per_step_each": [round(1e3 * x / args.steps, 4) for x in rep_s], "reported": "median",
@@ -512,12 +705,21 @@ def main():
                       "pnp_inliers": float(out["ninl"][:nt].mean()), "pnp_inliers_min": int(out["ninl"][:nt].min()),
                       "orb_status_nonzero": orb_bad, "ba_status_nonzero": ba_bad},
         }
+        if win_stats is not None:
+            res["stats"]["ba_windows"] = win_stats
         if host_inputs is not None:
             res["inputs_from_host"] = host_inputs
         if seq_mode and chained[0] is not None:
             res["trajectory"] = {"frames": int(len(chained[0])), "final_position": [float(x) for x in sharding.camera_centre(chained[0][-1])]}
-        if world == 1 and not args.no_cpu_baseline and not args.no_ba and args.depth == "match" and not seq_mode:
-            res["cpu_baseline"], res["pose_rmse_vs_oracle"] = cpu_baseline(pipe, out, args.anms)
+        extras_ok = world == 1 and not args.no_ba and args.depth == "match" and not seq_mode
+        if extras_ok and not args.no_config4 and pipe.ba_windows == "tracks":
+            pipe.close()    # (host arrays stay; the GPU memory goes back before the second pipeline is built)
+            try:
+                res["ba_config4"] = ba_config4_measure(args, local, torch)
+            except Exception as e:  # an extra must never cost the headline
+                res["ba_config4"] = {"error": repr(e)}
+        if extras_ok and not args.no_cpu_baseline:
+            res["cpu_baseline"], res["pose_rmse_vs_oracle"] = (cpu_baseline_tracks if pipe.ba_windows == "tracks" else cpu_baseline)(pipe, out, args.anms)
             info, have_cv2 = host_info()
             res["cpu_baseline"]["host"] = info
             if have_cv2:
@@ -528,7 +730,8 @@ def main():
             else:
                 res["cpu_baseline"]["reference_libs_timing"] = "unavailable on this host (no cv2 / OpenCV / g2o found at run time)"
         print(json.dumps(res), flush=True)
-    pipe.close()
+    if pipe.vo.h:
+        pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
