@@ -274,8 +274,8 @@ int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* batch, int schedule
  * frame f - 1, :592-599) plus every other keypoint with a valid depth (it creates a landmark, :403-421); a landmark with an
  * unreliable depth takes the point of its first later observation with a reliable one (:391-401).  Window b = the map right after
  * keyframe b: keyframes [max(0, b - n_kf + 1), b], every landmark they observe (position and reliable flag as of frame b, world
- * = frame 0 through the chained relative poses), one edge per observation, edges landmark-major (landmarks ordered by their first
- * observation inside the window: frame, then keypoint index), lm_idx / kf_idx window-local, is_inlier = 1.
+ * = frame 0 through the chained relative poses), one edge per observation, edges landmark-major (landmarks ordered by their number
+ * of observations inside the window, then by the first of them: frame, then keypoint index), lm_idx / kf_idx window-local, is_inlier = 1.
  * All pointers are device pointers. */
 typedef struct vslam_tracks_in {
     int32_t n_frames;

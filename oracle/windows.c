@@ -16,7 +16,8 @@
  * compaction): the two decompositions share nothing but the rule set.
  * Throughput-mode conventions shared with the HIP path: every frame is a keyframe; window b = keyframes [max(0, b - n_kf + 1), b] with
  * the map state right after keyframe b; is_inlier = 1 on entry; world = frame 0, poses = the pose stage's relative poses chained
- * sequentially; landmarks of a window ordered by their first observation inside it (frame, then keypoint index). */
+ * sequentially; landmarks of a window ordered by the number of observations inside it, then by their first observation inside it (frame, then
+ * keypoint index) -- the optimiser takes any order (the reference iterates an unordered_map), this one keeps neighbouring landmarks alike. */
 #include <stdlib.h>
 #include <string.h>
 
@@ -43,9 +44,10 @@ static void world_point(const double* G /* T_c_w of the frame */, const float* p
     out[0] = (float)pw[0]; out[1] = (float)pw[1]; out[2] = (float)pw[2];
 }
 
-typedef struct { int first_frame, first_kp, id; } head_t;
+typedef struct { int cnt, first_frame, first_kp, id; } head_t;
 static int head_cmp(const void* a, const void* b) {
     const head_t* x = (const head_t*)a; const head_t* y = (const head_t*)b;
+    if (x->cnt != y->cnt) return x->cnt < y->cnt ? -1 : 1;
     if (x->first_frame != y->first_frame) return x->first_frame < y->first_frame ? -1 : 1;
     return x->first_kp < y->first_kp ? -1 : (x->first_kp > y->first_kp);
 }
@@ -124,7 +126,7 @@ int vo_build_windows(int n_frames, int kp_cap, int lr_cap, int match_cap, int pn
             for (int o = 0; o < L[id].n_obs; ++o)
                 if (L[id].obs[o].frame >= s && L[id].obs[o].frame <= b) { if (first < 0) first = o; ++cnt; }
             if (first < 0) continue;
-            heads[nh].first_frame = L[id].obs[first].frame; heads[nh].first_kp = L[id].obs[first].kp; heads[nh].id = id; ++nh;
+            heads[nh].first_frame = L[id].obs[first].frame; heads[nh].first_kp = L[id].obs[first].kp; heads[nh].id = id; heads[nh].cnt = cnt; ++nh;
             ne += cnt;
         }
         if (status || tot_l + nh > lm_capacity || tot_e + ne > edge_capacity) { status = 1; lm_off[b + 1] = tot_l; edge_off[b + 1] = tot_e; continue; }

@@ -975,9 +975,16 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     };
 #pragma unroll
                     for (int q = 0; q < kLmE; ++q) if (q < cn[u]) add_edge(kk[u][q], zz[u][q]);
-                    if (cn[u] > kLmE) { // more than kLmE observations: the rest through the CSR
+                    if (cn[u] > kLmE) { // more than kLmE observations (long tracks of a real sequence): the rest through the CSR, ALL of them
+                        // requested at once -- one edge per loop trip was one dependent round trip per observation, up to seven per batch
+                        constexpr int kTail = kMaxKf - kLmE;
                         const int b0 = lm_ptr[l];
-                        for (int e = b0 + kLmE; e < b0 + cn[u]; ++e) add_edge(kfi[e], uv2[e]);
+                        int kt[kTail]; float2 zt[kTail];
+#pragma unroll
+                        for (int q = 0; q < kTail; ++q) { const int e = min(b0 + kLmE + q, max(ne - 1, 0)); kt[q] = kfi[e]; zt[q] = uv2[e]; }
+#pragma unroll
+                        for (int q = 0; q < kTail; ++q) if (kLmE + q < cn[u]) add_edge(kt[q], zt[q]);
+                        for (int e = b0 + kMaxKf; e < b0 + cn[u]; ++e) add_edge(kfi[e], uv2[e]); // (only a malformed graph gets here; it is rejected by the hit-list build)
                     }
                     if (!lam_known) {
 #pragma unroll
@@ -1359,9 +1366,15 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         };
 #pragma unroll
                         for (int q = 0; q < kLmE; ++q) if (q < cn[u]) sub_edge(kk[u][q], zz[u][q]);
-                        if (cn[u] > kLmE) {
+                        if (cn[u] > kLmE) { // (as in the landmark pass: the tail in one batch)
+                            constexpr int kTail = kMaxKf - kLmE;
                             const int b0 = lm_ptr[l];
-                            for (int e = b0 + kLmE; e < b0 + cn[u]; ++e) sub_edge(kfi[e], uv2[e]);
+                            int kt[kTail]; float2 zt[kTail];
+#pragma unroll
+                            for (int q = 0; q < kTail; ++q) { const int e = min(b0 + kLmE + q, max(ne - 1, 0)); kt[q] = kfi[e]; zt[q] = uv2[e]; }
+#pragma unroll
+                            for (int q = 0; q < kTail; ++q) if (kLmE + q < cn[u]) sub_edge(kt[q], zt[q]);
+                            for (int e = b0 + kMaxKf; e < b0 + cn[u]; ++e) sub_edge(kfi[e], uv2[e]);
                         }
                         const double x0 = Dq[u][0] * c0 + Dq[u][1] * c1 + Dq[u][2] * c2;
                         const double x1 = Dq[u][1] * c0 + Dq[u][3] * c1 + Dq[u][4] * c2;

@@ -15,8 +15,11 @@
 //
 // gfx950 mapping: the reference walks std::unordered_map<id, Landmark> with per-landmark observation vectors; here a track is a chain
 // of (frame, keypoint) nodes linked by two flat int32 tables pred / succ (B x kp_capacity) filled by one scatter pass per frame pair,
-// every keypoint slot of the batch is a thread, and a window is one workgroup that compacts the chain HEADS inside its frames in
-// (frame, keypoint) order with ballot ranks -- landmark-sorted, window-local edge lists come out directly, nothing is sorted.
+// every keypoint slot of the batch is a thread, and a window is one workgroup that ranks the chain HEADS inside its frames with ballots
+// -- landmark-sorted, window-local edge lists come out directly, nothing is sorted.  Landmark order inside a window: by observation
+// count, then by the head's (frame, keypoint).  The optimiser accepts any landmark order; THIS one makes the 64 consecutive landmarks a
+// wave of its landmark-wise phases owns homogeneous (most landmarks of a real sequence are seen once, a few in all ten keyframes: in
+// creation order every wave ran ten observation rounds for an average of 1.3 useful ones).
 // All kernels are byte / index work on < 25 MB of tables per 256 frames: bound by launch latency, not by bandwidth.
 #include "vslam_internal.h"
 
@@ -166,20 +169,26 @@ __device__ inline int block_sum_i32(int v, int* red /* 4 */) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// ---- per window: landmark and edge counts
+// ---- per window: landmark and edge counts, and the landmarks per observation count (the bins of the emit pass)
+constexpr int kHist = VSLAM_MAX_KF + 1;
 __global__ __launch_bounds__(256) void window_count_kernel(TrackDims d, const int32_t* __restrict__ root, const int32_t* __restrict__ pred,
-                                                          const int32_t* __restrict__ succ, int32_t* __restrict__ counts) {
+                                                          const int32_t* __restrict__ succ, int32_t* __restrict__ counts, int32_t* __restrict__ hist) {
     const int b = blockIdx.x, tid = threadIdx.x, s = max(0, b - d.n_kf + 1);
     __shared__ int red[4];
+    __shared__ int h[kHist];
+    if (tid < kHist) h[tid] = 0;
+    __syncthreads();
     int nl = 0, ne = 0;
     for (int f = s; f <= b; ++f)
         for (int i = tid; i < d.kp_cap; i += 256) {
             const int len = window_head_len(d, root, pred, succ, s, b, f, i);
             nl += len > 0; ne += len;
+            if (len > 0) atomicAdd(&h[min(len, kHist - 1)], 1); // (integer: order-free)
         }
     nl = block_sum_i32(nl, red);
     ne = block_sum_i32(ne, red);
     if (tid == 0) { counts[2 * b] = nl; counts[2 * b + 1] = ne; }
+    if (tid < kHist) hist[(size_t)b * kHist + tid] = h[tid];
 }
 
 // ---- offsets of the concatenated arrays (exclusive scan over the windows; one workgroup).  A window that would run past a capacity, and
@@ -232,17 +241,19 @@ __global__ __launch_bounds__(256) void window_scan_kernel(TrackDims d, const int
     }
 }
 
-// ---- per window: emit poses, landmarks (head order) and edges (landmark-major, chronological inside a landmark)
+// ---- per window: emit poses, landmarks (by observation count, then head order) and edges (landmark-major, chronological inside a landmark)
 __global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vslam_keypoint* __restrict__ d_kps, const float* __restrict__ d_xyz,
                                                          const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ root,
                                                          const int32_t* __restrict__ relsrc, const int32_t* __restrict__ pred,
                                                          const int32_t* __restrict__ succ, const double* __restrict__ G,
-                                                         const int32_t* __restrict__ counts, const int32_t* __restrict__ lm_off,
+                                                         const int32_t* __restrict__ counts, const int32_t* __restrict__ hist,
+                                                         const int32_t* __restrict__ lm_off,
                                                          const int32_t* __restrict__ edge_off, double* __restrict__ T_out, float* __restrict__ xyz_out,
                                                          uint8_t* __restrict__ rel_out, uint8_t* __restrict__ inl_out, int32_t* __restrict__ kf_out,
                                                          int32_t* __restrict__ lm_out, float* __restrict__ uv_out) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = max(0, b - d.n_kf + 1), nk = b - s + 1;
-    __shared__ int s_l[4], s_e[4];
+    __shared__ int s_c[4][kHist];
+    __shared__ int bin_l[kHist], bin_e[kHist]; // first landmark / first edge (window-local) of the landmarks with c observations
     // poses of the window's keyframes (unused slots: identity)
     for (int i = tid; i < d.n_kf * 7; i += 256) {
         const int k = i / 7, c = i - 7 * k;
@@ -250,23 +261,33 @@ __global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vsl
     }
     const int l0 = lm_off[b], e0 = edge_off[b];
     if (lm_off[b + 1] - l0 != counts[2 * b] || edge_off[b + 1] - e0 != counts[2 * b + 1]) return; // truncated by the capacity check: empty window
-    int run_l = 0, run_e = 0;
+    if (tid == 0) {
+        int al = 0, ae = 0;
+        for (int c = 1; c < kHist; ++c) { bin_l[c] = al; bin_e[c] = ae; const int n = hist[(size_t)b * kHist + c]; al += n; ae += n * c; }
+    }
+    __syncthreads();
+    __shared__ int s_run[kHist]; // heads of every count seen so far
+    if (tid < kHist) s_run[tid] = 0;
     for (int f = s; f <= b; ++f)
         for (int base = 0; base < d.kp_cap; base += 256) {
             const int i = base + tid;
-            const int len = i < d.kp_cap ? window_head_len(d, root, pred, succ, s, b, f, i) : 0;
-            // ordered ranks: landmarks by ballot, edges by an in-wave inclusive scan of len
-            const unsigned long long mask = __ballot(len > 0);
-            int inc = len;
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+            const int len = i < d.kp_cap ? min(window_head_len(d, root, pred, succ, s, b, f, i), kHist - 1) : 0;
+            // rank of this head among the heads of the same count, in (frame, keypoint) order: one ballot per count
+            int my_rank = 0, my_wave_cnt = 0;
+#pragma unroll
+            for (int c = 1; c < kHist; ++c) {
+                const unsigned long long m = __ballot(len == c);
+                if (len == c) my_rank = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == c) my_wave_cnt = __popcll(m);
+            }
             __syncthreads();
-            if (lane == 63) { s_l[wave] = __popcll(mask); s_e[wave] = inc; }
+            if (lane < kHist) s_c[wave][lane] = my_wave_cnt;
             __syncthreads();
-            int ol = run_l, oe = run_e;
-            for (int w = 0; w < wave; ++w) { ol += s_l[w]; oe += s_e[w]; }
             if (len > 0) {
-                const int l = ol + __popcll(mask & ((1ull << lane) - 1ull));
-                int e = e0 + oe + inc - len;
+                int before = s_run[len];
+                for (int w = 0; w < wave; ++w) before += s_c[w][len];
+                const int l = bin_l[len] + before + my_rank;
+                int e = e0 + bin_e[len] + (before + my_rank) * len;
                 int cf = f, ci = i;
                 for (int k = 0; k < len; ++k) {
                     const vslam_keypoint* kp = d_kps + (size_t)cf * d.kp_cap + ci;
@@ -290,14 +311,14 @@ __global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vsl
                 o[0] = (float)pw[0]; o[1] = (float)pw[1]; o[2] = (float)pw[2];
                 rel_out[l0 + l] = rs >= 0; inl_out[l0 + l] = 1;
             }
-            run_l += s_l[0] + s_l[1] + s_l[2] + s_l[3];
-            run_e += s_e[0] + s_e[1] + s_e[2] + s_e[3];
+            __syncthreads();
+            if (tid < kHist) s_run[tid] += s_c[0][tid] + s_c[1][tid] + s_c[2][tid] + s_c[3][tid];
         }
 }
 
 size_t track_scratch_bytes(int B, int kp_cap) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return 5 * al((size_t)B * kp_cap * 4) + al((size_t)B * 7 * 8) + al((size_t)B * 2 * 4);
+    return 5 * al((size_t)B * kp_cap * 4) + al((size_t)B * 7 * 8) + al((size_t)B * 2 * 4) + al((size_t)B * (VSLAM_MAX_KF + 1) * 4);
 }
 
 int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, uint8_t* scratch, int32_t* d_lm_off,
@@ -310,14 +331,15 @@ int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, i
     int32_t* kp2lr = (int32_t*)scratch; int32_t* pred = (int32_t*)(scratch + tab); int32_t* succ = (int32_t*)(scratch + 2 * tab);
     int32_t* root = (int32_t*)(scratch + 3 * tab); int32_t* relsrc = (int32_t*)(scratch + 4 * tab);
     double* G = (double*)(scratch + 5 * tab); int32_t* counts = (int32_t*)(scratch + 5 * tab + al((size_t)d.B * 7 * 8));
+    int32_t* hist = (int32_t*)((uint8_t*)counts + al((size_t)d.B * 2 * 4));
     ProfScope prof__(stream, "build_windows_kernels", 7);
     hipLaunchKernelGGL(track_init_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_lr, in.d_nlr, kp2lr, pred, succ);
     hipLaunchKernelGGL(track_pose_chain_kernel, dim3(1), dim3(256), 0, stream, d.B, in.d_T_rel, G);
     if (d.B > 1) hipLaunchKernelGGL(track_link_kernel, dim3(d.B - 1), dim3(256), 0, stream, d, in.d_f2f, in.d_nf2f, in.d_valid, in.d_pose_inlier, kp2lr, pred, succ);
     hipLaunchKernelGGL(track_chain_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, in.d_valid, in.d_reliable, kp2lr, pred, root, relsrc);
-    hipLaunchKernelGGL(window_count_kernel, dim3(d.B), dim3(256), 0, stream, d, root, pred, succ, counts);
+    hipLaunchKernelGGL(window_count_kernel, dim3(d.B), dim3(256), 0, stream, d, root, pred, succ, counts, hist);
     hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(256), 0, stream, d, counts, lm_capacity, edge_capacity, d_lm_off, d_edge_off, d_n_kf, d_status);
-    hipLaunchKernelGGL(window_emit_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_kps, in.d_xyz, kp2lr, root, relsrc, pred, succ, G, counts, d_lm_off,
+    hipLaunchKernelGGL(window_emit_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_kps, in.d_xyz, kp2lr, root, relsrc, pred, succ, G, counts, hist, d_lm_off,
                        d_edge_off, d_T, d_xyz_out, d_rel_out, d_inl_out, d_kf_out, d_lm_out, d_uv_out);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;

@@ -41,16 +41,17 @@ def test_build_windows_hand_worked(oracle):
     assert w["kf_idx"][0:2].tolist() == [0, 0] and w["lm_idx"][0:2].tolist() == [0, 1]
     assert w["reliable"][0:2].tolist() == [1, 0]
     assert np.array_equal(w["xyz"][0], xyz[0, 0]) and np.array_equal(w["xyz"][1], xyz[0, 1])
-    # window 1 = keyframes 0, 1: A {(0,0), (1,1)}, B {(0,1), (1,0)} now reliable with the point of (1, 0), C created at (1, 2)
-    assert w["lm_idx"][2:7].tolist() == [0, 0, 1, 1, 2] and w["kf_idx"][2:7].tolist() == [0, 1, 0, 1, 1]
+    # window 1 = keyframes 0, 1: A {(0,0), (1,1)}, B {(0,1), (1,0)} now reliable with the point of (1, 0), C created at (1, 2).
+    # Landmark order: by observation count, then by the first observation inside the window -> C (1 obs), A, B (2 obs each)
+    assert w["lm_idx"][2:7].tolist() == [0, 1, 1, 2, 2] and w["kf_idx"][2:7].tolist() == [1, 0, 1, 0, 1]
     assert w["reliable"][2:5].tolist() == [1, 1, 1]
-    assert np.array_equal(w["xyz"][2], xyz[0, 0]) and np.array_equal(w["xyz"][3], xyz[1, 0]) and np.array_equal(w["xyz"][4], xyz[1, 1])
+    assert np.array_equal(w["xyz"][2], xyz[1, 1]) and np.array_equal(w["xyz"][3], xyz[0, 0]) and np.array_equal(w["xyz"][4], xyz[1, 0])
     uv = w["uv"][2:7]
-    assert uv[:, 0].tolist() == [kps["x"][0, 0], kps["x"][1, 1], kps["x"][0, 1], kps["x"][1, 0], kps["x"][1, 2]]
-    # window 2 = keyframes 1, 2: order by the first observation inside the window: B (1,0) [+ (2,0)], A (1,1), C (1,2); the rejected
-    # match (1,2) -> (2,1) adds nothing, and (2,1) has no depth: not a feature
-    assert w["lm_idx"][7:11].tolist() == [0, 0, 1, 2] and w["kf_idx"][7:11].tolist() == [0, 1, 0, 0]
-    assert np.array_equal(w["xyz"][5], xyz[1, 0]) and np.array_equal(w["xyz"][6], xyz[0, 0]) and np.array_equal(w["xyz"][7], xyz[1, 1])
+    assert uv[:, 0].tolist() == [kps["x"][1, 2], kps["x"][0, 0], kps["x"][1, 1], kps["x"][0, 1], kps["x"][1, 0]]
+    # window 2 = keyframes 1, 2: A (1,1) and C (1,2) with one observation, then B (1,0) [+ (2,0)]; the rejected match (1,2) -> (2,1) adds
+    # nothing, and (2,1) has no depth: not a feature
+    assert w["lm_idx"][7:11].tolist() == [0, 1, 2, 2] and w["kf_idx"][7:11].tolist() == [0, 0, 0, 1]
+    assert np.array_equal(w["xyz"][5], xyz[0, 0]) and np.array_equal(w["xyz"][6], xyz[1, 1]) and np.array_equal(w["xyz"][7], xyz[1, 0])
     assert (w["lm_inlier"][:8] == 1).all()
     assert np.allclose(w["T"][:, :, 3], 1) and np.allclose(w["T"][:, :, :3], 0)
 
@@ -65,6 +66,6 @@ def test_build_windows_world_frame_and_capacity(oracle):
     G1 = T_rel[0]; G2 = oracle.se3_mul(T_rel[1], T_rel[0])
     assert np.allclose(w["T"][1, 1], G1) and np.allclose(w["T"][2, 0], G1) and np.allclose(w["T"][2, 1], G2)
     pw = oracle.se3_act(oracle.se3_inv(G1), xyz[1, 0].astype(np.float64))
-    assert np.allclose(w["xyz"][3], pw, rtol=1e-6)          # landmark B in window 1: the point seen from frame 1, in the world frame
+    assert np.allclose(w["xyz"][4], pw, rtol=1e-6)          # landmark B in window 1: the point seen from frame 1, in the world frame
     small = oracle.build_windows(kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, n_kf=2, lm_capacity=6, edge_capacity=64)
     assert small["status"] == 1 and small["lm_off"].tolist() == [0, 2, 5, 5] and small["edge_off"].tolist() == [0, 2, 7, 7]
