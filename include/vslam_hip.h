@@ -292,6 +292,8 @@ typedef struct vslam_tracks_in {
     const uint8_t* d_pose_inlier;  /* (n_frames - 1) x pnp_capacity: inlier flag of input j of item i's pose problem, inputs in the order
                                       vslam_build_pnp_inputs_dev emitted them */
     const double* d_T_rel;         /* (n_frames - 1) x 7: T_{i+1,i}, the pose stage's estimate with frame i as the world */
+    const int32_t* d_nkps;         /* n_frames: keypoints of frame f (no match refers to a keypoint index beyond it), or NULL: every slot up to
+                                      kp_capacity is examined (slower, same result) */
 } vslam_tracks_in;
 /* Fills the device arrays of `out` (caller-allocated: d_lm_off / d_edge_off n_frames + 1, d_T_c_w n_frames x n_kf x 7, d_xyz /
  * d_reliable / d_lm_inlier for lm_capacity landmarks, d_kf_idx / d_lm_idx / d_uv for edge_capacity edges, d_n_kf n_frames; the

@@ -62,7 +62,7 @@ class TracksIn(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("kp_capacity", C.c_int32), ("lr_capacity", C.c_int32), ("match_capacity", C.c_int32),
                 ("pnp_capacity", C.c_int32), ("d_kps", C.c_void_p), ("d_lr", C.c_void_p), ("d_nlr", C.c_void_p), ("d_xyz", C.c_void_p),
                 ("d_valid", C.c_void_p), ("d_reliable", C.c_void_p), ("d_f2f", C.c_void_p), ("d_nf2f", C.c_void_p),
-                ("d_pose_inlier", C.c_void_p), ("d_T_rel", C.c_void_p)]
+                ("d_pose_inlier", C.c_void_p), ("d_T_rel", C.c_void_p), ("d_nkps", C.c_void_p)]
 
 
 # every symbol include/vslam_hip.h declares (checked by tests/test_abi.py)

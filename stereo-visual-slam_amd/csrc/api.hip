@@ -204,7 +204,7 @@ const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tes
            "sgbm_wta_kernel sgbm_lrcheck_kernel sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel "
            "sgbm_ccl_apply_kernel sgbm_ccl_kernels triangulate_kernel find3d_disparity_kernel gather_uv_kernel build_pnp_inputs_kernel lm_window_kernel pose_only_wave_kernel "
            "lm_window_kernel<pnp> pnp_wave_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel "
-           "build_windows_kernels track_init_kernel track_pose_chain_kernel track_link_kernel track_chain_kernel window_count_kernel window_scan_kernel window_emit_kernel";
+           "build_windows_kernels track_init_kernel track_pose_chain_kernel track_link_kernel track_chain_kernel window_count_kernel window_scan_kernel window_rank_kernel window_emit_kernel";
 }
 
 int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** out) {
@@ -931,7 +931,7 @@ int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf,
         !out->d_uv || !out->d_n_kf) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if ((long long)in->n_frames * in->kp_capacity > 0x7FFFFFFFll) { set_error("n_frames x kp_capacity exceeds the 31-bit node keys"); return VSLAM_ERR_ARG; }
     VS_ENTER(c);
-    const size_t need = track_scratch_bytes(in->n_frames, in->kp_capacity);
+    const size_t need = track_scratch_bytes(in->n_frames, in->kp_capacity, lm_capacity);
     if (c->track_bytes < need) {
         VS_HIP(hipStreamSynchronize(c->stream));
         if (c->d_track) { (void)hipFree(c->d_track); c->dev_bytes -= c->track_bytes; }

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void track_link_kernel(TrackDims d, const vsla
 // at the time of this node is that node's point if there is one, the root's otherwise (visual_odometry.cpp:391-401).
 __global__ __launch_bounds__(256) void track_chain_kernel(TrackDims d, const uint8_t* __restrict__ d_valid, const uint8_t* __restrict__ d_rel,
                                                          const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ pred,
-                                                         int32_t* __restrict__ root, int32_t* __restrict__ relsrc) {
+                                                         const int32_t* __restrict__ succ, int32_t* __restrict__ root, int32_t* __restrict__ relsrc,
+                                                         int32_t* __restrict__ info) {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d.kp_cap) return;
     const size_t at = (size_t)f * d.kp_cap + i;
@@ -144,21 +145,25 @@ __global__ __launch_bounds__(256) void track_chain_kernel(TrackDims d, const uin
         r = cf * d.kp_cap + ci;
     }
     root[at] = r; relsrc[at] = first;
+    // what a window needs to know about this slot without walking: node?, has a predecessor?, successors left in its chain
+    int rem = 0;
+    if (r >= 0) {
+        int cf = f, ci = i;
+        while (cf + 1 < d.B && rem < VSLAM_MAX_KF) {
+            const int nx = succ[(size_t)cf * d.kp_cap + ci];
+            if (nx < 0) break;
+            ++cf; ci = nx; ++rem;
+        }
+    }
+    info[at] = (r >= 0 ? 1 : 0) | (p >= 0 ? 2 : 0) | (rem << 8);
 }
 
 // A chain HEAD of window [s, b]: a node in frame s, or a node without predecessor (a landmark created inside the window).  Every
-// landmark observed in the window has exactly one.  Returns the observations it has inside the window (0: not a head).
-__device__ inline int window_head_len(const TrackDims& d, const int32_t* __restrict__ root, const int32_t* __restrict__ pred,
-                                      const int32_t* __restrict__ succ, int s, int b, int f, int i) {
-    const size_t at = (size_t)f * d.kp_cap + i;
-    if (root[at] < 0 || (f != s && pred[at] >= 0)) return 0;
-    int len = 1, cf = f, ci = i;
-    while (cf < b) {
-        const int nx = succ[(size_t)cf * d.kp_cap + ci];
-        if (nx < 0) break;
-        ++cf; ci = nx; ++len;
-    }
-    return len;
+// landmark observed in the window has exactly one.  Returns the observations it has inside the window (0: not a head) -- from the
+// slot's info word alone (track_chain_kernel), no chain walk.
+__device__ inline int window_head_len(int info, int s, int b, int f) {
+    if (!(info & 1) || (f != s && (info & 2))) return 0;
+    return min((info >> 8) + 1, b - f + 1);
 }
 
 __device__ inline int block_sum_i32(int v, int* red /* 4 */) {
@@ -171,20 +176,22 @@ __device__ inline int block_sum_i32(int v, int* red /* 4 */) {
 
 // ---- per window: landmark and edge counts, and the landmarks per observation count (the bins of the emit pass)
 constexpr int kHist = VSLAM_MAX_KF + 1;
-__global__ __launch_bounds__(256) void window_count_kernel(TrackDims d, const int32_t* __restrict__ root, const int32_t* __restrict__ pred,
-                                                          const int32_t* __restrict__ succ, int32_t* __restrict__ counts, int32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void window_count_kernel(TrackDims d, const int32_t* __restrict__ info, const int32_t* __restrict__ nkps,
+                                                          int32_t* __restrict__ counts, int32_t* __restrict__ hist) {
     const int b = blockIdx.x, tid = threadIdx.x, s = max(0, b - d.n_kf + 1);
     __shared__ int red[4];
     __shared__ int h[kHist];
     if (tid < kHist) h[tid] = 0;
     __syncthreads();
     int nl = 0, ne = 0;
-    for (int f = s; f <= b; ++f)
-        for (int i = tid; i < d.kp_cap; i += 256) {
-            const int len = window_head_len(d, root, pred, succ, s, b, f, i);
+    for (int f = s; f <= b; ++f) {
+        const int nkp = nkps ? min(max(nkps[f], 0), d.kp_cap) : d.kp_cap; // (slots beyond the frame's keypoints are never nodes)
+        for (int i = tid; i < nkp; i += 256) {
+            const int len = window_head_len(info[(size_t)f * d.kp_cap + i], s, b, f);
             nl += len > 0; ne += len;
             if (len > 0) atomicAdd(&h[min(len, kHist - 1)], 1); // (integer: order-free)
         }
+    }
     nl = block_sum_i32(nl, red);
     ne = block_sum_i32(ne, red);
     if (tid == 0) { counts[2 * b] = nl; counts[2 * b + 1] = ne; }
@@ -241,38 +248,32 @@ __global__ __launch_bounds__(256) void window_scan_kernel(TrackDims d, const int
     }
 }
 
-// ---- per window: emit poses, landmarks (by observation count, then head order) and edges (landmark-major, chronological inside a landmark)
-__global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vslam_keypoint* __restrict__ d_kps, const float* __restrict__ d_xyz,
-                                                         const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ root,
-                                                         const int32_t* __restrict__ relsrc, const int32_t* __restrict__ pred,
-                                                         const int32_t* __restrict__ succ, const double* __restrict__ G,
-                                                         const int32_t* __restrict__ counts, const int32_t* __restrict__ hist,
-                                                         const int32_t* __restrict__ lm_off,
-                                                         const int32_t* __restrict__ edge_off, double* __restrict__ T_out, float* __restrict__ xyz_out,
-                                                         uint8_t* __restrict__ rel_out, uint8_t* __restrict__ inl_out, int32_t* __restrict__ kf_out,
-                                                         int32_t* __restrict__ lm_out, float* __restrict__ uv_out) {
+// ---- per window: poses, and the RANK of every chain head = its window-local landmark index (by observation count, then by (frame,
+// keypoint)); the head's record goes to head_rec[global landmark index] for the emit pass.  No dependent loads here: one info word per
+// slot, a ballot per count, three barriers per 1024 slots.
+constexpr int kRankBlock = 1024, kRankWaves = kRankBlock / 64;
+__global__ __launch_bounds__(kRankBlock) void window_rank_kernel(TrackDims d, const double* __restrict__ G, const int32_t* __restrict__ counts,
+                                                                const int32_t* __restrict__ hist, const int32_t* __restrict__ info,
+                                                                const int32_t* __restrict__ nkps, const int32_t* __restrict__ lm_off,
+                                                                const int32_t* __restrict__ edge_off, double* __restrict__ T_out,
+                                                                uint32_t* __restrict__ head_rec) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = max(0, b - d.n_kf + 1), nk = b - s + 1;
-    __shared__ int s_c[4][kHist];
-    __shared__ int bin_l[kHist], bin_e[kHist]; // first landmark / first edge (window-local) of the landmarks with c observations
-    // poses of the window's keyframes (unused slots: identity)
-    for (int i = tid; i < d.n_kf * 7; i += 256) {
+    __shared__ int s_c[kRankWaves][kHist];
+    __shared__ int bin_l[kHist], s_run[kHist];
+    for (int i = tid; i < d.n_kf * 7; i += kRankBlock) { // poses of the window's keyframes (unused slots: identity)
         const int k = i / 7, c = i - 7 * k;
         T_out[(size_t)b * d.n_kf * 7 + i] = k < nk ? G[(size_t)(s + k) * 7 + c] : (c == 3 ? 1.0 : 0.0);
     }
-    const int l0 = lm_off[b], e0 = edge_off[b];
-    if (lm_off[b + 1] - l0 != counts[2 * b] || edge_off[b + 1] - e0 != counts[2 * b + 1]) return; // truncated by the capacity check: empty window
-    if (tid == 0) {
-        int al = 0, ae = 0;
-        for (int c = 1; c < kHist; ++c) { bin_l[c] = al; bin_e[c] = ae; const int n = hist[(size_t)b * kHist + c]; al += n; ae += n * c; }
-    }
-    __syncthreads();
-    __shared__ int s_run[kHist]; // heads of every count seen so far
+    const int l0 = lm_off[b];
+    if (lm_off[b + 1] - l0 != counts[2 * b] || edge_off[b + 1] - edge_off[b] != counts[2 * b + 1]) return; // truncated by the capacity check: empty window
+    if (tid == 0) { int al = 0; for (int c = 1; c < kHist; ++c) { bin_l[c] = al; al += hist[(size_t)b * kHist + c]; } }
     if (tid < kHist) s_run[tid] = 0;
-    for (int f = s; f <= b; ++f)
-        for (int base = 0; base < d.kp_cap; base += 256) {
+    __syncthreads();
+    for (int f = s; f <= b; ++f) {
+        const int nkp = nkps ? min(max(nkps[f], 0), d.kp_cap) : d.kp_cap;
+        for (int base = 0; base < nkp; base += kRankBlock) {
             const int i = base + tid;
-            const int len = i < d.kp_cap ? min(window_head_len(d, root, pred, succ, s, b, f, i), kHist - 1) : 0;
-            // rank of this head among the heads of the same count, in (frame, keypoint) order: one ballot per count
+            const int len = i < nkp ? min(window_head_len(info[(size_t)f * d.kp_cap + i], s, b, f), kHist - 1) : 0;
             int my_rank = 0, my_wave_cnt = 0;
 #pragma unroll
             for (int c = 1; c < kHist; ++c) {
@@ -286,39 +287,60 @@ __global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vsl
             if (len > 0) {
                 int before = s_run[len];
                 for (int w = 0; w < wave; ++w) before += s_c[w][len];
-                const int l = bin_l[len] + before + my_rank;
-                int e = e0 + bin_e[len] + (before + my_rank) * len;
-                int cf = f, ci = i;
-                for (int k = 0; k < len; ++k) {
-                    const vslam_keypoint* kp = d_kps + (size_t)cf * d.kp_cap + ci;
-                    kf_out[e] = cf - s; lm_out[e] = l;
-                    reinterpret_cast<float2*>(uv_out)[e] = make_float2(kp->x, kp->y);
-                    ++e;
-                    if (k + 1 < len) { ci = succ[(size_t)cf * d.kp_cap + ci]; ++cf; }
-                }
-                // position / reliable_depth_ as of the landmark's last observation inside the window
-                const size_t last = (size_t)cf * d.kp_cap + ci;
-                const int rs = relsrc[last];
-                const int src = rs >= 0 ? rs : root[last];
-                const int sf = src / d.kp_cap, si = src - sf * d.kp_cap;
-                const int mm = kp2lr[(size_t)sf * d.kp_cap + si];
-                const float* pc = d_xyz + 3 * ((size_t)sf * d.lr_cap + mm);
-                double Gi[7], pw[3];
-                const double p[3] = {(double)pc[0], (double)pc[1], (double)pc[2]};
-                se3::inverse(G + (size_t)sf * 7, Gi);
-                se3::act(Gi, p, pw);
-                float* o = xyz_out + 3 * (size_t)(l0 + l);
-                o[0] = (float)pw[0]; o[1] = (float)pw[1]; o[2] = (float)pw[2];
-                rel_out[l0 + l] = rs >= 0; inl_out[l0 + l] = 1;
+                head_rec[l0 + bin_l[len] + before + my_rank] = (uint32_t)(f - s) | ((uint32_t)i << 4) | ((uint32_t)len << 20);
             }
             __syncthreads();
-            if (tid < kHist) s_run[tid] += s_c[0][tid] + s_c[1][tid] + s_c[2][tid] + s_c[3][tid];
+            if (tid < kHist) { int t = 0; for (int w = 0; w < kRankWaves; ++w) t += s_c[w][tid]; s_run[tid] += t; }
         }
+    }
 }
 
-size_t track_scratch_bytes(int B, int kp_cap) {
+// ---- one thread per landmark of the batch: its edges (chronological) and its position / reliable_depth_ as of its last observation inside
+// the window.  Flat over the concatenated landmark array: the window is found by bisection of lm_off.
+__global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vslam_keypoint* __restrict__ d_kps, const float* __restrict__ d_xyz,
+                                                         const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ root,
+                                                         const int32_t* __restrict__ relsrc, const int32_t* __restrict__ succ,
+                                                         const double* __restrict__ G, const int32_t* __restrict__ hist,
+                                                         const uint32_t* __restrict__ head_rec, const int32_t* __restrict__ lm_off,
+                                                         const int32_t* __restrict__ edge_off, float* __restrict__ xyz_out,
+                                                         uint8_t* __restrict__ rel_out, uint8_t* __restrict__ inl_out, int32_t* __restrict__ kf_out,
+                                                         int32_t* __restrict__ lm_out, float* __restrict__ uv_out) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= lm_off[d.B]) return;
+    int lo = 0, hi = d.B; // largest b with lm_off[b] <= g
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lm_off[mid] <= g) lo = mid; else hi = mid; }
+    const int b = lo, s = max(0, b - d.n_kf + 1), l = g - lm_off[b];
+    const uint32_t rec = head_rec[g];
+    const int f = s + (int)(rec & 15u), i = (int)((rec >> 4) & 0xFFFFu), len = (int)(rec >> 20);
+    int bl = 0, be = 0; // first landmark / first edge of the landmarks with `len` observations
+    for (int c = 1; c < len; ++c) { const int n = hist[(size_t)b * kHist + c]; bl += n; be += n * c; }
+    int e = edge_off[b] + be + (l - bl) * len;
+    int cf = f, ci = i;
+    for (int k = 0; k < len; ++k) {
+        const vslam_keypoint* kp = d_kps + (size_t)cf * d.kp_cap + ci;
+        kf_out[e] = cf - s; lm_out[e] = l;
+        reinterpret_cast<float2*>(uv_out)[e] = make_float2(kp->x, kp->y);
+        ++e;
+        if (k + 1 < len) { ci = succ[(size_t)cf * d.kp_cap + ci]; ++cf; }
+    }
+    const size_t last = (size_t)cf * d.kp_cap + ci;
+    const int rs = relsrc[last];
+    const int src = rs >= 0 ? rs : root[last];
+    const int sf = src / d.kp_cap, si = src - sf * d.kp_cap;
+    const int mm = kp2lr[(size_t)sf * d.kp_cap + si];
+    const float* pc = d_xyz + 3 * ((size_t)sf * d.lr_cap + mm);
+    double Gi[7], pw[3];
+    const double p[3] = {(double)pc[0], (double)pc[1], (double)pc[2]};
+    se3::inverse(G + (size_t)sf * 7, Gi);
+    se3::act(Gi, p, pw);
+    float* o = xyz_out + 3 * (size_t)g;
+    o[0] = (float)pw[0]; o[1] = (float)pw[1]; o[2] = (float)pw[2];
+    rel_out[g] = rs >= 0; inl_out[g] = 1;
+}
+
+size_t track_scratch_bytes(int B, int kp_cap, int lm_capacity) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return 5 * al((size_t)B * kp_cap * 4) + al((size_t)B * 7 * 8) + al((size_t)B * 2 * 4) + al((size_t)B * (VSLAM_MAX_KF + 1) * 4);
+    return al((size_t)lm_capacity * 4) + 6 * al((size_t)B * kp_cap * 4) + al((size_t)B * 7 * 8) + al((size_t)B * 2 * 4) + al((size_t)B * (VSLAM_MAX_KF + 1) * 4);
 }
 
 int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, uint8_t* scratch, int32_t* d_lm_off,
@@ -329,18 +351,20 @@ int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, i
     d.B = in.n_frames; d.kp_cap = in.kp_capacity; d.lr_cap = in.lr_capacity; d.match_cap = in.match_capacity; d.pnp_cap = in.pnp_capacity; d.n_kf = n_kf;
     const size_t tab = al((size_t)d.B * d.kp_cap * 4);
     int32_t* kp2lr = (int32_t*)scratch; int32_t* pred = (int32_t*)(scratch + tab); int32_t* succ = (int32_t*)(scratch + 2 * tab);
-    int32_t* root = (int32_t*)(scratch + 3 * tab); int32_t* relsrc = (int32_t*)(scratch + 4 * tab);
-    double* G = (double*)(scratch + 5 * tab); int32_t* counts = (int32_t*)(scratch + 5 * tab + al((size_t)d.B * 7 * 8));
+    int32_t* root = (int32_t*)(scratch + 3 * tab); int32_t* relsrc = (int32_t*)(scratch + 4 * tab); int32_t* info = (int32_t*)(scratch + 5 * tab);
+    double* G = (double*)(scratch + 6 * tab); int32_t* counts = (int32_t*)(scratch + 6 * tab + al((size_t)d.B * 7 * 8));
     int32_t* hist = (int32_t*)((uint8_t*)counts + al((size_t)d.B * 2 * 4));
-    ProfScope prof__(stream, "build_windows_kernels", 7);
+    uint32_t* head_rec = (uint32_t*)((uint8_t*)hist + al((size_t)d.B * (VSLAM_MAX_KF + 1) * 4));
+    ProfScope prof__(stream, "build_windows_kernels", 8);
     hipLaunchKernelGGL(track_init_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_lr, in.d_nlr, kp2lr, pred, succ);
     hipLaunchKernelGGL(track_pose_chain_kernel, dim3(1), dim3(256), 0, stream, d.B, in.d_T_rel, G);
     if (d.B > 1) hipLaunchKernelGGL(track_link_kernel, dim3(d.B - 1), dim3(256), 0, stream, d, in.d_f2f, in.d_nf2f, in.d_valid, in.d_pose_inlier, kp2lr, pred, succ);
-    hipLaunchKernelGGL(track_chain_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, in.d_valid, in.d_reliable, kp2lr, pred, root, relsrc);
-    hipLaunchKernelGGL(window_count_kernel, dim3(d.B), dim3(256), 0, stream, d, root, pred, succ, counts, hist);
+    hipLaunchKernelGGL(track_chain_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, in.d_valid, in.d_reliable, kp2lr, pred, succ, root, relsrc, info);
+    hipLaunchKernelGGL(window_count_kernel, dim3(d.B), dim3(256), 0, stream, d, info, in.d_nkps, counts, hist);
     hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(256), 0, stream, d, counts, lm_capacity, edge_capacity, d_lm_off, d_edge_off, d_n_kf, d_status);
-    hipLaunchKernelGGL(window_emit_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_kps, in.d_xyz, kp2lr, root, relsrc, pred, succ, G, counts, hist, d_lm_off,
-                       d_edge_off, d_T, d_xyz_out, d_rel_out, d_inl_out, d_kf_out, d_lm_out, d_uv_out);
+    hipLaunchKernelGGL(window_rank_kernel, dim3(d.B), dim3(kRankBlock), 0, stream, d, G, counts, hist, info, in.d_nkps, d_lm_off, d_edge_off, d_T, head_rec);
+    hipLaunchKernelGGL(window_emit_kernel, dim3((lm_capacity + 255) / 256), dim3(256), 0, stream, d, in.d_kps, in.d_xyz, kp2lr, root, relsrc, succ, G, hist, head_rec,
+                       d_lm_off, d_edge_off, d_xyz_out, d_rel_out, d_inl_out, d_kf_out, d_lm_out, d_uv_out);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }

@@ -230,7 +230,7 @@ int launch_pnp_count_inliers(const float* d_xyz, const float* d_uv, int n, const
                              double reproj_thr, int32_t* d_counts, uint8_t* d_mask, hipStream_t stream);
 
 // track_kernels.hip: BA windows of a batch of consecutive keyframes from the front end's device-resident output
-size_t track_scratch_bytes(int B, int kp_cap);
+size_t track_scratch_bytes(int B, int kp_cap, int lm_capacity);
 int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, uint8_t* scratch, int32_t* d_lm_off,
                          int32_t* d_edge_off, int32_t* d_n_kf, double* d_T, float* d_xyz_out, uint8_t* d_rel_out, uint8_t* d_inl_out,
                          int32_t* d_kf_out, int32_t* d_lm_out, float* d_uv_out, int32_t* d_status, hipStream_t stream);

@@ -124,6 +124,7 @@ class KeyframePipeline:
             tr.d_kps = self.d_kps.data_ptr(); tr.d_lr = self.d_lr.data_ptr(); tr.d_nlr = self.d_nlr.data_ptr(); tr.d_xyz = self.d_xyz.data_ptr()
             tr.d_valid = self.d_valid.data_ptr(); tr.d_reliable = self.d_rel.data_ptr(); tr.d_f2f = self.d_f2f.data_ptr()
             tr.d_nf2f = self.d_nf2f.data_ptr(); tr.d_pose_inlier = self.d_inl.data_ptr(); tr.d_T_rel = self.d_Tpnp.data_ptr()
+            tr.d_nkps = self.d_cnt.data_ptr()   # (the first B counts: the left images)
             self.tracks = tr
             bb = BaBatch()
             bb.n_windows = B; bb.n_kf = n_kf
