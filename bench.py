@@ -377,6 +377,54 @@ def ba_config4_measure(args, local, torch):
         pipe.close()
 
 
+def reference_pipeline_measure(args, local, torch, seq, B=64):
+    """The REFERENCE's own stages in throughput mode, measured in the default run so that the driver records it: depth from StereoSGBM +
+    Frame::find_3d on the left keypoints (visual_odometry.cpp:159-217) instead of L/R match + DLT, pose from cv::solvePnPRansac(..., 100, 4.0,
+    0.99) (:277) instead of the motion-only LM, then the same device-built windows and BA schedule.  B keyframes per step, a few steps."""
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    B = min(B, len(seq))
+    pipe = KeyframePipeline(B, device=local, anms_num=args.anms, unique_frames=B, sequence=seq[:B], depth="sgbm", pose="ransac", ba_windows="tracks")
+    try:
+        for _ in range(2):
+            pipe.step()
+        torch.cuda.synchronize(pipe.dev)
+        n = max(args.steps // 2, 3)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            pipe.step()
+        torch.cuda.synchronize(pipe.dev)
+        el = time.perf_counter() - t0
+        pipe.vo.profile_enable(True); pipe.vo.profile_read()
+        for _ in range(n):
+            pipe.step()
+        prof = pipe.vo.profile_read(); pipe.vo.profile_enable(False)
+        bad = int((pipe.vo.orb_status(B) != 0).sum()) + int((pipe.vo.ba_status(B) != 0).sum()) + int(pipe.ba_build_status.item()) + int(pipe.vo.sgbm_status() != 0)
+        if bad:
+            return {"error": "status words non-zero (%d)" % bad}
+        out = pipe.download()
+        kern = sorted(prof.items(), key=lambda kv: -kv[1][0])
+        fam_ms = sum(v[0] for k, v in kern if k.startswith("sgbm_")) / n
+        cv = (pipe.w - 96) * pipe.h * 96 * 2
+        alg = B * (cv + 2 * pipe.w * pipe.h + 4 * pipe.w * pipe.h)
+        gbs = alg / (fam_ms / 1e3) / 1e9 if fam_ms > 0 else 0.0
+        tj, src = load_counter_json("traffic_sgbm.json")
+        nt = max(B - 1, 1)
+        return {"workload": "reference stages: ORB(3000)->ANMS(%d)->rBRIEF on the left image, StereoSGBM(0,96,9,648,2592,1,63,10,100,32) + find_3d depth, "
+                            "frame-to-frame match, solvePnPRansac(100, 4.0, 0.99) pose (EPnP hypotheses, OpenCV 3.2.0 return value), device-built BA windows, "
+                            "BA schedule 5+5+10+10; %d keyframes per step" % (args.anms, B),
+                "value": round(B * n / el, 2), "unit": "keyframes/s", "ms_per_step": round(1e3 * el / n, 4), "steps": n, "batch": B,
+                "kernels_ms_per_step": {k: round(v[0] / n, 4) for k, v in kern[:14]},
+                "roofline": {"bound": "hbm", "kernel": "sgbm_* (family)", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                             "ms_per_pair": round(fam_ms / B, 4), "algorithmic_bytes_per_launch_set": int(alg),
+                             "formula": "B pairs x ((w-96)*h*96*2 B cost volume once + 2*w*h B images in + 4*w*h B f32 disparity out)",
+                             "traffic": int(tj["hbm_bytes_per_launch_set"]) if tj and tj.get("batch") == B else None, "traffic_source": src},
+                "stats": {"keypoints_per_image": float(out["cnt"][:B].mean()), "valid_depth_per_image": float(out["valid"].sum(1).mean()),
+                          "f2f_matches": float(out["nf2f"][:nt].mean()), "pose_inputs": float(out["pn"][:nt].mean()), "ransac_inliers": float(out["ninl"][:nt].mean()),
+                          "landmarks_per_window_mean": float(np.diff(out["ba_lm_off"]).mean()), "edges_per_window_mean": float(np.diff(out["ba_e_off"]).mean())}}
+    finally:
+        pipe.close()
+
+
 def host_input_region(pipe, args, timed_region, one_step, torch):
     """--inputs host: the same steps with every step's 2B images arriving from pinned host memory: ring of two device batches, the
     hipMemcpyAsync of step k+1 on a copy stream overlapped with step k (the reference reads its pairs from disk per frame,
@@ -502,6 +550,9 @@ def main():
                     help="tracks (default): the BA windows are built on the device from the step's own matches and poses (one pipeline: window b = "
                          "keyframes [b-9, b] of the batch); synthetic: B canned windows of the BASELINE config-4 shape (10 KF x --landmarks)")
     ap.add_argument("--no-config4", action="store_true", help="skip the extra BA-only measurement on the config-4 shape")
+    ap.add_argument("--pose", choices=["lm", "ransac"], default="lm",
+                    help="pose stage: north_star motion-only LM (default, BASELINE metric) or the reference's solvePnPRansac(100, 4.0, 0.99), batched on the device")
+    ap.add_argument("--no-reference-pipeline", action="store_true", help="skip the extra measurement of the reference's own stages (SGBM depth + RANSAC pose)")
     ap.add_argument("--sequence", type=int, default=0, metavar="F",
                     help="BASELINE config 5: one F-frame sequence split into contiguous chunks with a 1-frame halo across the ranks, relative poses "
                          "gathered over RCCL and chained on rank 0 (stereo-visual-slam_amd/sharding.py); 0 = independent batches per rank")
@@ -558,11 +609,11 @@ def main():
         B = hi - h_lo
         pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=0, verbose=args.verbose and rank == 0,
                                 with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence),
-                                render_workers=render_workers, ba_windows=ba_windows)
+                                render_workers=render_workers, ba_windows=ba_windows, pose=args.pose)
     else:
         pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
                                 with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, render_workers=render_workers,
-                                ba_windows=ba_windows)
+                                ba_windows=ba_windows, pose=args.pose)
     dev = pipe.dev
     chained = [None]
 
@@ -665,6 +716,16 @@ def main():
             else:
                 traffic_src = "profiles/%s was measured for kernel %s at batch %s, not %s at %d" % (tname, tj.get("kernel"), tj.get("batch"), dom, B)
         nt = max(B - 1, 1)
+        pose_txt = ("motion-only LM pose (10 its)" if args.pose == "lm" else
+                    "solvePnPRansac(100, 4.0, 0.99) pose [the reference's own pose stage; not the BASELINE metric]")
+        win_txt = ("BA windows built on the device from this step's own tracks (window b = keyframes [b-9, b]: poses = chained pose-stage estimates, "
+                   "landmarks / observations as VO::insert_key_frame records them)" if pipe.ba_windows == "tracks" else
+                   "%d canned synthetic windows of 10 KF x %d landmarks (config-4 shape; NOT fed by the front end of the step)" % (pipe.unique_windows, args.landmarks))
+        workload = ("stereo keyframe hot path, north_star stages (NOT the reference's SGBM depth / solvePnPRansac pose, which are built and measured "
+                    "under `reference_pipeline`; --depth sgbm / --pose ransac select them here): ORB(3000)->ANMS(%d)->rBRIEF on L+R 1241x376, L/R + "
+                    "frame-to-frame BF-Hamming cross-check match, epipolar-gated DLT triangulation, %s, %s, local BA schedule 5+5+10 LM + 10 pose-only "
+                    "per window%s%s" % (args.anms, pose_txt, win_txt, "" if not args.no_ba else " [BA disabled]",
+                                        " [depth stage swapped for the reference's own: SGBM disparity + find_3d; not the BASELINE metric]" if args.depth == "sgbm" else ""))
         res = {
             "metric": "stereo keyframes/sec (ORB+match+tri+local-BA), KITTI-00 1241x376",
             "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -672,15 +733,7 @@ def main():
             "collective": ("RCCL %s over torch.distributed backend nccl" % _rccl_version(torch)) if dist is not None else "none (1 rank)",
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if seq_mode else "weak", "vs_baseline": None,
             "dtype": "u8+f64", "data": "synthetic",
-            "config": {"workload": ("stereo keyframe hot path, north_star stages (NOT the reference's SGBM depth / solvePnPRansac pose, which are built "
-                                    "and selectable: --depth sgbm, host driver): ORB(3000)->ANMS(%d)->rBRIEF on L+R 1241x376, L/R + frame-to-frame "
-                                    "BF-Hamming cross-check match, epipolar-gated DLT triangulation, motion-only LM pose (10 its), %s, local BA "
-                                    "schedule 5+5+10 LM + 10 pose-only per window%s" % (args.anms,
-                                    ("BA windows built on the device from this step's own tracks (window b = keyframes [b-9, b]: poses = chained pose-stage estimates, "
-                                     "landmarks / observations as VO::insert_key_frame records them)" if pipe.ba_windows == "tracks" else
-                                     "%d canned synthetic windows of 10 KF x %d landmarks (config-4 shape; NOT fed by the front end of the step)" % (pipe.unique_windows, args.landmarks)),
-                                    "" if not args.no_ba else " [BA disabled]"))
-                                   + (" [depth stage swapped for the reference's own: SGBM disparity + find_3d; not the BASELINE metric]" if args.depth == "sgbm" else ""),
+            "config": {"workload": workload,
                        "batch_keyframes_per_gpu": B, "image": "1241x376 u8",
                        "ba_windows": pipe.ba_windows if pipe.with_ba else None,
                        "unique_inputs": "%d rendered stereo keyframes of one sequence (ping-pong over the batch), %d BA windows (%s)" % (
@@ -711,13 +764,19 @@ def main():
             res["inputs_from_host"] = host_inputs
         if seq_mode and chained[0] is not None:
             res["trajectory"] = {"frames": int(len(chained[0])), "final_position": [float(x) for x in sharding.camera_centre(chained[0][-1])]}
-        extras_ok = world == 1 and not args.no_ba and args.depth == "match" and not seq_mode
-        if extras_ok and not args.no_config4 and pipe.ba_windows == "tracks":
-            pipe.close()    # (host arrays stay; the GPU memory goes back before the second pipeline is built)
-            try:
-                res["ba_config4"] = ba_config4_measure(args, local, torch)
-            except Exception as e:  # an extra must never cost the headline
-                res["ba_config4"] = {"error": repr(e)}
+        extras_ok = world == 1 and not args.no_ba and args.depth == "match" and args.pose == "lm" and not seq_mode
+        if extras_ok and pipe.ba_windows == "tracks":
+            pipe.close()    # (host arrays stay; the GPU memory goes back before the next pipeline is built)
+            if not args.no_reference_pipeline:
+                try:
+                    res["reference_pipeline"] = reference_pipeline_measure(args, local, torch, pipe.h_seq)
+                except Exception as e:  # an extra must never cost the headline
+                    res["reference_pipeline"] = {"error": repr(e)}
+            if not args.no_config4:
+                try:
+                    res["ba_config4"] = ba_config4_measure(args, local, torch)
+                except Exception as e:
+                    res["ba_config4"] = {"error": repr(e)}
         if extras_ok and not args.no_cpu_baseline:
             res["cpu_baseline"], res["pose_rmse_vs_oracle"] = (cpu_baseline_tracks if pipe.ba_windows == "tracks" else cpu_baseline)(pipe, out, args.anms)
             info, have_cv2 = host_info()

@@ -212,6 +212,13 @@ int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n,
 int vslam_pnp_ransac_models(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters, double reproj_err,
                             double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run, double* models_Rt,
                             int32_t* models_count);
+/* The same call for B independent problems whose points are already on the device (throughput mode: the reference's own pose stage,
+ * visual_odometry.cpp:277, batched): problem b owns d_n[b] points at [b * capacity, ...) of d_xyz_w (x 3) / d_uv (x 2).  All B x max_iters
+ * hypotheses are solved and scored at once, the sequential acceptance rule with its adaptive stopping is replayed per problem.  Returns
+ * what OpenCV 3.2.0 returns: the best RANSAC model itself (no refinement; the host-buffer call's lm_iters = 0), T = identity and 0 inliers
+ * when no model was accepted or d_n[b] < 5.  d_inlier (B x capacity), d_n_inliers (B), d_iters_run (B) may be NULL.  Asynchronous. */
+int vslam_pnp_ransac_dev(vslam_ctx* ctx, const float* d_xyz_w, const float* d_uv, const int32_t* d_n, int capacity, int B, double* d_T_c_w,
+                         int max_iters, double reproj_err, double confidence, uint8_t* d_inlier, int32_t* d_n_inliers, int32_t* d_iters_run);
 
 /* VO::check_motion_estimation (visual_odometry.cpp:316-346); host arithmetic (scalar). returns 1/0. */
 int vslam_check_motion(int num_inliers, const double T_c_l[7], double frame_gap);

@@ -75,7 +75,7 @@ ABI_SYMBOLS = [
     "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
     "vslam_profile_enable", "vslam_profile_read", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
-    "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant", "vslam_sgbm_status_dev", "vslam_set_tuning", "vslam_build_windows_dev",
+    "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant", "vslam_sgbm_status_dev", "vslam_set_tuning", "vslam_build_windows_dev", "vslam_pnp_ransac_dev",
 ]
 
 
@@ -132,6 +132,7 @@ def load_library():
     lib.vslam_pose_only_window.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     lib.vslam_ba_batch_dev.argtypes = [vp, vp, i32, i32, i32, i32, i32]
     lib.vslam_pnp_ransac.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, i32, vp, vp, vp]
+    lib.vslam_pnp_ransac_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, dbl, dbl, vp, vp, vp]
     lib.vslam_pnp_ransac_models.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, i32, vp, vp, vp, vp, vp]
     lib.vslam_feature_matching_dev.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp, vp, i32, i32, i32, vp, i32, vp]
     lib.vslam_hbm_copy_probe_variant.argtypes = [vp, C.c_size_t, i32, i32, vp, vp]
@@ -358,6 +359,13 @@ class VO:
     def motion_estimation_dev(self, d_xyz, d_uv, d_n, capacity, B, d_T, iters, d_inlier, d_ninl):
         self._chk(self.lib.vslam_pnp_motion_only_dev(self.h, _p(d_xyz), _p(d_uv), _p(d_n), int(capacity), int(B), _p(d_T), int(iters),
                                                      _p(d_inlier), _p(d_ninl)), "vslam_pnp_motion_only_dev")
+
+    def pnp_ransac_dev(self, d_xyz, d_uv, d_n, capacity, B, d_T, max_iters=100, reproj_err=4.0, confidence=0.99, d_inlier=None, d_ninl=None, d_iters=None):
+        """cv::solvePnPRansac(..., 100, 4.0, 0.99) of VO::motion_estimation (visual_odometry.cpp:277) for B device-resident problems"""
+        self._chk(self.lib.vslam_pnp_ransac_dev(self.h, _p(d_xyz), _p(d_uv), _p(d_n), int(capacity), int(B), _p(d_T), int(max_iters), C.c_double(reproj_err),
+                                                C.c_double(confidence), _p(d_inlier) if d_inlier is not None else None,
+                                                _p(d_ninl) if d_ninl is not None else None, _p(d_iters) if d_iters is not None else None),
+                  "vslam_pnp_ransac_dev")
 
     def check_motion_estimation(self, num_inliers, T_c_l, frame_gap):
         T = np.ascontiguousarray(T_c_l, np.float64)

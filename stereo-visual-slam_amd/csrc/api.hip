@@ -204,6 +204,7 @@ const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tes
            "sgbm_wta_kernel sgbm_lrcheck_kernel sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel "
            "sgbm_ccl_apply_kernel sgbm_ccl_kernels triangulate_kernel find3d_disparity_kernel gather_uv_kernel build_pnp_inputs_kernel lm_window_kernel pose_only_wave_kernel "
            "lm_window_kernel<pnp> pnp_wave_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel "
+           "pnp_ransac_subsets_kernel pnp_ransac_count_kernel pnp_ransac_select_kernel "
            "build_windows_kernels track_init_kernel track_pose_chain_kernel track_link_kernel track_chain_kernel window_count_kernel window_scan_kernel window_rank_kernel window_emit_kernel";
 }
 
@@ -260,6 +261,7 @@ void vslam_destroy(vslam_ctx* ctx) {
     orb_tables_free(&c->tab);
     if (c->d_sgbm) hipFree(c->d_sgbm);
     if (c->d_track) hipFree(c->d_track);
+    if (c->d_ransac) hipFree(c->d_ransac);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->lm.buf) hipFree(c->lm.buf);
     void* ptrs[] = {c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel, c->orb.d_sel_cnt, c->orb.d_status, c->orb.d_det, c->orb.d_blur, c->orb.d_cs, c->orb.d_order, c->orb.d_rad,
@@ -806,6 +808,25 @@ static int pnp_ransac_impl(vslam_ctx* ctx, const float* xyz_w, const float* uv, 
 int vslam_pnp_ransac(vslam_ctx* ctx, const float* xyz_w, const float* uv, int n, double T_c_w[7], int max_iters, double reproj_err,
                      double confidence, int lm_iters, uint8_t* inlier, int* n_inliers, int* iters_run) {
     return pnp_ransac_impl(ctx, xyz_w, uv, n, T_c_w, max_iters, reproj_err, confidence, lm_iters, inlier, n_inliers, iters_run, nullptr, nullptr);
+}
+
+int vslam_pnp_ransac_dev(vslam_ctx* ctx, const float* d_xyz_w, const float* d_uv, const int32_t* d_n, int capacity, int B, double* d_T_c_w, int max_iters,
+                         double reproj_err, double confidence, uint8_t* d_inlier, int32_t* d_n_inliers, int32_t* d_iters_run) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !d_xyz_w || !d_uv || !d_n || !d_T_c_w || capacity <= 0 || B < 0 || max_iters <= 0 || max_iters > 4096 || !(reproj_err > 0)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
+    if (B == 0) return VSLAM_OK;
+    const size_t need = pnp_ransac_scratch_bytes(B, max_iters);
+    if (c->ransac_bytes < need) {
+        VS_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_ransac) { (void)hipFree(c->d_ransac); c->dev_bytes -= c->ransac_bytes; }
+        c->d_ransac = nullptr; c->ransac_bytes = 0;
+        if (hipMalloc((void**)&c->d_ransac, need) != hipSuccess) { c->d_ransac = nullptr; set_error("RANSAC scratch hipMalloc(%zu) failed", need); return VSLAM_ERR_HIP; }
+        c->ransac_bytes = need; c->dev_bytes += need;
+    }
+    double K[4];
+    fill_K(c, K);
+    return launch_pnp_ransac_batch(d_xyz_w, d_uv, d_n, capacity, B, max_iters, K, reproj_err, confidence, c->d_ransac, d_T_c_w, d_inlier, d_n_inliers, d_iters_run, c->stream);
 }
 
 // diagnostic form: additionally returns every hypothesis model ([R row-major | t], 12 doubles each) and its inlier count (-1: degenerate)

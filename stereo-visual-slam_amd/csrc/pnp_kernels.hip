@@ -216,9 +216,11 @@ __device__ inline void rotmat_to_quat(const double R[9], double q[4]) {
 // one wave (= one 64-thread workgroup) per hypothesis: hx / hu hold the 5 points of every subset (H x 5 x 3 f32, H x 5 x 2 f32)
 __global__ __launch_bounds__(64) void pnp_epnp_kernel(const float* __restrict__ hx, const float* __restrict__ hu, double fu, double fv, double uc, double vc,
                                                      double* __restrict__ Rt /* H x 12: R row-major, t */, double* __restrict__ T /* H x 7 */,
-                                                     int32_t* __restrict__ ok_out) {
+                                                     int32_t* __restrict__ ok_out, const int32_t* __restrict__ nh_of, int h_per) {
     __shared__ EpnpShared e;
     const int h = blockIdx.x, lane = threadIdx.x;
+    // batched form: problem h / h_per draws only nh_of[.] of its h_per hypothesis slots (0: fewer than 5 points, 1: exactly 5)
+    if (nh_of && (h % h_per) >= nh_of[h / h_per]) { if (lane == 0) ok_out[h] = 0; return; }
     const float* xyz = hx + (size_t)h * kMp * 3;
     const float* uv = hu + (size_t)h * kMp * 2;
     if (lane == 0) {
@@ -408,7 +410,179 @@ __global__ __launch_bounds__(256) void pnp_count_inliers_kernel(const float* __r
 int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[4], double* d_Rt, double* d_T, int32_t* d_ok, hipStream_t stream) {
     if (H <= 0) return VSLAM_OK;
     ProfScope prof__(stream, "pnp_epnp_kernel");
-    hipLaunchKernelGGL(pnp_epnp_kernel, dim3(H), dim3(64), 0, stream, d_hx, d_hu, K[0], K[1], K[2], K[3], d_Rt, d_T, d_ok);
+    hipLaunchKernelGGL(pnp_epnp_kernel, dim3(H), dim3(64), 0, stream, d_hx, d_hu, K[0], K[1], K[2], K[3], d_Rt, d_T, d_ok, (const int32_t*)nullptr, 1);
+    VS_HIP(hipGetLastError());
+    return VSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------- batched RANSAC pose (vslam_pnp_ransac_dev)
+// cv::solvePnPRansac(..., useExtrinsicGuess = false, 100, 4.0, 0.99) of VO::motion_estimation (visual_odometry.cpp:277) for B independent
+// problems whose points are already in device memory -- the reference's own pose stage in throughput mode.  Same restatement as the host
+// tier (api.hip pnp_ransac_impl, oracle/ransac.c): every problem draws the SAME cv::RNG sequence (seed -1) of 5-point subsets modulo its
+// own point count, all B x max_iters hypotheses are solved (EPnP, one wave each) and scored at once, and the sequential acceptance rule
+// with its adaptive stopping (RANSACUpdateNumIters) is replayed per problem over the counts.  Returns the best RANSAC model itself (OpenCV
+// 3.2.0, the reference's pinned version: the refined pose is discarded) and its inlier mask.
+__device__ inline unsigned cv_rng_next_dev(unsigned long long& state) {
+    state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);
+    return (unsigned)state;
+}
+// one lane per problem: the subset sequence (a chain of RNG draws: ~600 dependent multiply-adds) and the gather of its points
+__global__ __launch_bounds__(64) void pnp_ransac_subsets_kernel(const float* __restrict__ xyz, const float* __restrict__ uv, const int32_t* __restrict__ d_n,
+                                                               int capacity, int B, int H, float* __restrict__ hx, float* __restrict__ hu,
+                                                               int32_t* __restrict__ nh_of) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int n = min(max(d_n[b], 0), capacity);
+    const int nh = n < kMp ? 0 : (n == kMp ? 1 : H); // ptsetreg.cpp: count == modelPoints -> one model from all points
+    nh_of[b] = nh;
+    const float* px = xyz + 3 * (size_t)b * capacity;
+    const float* pu = uv + 2 * (size_t)b * capacity;
+    unsigned long long state = 0xFFFFFFFFFFFFFFFFULL;
+    for (int it = 0; it < nh; ++it) {
+        int idx[kMp];
+#pragma unroll
+        for (int i = 0; i < kMp; ++i) {
+            if (nh == 1) { idx[i] = i; continue; }
+            for (;;) {
+                const int v = (int)(cv_rng_next_dev(state) % (unsigned)n);
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < kMp; ++j) if (j < i && idx[j] == v) dup = true;
+                idx[i] = v;
+                if (!dup) break;
+            }
+        }
+        float* ox = hx + ((size_t)b * H + it) * kMp * 3;
+        float* ou = hu + ((size_t)b * H + it) * kMp * 2;
+#pragma unroll
+        for (int i = 0; i < kMp; ++i) {
+            ox[3 * i] = px[3 * idx[i]]; ox[3 * i + 1] = px[3 * idx[i] + 1]; ox[3 * i + 2] = px[3 * idx[i] + 2];
+            ou[2 * i] = pu[2 * idx[i]]; ou[2 * i + 1] = pu[2 * idx[i] + 1];
+        }
+    }
+}
+
+// PnPRansacCallback::computeError of one point under one model: f64 projection with one reciprocal, f32 squared error (the arithmetic of
+// pnp_count_inliers_kernel above, shared by the two batched kernels below)
+__device__ inline bool ransac_point_is_inlier(const double* sR, const float* xyz, const float* uv, int i, double fx, double fy, double cx, double cy, float thr2) {
+    const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+    double x = sR[0] * X + sR[1] * Y + sR[2] * Z + sR[9];
+    double y = sR[3] * X + sR[4] * Y + sR[5] * Z + sR[10];
+    double z = sR[6] * X + sR[7] * Y + sR[8] * Z + sR[11];
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    const float pu = (float)(x * fx + cx), pv = (float)(y * fy + cy);
+    const float du = uv[2 * i] - pu, dv = uv[2 * i + 1] - pv;
+    float err = 0.f;
+    err += du * du;
+    err += dv * dv;
+    return err <= thr2;
+}
+// block (h, b): inliers of problem b's points under its hypothesis h
+__global__ __launch_bounds__(128) void pnp_ransac_count_kernel(const float* __restrict__ xyz, const float* __restrict__ uv, const int32_t* __restrict__ d_n,
+                                                              int capacity, int H, const double* __restrict__ Rt, const int32_t* __restrict__ ok,
+                                                              double fx, double fy, double cx, double cy, float thr2, int32_t* __restrict__ counts) {
+    const int h = blockIdx.x, b = blockIdx.y, hyp = b * H + h;
+    __shared__ double sR[12];
+    __shared__ int cnt;
+    if (!ok[hyp]) { if (threadIdx.x == 0) counts[hyp] = 0; return; } // (uniform)
+    if (threadIdx.x < 12) sR[threadIdx.x] = Rt[(size_t)hyp * 12 + threadIdx.x];
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int n = min(max(d_n[b], 0), capacity);
+    const float* px = xyz + 3 * (size_t)b * capacity;
+    const float* pu = uv + 2 * (size_t)b * capacity;
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += 128) mine += ransac_point_is_inlier(sR, px, pu, i, fx, fy, cx, cy, thr2);
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[hyp] = cnt;
+}
+// cv::RANSACUpdateNumIters (ptsetreg.cpp)
+__device__ inline int ransac_update_num_iters_dev(double p, double ep, int model_points, int max_iters) {
+    p = fmin(fmax(p, 0.), 1.); ep = fmin(fmax(ep, 0.), 1.);
+    double num = fmax(1. - p, 2.2250738585072014e-308), denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = log(num); denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+}
+// block per problem: thread 0 replays the sequential loop over the counts (strict improvement, adaptive iteration count), then all
+// threads write the best model's inlier mask; pose = the best model (identity when no model was accepted)
+__global__ __launch_bounds__(128) void pnp_ransac_select_kernel(const float* __restrict__ xyz, const float* __restrict__ uv, const int32_t* __restrict__ d_n,
+                                                               int capacity, int H, const double* __restrict__ Rt, const double* __restrict__ hT,
+                                                               const int32_t* __restrict__ ok, const int32_t* __restrict__ counts,
+                                                               const int32_t* __restrict__ nh_of, double confidence, double fx, double fy, double cx,
+                                                               double cy, float thr2, double* __restrict__ T_out, uint8_t* __restrict__ inlier,
+                                                               int32_t* __restrict__ n_inl, int32_t* __restrict__ iters_run) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_best, s_good;
+    __shared__ double sR[12];
+    const int n = min(max(d_n[b], 0), capacity), nh = nh_of[b];
+    if (tid == 0) {
+        int best = -1, max_good = 0, it = 0;
+        if (nh == 1) { if (ok[(size_t)b * H]) { best = 0; max_good = n; } }
+        else {
+            int niters = nh;
+            for (it = 0; it < niters; ++it) {
+                const int hyp = b * H + it;
+                if (ok[hyp] && counts[hyp] > max(max_good, kMp - 1)) {
+                    best = it; max_good = counts[hyp];
+                    niters = ransac_update_num_iters_dev(confidence, (double)(n - max_good) / n, kMp, niters);
+                }
+            }
+        }
+        s_best = best; s_good = max_good;
+        if (iters_run) iters_run[b] = it;
+        if (n_inl) n_inl[b] = best >= 0 ? max_good : 0;
+    }
+    __syncthreads();
+    const int best = s_best;
+    uint8_t* m = inlier ? inlier + (size_t)b * capacity : nullptr;
+    if (best < 0) {
+        if (tid < 7) T_out[7 * (size_t)b + tid] = tid == 3 ? 1.0 : 0.0;
+        if (m) for (int i = tid; i < capacity; i += 128) m[i] = 0;
+        return;
+    }
+    const int hyp = b * H + best;
+    if (tid < 7) T_out[7 * (size_t)b + tid] = hT[(size_t)hyp * 7 + tid];
+    if (!m) return;
+    if (tid < 12) sR[tid] = Rt[(size_t)hyp * 12 + tid];
+    __syncthreads();
+    const float* px = xyz + 3 * (size_t)b * capacity;
+    const float* pu = uv + 2 * (size_t)b * capacity;
+    for (int i = tid; i < capacity; i += 128)
+        m[i] = i < n ? (nh == 1 ? (uint8_t)1 : (uint8_t)ransac_point_is_inlier(sR, px, pu, i, fx, fy, cx, cy, thr2)) : (uint8_t)0;
+}
+
+size_t pnp_ransac_scratch_bytes(int B, int H) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t nh = (size_t)B * H;
+    return al(nh * kMp * 3 * 4) + al(nh * kMp * 2 * 4) + al(nh * 12 * 8) + al(nh * 7 * 8) + 2 * al(nh * 4) + al((size_t)B * 4);
+}
+
+int launch_pnp_ransac_batch(const float* d_xyz, const float* d_uv, const int32_t* d_n, int capacity, int B, int H, const double K[4], double reproj_err,
+                            double confidence, uint8_t* scratch, double* d_T, uint8_t* d_inlier, int32_t* d_n_inl, int32_t* d_iters, hipStream_t stream) {
+    if (B <= 0) return VSLAM_OK;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t nh = (size_t)B * H;
+    float* hx = (float*)scratch; scratch += al(nh * kMp * 3 * 4);
+    float* hu = (float*)scratch; scratch += al(nh * kMp * 2 * 4);
+    double* Rt = (double*)scratch; scratch += al(nh * 12 * 8);
+    double* hT = (double*)scratch; scratch += al(nh * 7 * 8);
+    int32_t* ok = (int32_t*)scratch; scratch += al(nh * 4);
+    int32_t* cnt = (int32_t*)scratch; scratch += al(nh * 4);
+    int32_t* nh_of = (int32_t*)scratch;
+    const float thr2 = (float)(reproj_err * reproj_err);
+    { ProfScope p(stream, "pnp_ransac_subsets_kernel");
+      hipLaunchKernelGGL(pnp_ransac_subsets_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_xyz, d_uv, d_n, capacity, B, H, hx, hu, nh_of); }
+    { ProfScope p(stream, "pnp_epnp_kernel");
+      hipLaunchKernelGGL(pnp_epnp_kernel, dim3((unsigned)nh), dim3(64), 0, stream, hx, hu, K[0], K[1], K[2], K[3], Rt, hT, ok, nh_of, H); }
+    { ProfScope p(stream, "pnp_ransac_count_kernel");
+      hipLaunchKernelGGL(pnp_ransac_count_kernel, dim3(H, B), dim3(128), 0, stream, d_xyz, d_uv, d_n, capacity, H, Rt, ok, K[0], K[1], K[2], K[3], thr2, cnt); }
+    { ProfScope p(stream, "pnp_ransac_select_kernel");
+      hipLaunchKernelGGL(pnp_ransac_select_kernel, dim3(B), dim3(128), 0, stream, d_xyz, d_uv, d_n, capacity, H, Rt, hT, ok, cnt, nh_of, confidence, K[0], K[1], K[2],
+                         K[3], thr2, d_T, d_inlier, d_n_inl, d_iters); }
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }

@@ -229,6 +229,9 @@ int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[
 int launch_pnp_count_inliers(const float* d_xyz, const float* d_uv, int n, const double* d_Rt, const int32_t* d_ok, int hyp0, int n_hyp, const double K[4],
                              double reproj_thr, int32_t* d_counts, uint8_t* d_mask, hipStream_t stream);
 
+size_t pnp_ransac_scratch_bytes(int B, int H);
+int launch_pnp_ransac_batch(const float* d_xyz, const float* d_uv, const int32_t* d_n, int capacity, int B, int H, const double K[4], double reproj_err,
+                            double confidence, uint8_t* scratch, double* d_T, uint8_t* d_inlier, int32_t* d_n_inl, int32_t* d_iters, hipStream_t stream);
 // track_kernels.hip: BA windows of a batch of consecutive keyframes from the front end's device-resident output
 size_t track_scratch_bytes(int B, int kp_cap, int lm_capacity);
 int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, uint8_t* scratch, int32_t* d_lm_off,
@@ -251,6 +254,7 @@ struct Ctx {
     uint8_t* h_pinned; size_t pinned_bytes;
     // SGBM working set (cost volumes; grown on demand by vslam_disparity_map*)
     uint8_t* d_sgbm; size_t sgbm_bytes;
+    uint8_t* d_ransac; size_t ransac_bytes; // hypothesis tables of vslam_pnp_ransac_dev (grown on demand)
     uint8_t* d_track; size_t track_bytes; // chain tables of vslam_build_windows_dev (grown on demand)
     LmScratch lm;
     Tuning tune;

@@ -24,7 +24,7 @@ from . import synth
 class KeyframePipeline:
     def __init__(self, B, device=0, anms_num=1500, n_lm=3000, n_kf=10, unique_frames=64, unique_windows=None, seed=0, verbose=False,
                  with_ba=True, depth="match", frame_range=None, render_workers=0, sequence=None, ba_windows="synthetic",
-                 lm_per_window=6144, edges_per_window=8192):
+                 lm_per_window=None, edges_per_window=None, pose="lm"):
         """depth = "match": north_star stage (right-image ORB, L/R match, DLT); "sgbm": the reference's own depth path
         (VO::disparity_map + Frame::find_3d on the left keypoints; the right image is only consumed by SGBM).
         Inputs: ONE rendered sequence of `unique_frames` consecutive stereo keyframes, laid over the batch as a ping-pong
@@ -32,8 +32,9 @@ class KeyframePipeline:
         scene (driving the sequence backwards is as valid a frame-to-frame pair as driving it forwards); `unique_windows` BA
         windows (default: one per batch item).  frame_range = (first, last + 1, F): sequence mode -- the batch is the contiguous
         chunk [first, last] of an F-frame sequence (frame f shows ping-pong frame f of the SAME rendered scene on every rank)."""
-        assert depth in ("match", "sgbm") and ba_windows in ("synthetic", "tracks")
+        assert depth in ("match", "sgbm") and ba_windows in ("synthetic", "tracks") and pose in ("lm", "ransac")
         self.depth = depth
+        self.pose = pose   # "lm": north_star motion-only LM; "ransac": the reference's cv::solvePnPRansac(..., 100, 4.0, 0.99) (visual_odometry.cpp:277)
         self.ba_windows = ba_windows
         self.B = B
         self.dev = torch.device("cuda", device)
@@ -68,6 +69,7 @@ class KeyframePipeline:
             imgs[b, :, :self.w] = L
             imgs[B + b, :, :self.w] = R
         self.unique_frames = n_u
+        self.h_seq = seq   # (kept: a second pipeline over the same frames needs no second rendering)
         self.h_imgs = imgs
         self.h_imgs_unique_left = np.stack([np.pad(f[0], ((0, 0), (0, self.pitch - self.w))) for f in seq])
         self.h_imgs_unique_right = np.stack([np.pad(f[1], ((0, 0), (0, self.pitch - self.w))) for f in seq])
@@ -106,6 +108,11 @@ class KeyframePipeline:
         # ---- local-BA windows built on the device from this step's tracks (vslam_build_windows_dev)
         if with_ba and ba_windows == "tracks":
             self.n_kf = n_kf
+            # capacities of the concatenated window arrays: L/R match + DLT gives ~1/3 of the keypoints a depth, the disparity map nearly all
+            if lm_per_window is None:
+                lm_per_window = n_kf * anms_num if depth == "sgbm" else max(4 * n_kf * anms_num // 10, 1024)
+            if edges_per_window is None:
+                edges_per_window = lm_per_window + lm_per_window // 3
             self.lm_capacity, self.edge_capacity = B * lm_per_window, B * edges_per_window
             self.ba_T = torch.zeros((B, n_kf, 7), dtype=torch.float64, device=d)
             self.ba_xyz = torch.zeros((self.lm_capacity, 3), dtype=torch.float32, device=d)
@@ -211,6 +218,10 @@ class KeyframePipeline:
         vo.build_pnp_inputs_dev(self.d_f2f.data_ptr(), self.d_nf2f.data_ptr(), cap, self.d_lr.data_ptr(), self.d_nlr.data_ptr(), cap,
                                 self.d_xyz.data_ptr(), self.d_valid.data_ptr(), self.d_kps.data_ptr() + cap * 28, cap, n, self.d_kp2lr.data_ptr(),
                                 self.d_pxyz.data_ptr(), self.d_puv.data_ptr(), self.d_pn.data_ptr(), cap)
+        if self.pose == "ransac":   # no pose guess is consumed (useExtrinsicGuess = false)
+            vo.pnp_ransac_dev(self.d_pxyz.data_ptr(), self.d_puv.data_ptr(), self.d_pn.data_ptr(), cap, n, self.d_Tpnp.data_ptr(), 100, 4.0, 0.99,
+                              self.d_inl.data_ptr(), self.d_ninl.data_ptr(), None)
+            return
         with torch.cuda.stream(self.stream):
             self.d_Tpnp.copy_(self.d_Tident)
         vo.motion_estimation_dev(self.d_pxyz.data_ptr(), self.d_puv.data_ptr(), self.d_pn.data_ptr(), cap, n, self.d_Tpnp.data_ptr(), 10,

@@ -196,3 +196,46 @@ def test_schedule_pose_only_wave_vs_window_kernel(pkg, synth):
         assert not np.allclose(Ta, np.stack([w["T0"] for w in wins]))   # the schedule moved the poses
     finally:
         ctx.close()
+
+
+def test_pnp_ransac_dev_batch_parity(pkg, oracle, synth):
+    """vslam_pnp_ransac_dev: B problems of different sizes in one call (incl. exactly 5 points, fewer than 5, heavy outliers) against
+    oracle/ransac.c problem by problem: iterations run, inlier count and mask identical, the returned model bit-identical up to the quaternion
+    conversion (cv::solvePnPRansac(..., 100, 4.0, 0.99), visual_odometry.cpp:277; OpenCV 3.2.0 return value: the best RANSAC model)"""
+    import torch
+    cases = [(400, 0.35, 9), (120, 0.15, 3), (60, 0.0, 2), (900, 0.5, 7), (6, 0.0, 4), (5, 0.0, 5), (37, 0.6, 11), (3, 0.0, 6), (257, 0.45, 75512239), (0, 0.0, 1)]
+    cap, B = 1024, len(cases)
+    xyz = np.zeros((B, cap, 3), np.float32); uv = np.zeros((B, cap, 2), np.float32); n = np.zeros(B, np.int32)
+    probs = []
+    for b, (M, outl, seed) in enumerate(cases):
+        if M > 0:
+            p = synth.pnp_problem(M=M, seed=seed, outlier_frac=outl, sigma_px=0.4)
+            xyz[b, :M] = p["xyz"]; uv[b, :M] = p["uv"]
+            probs.append(p)
+        else:
+            probs.append(None)
+        n[b] = M
+    ctx = pkg.VO(device=0, max_batch=1)
+    try:
+        d_xyz, d_uv, d_n = (torch.from_numpy(a).cuda() for a in (xyz, uv, n))
+        d_T = torch.zeros((B, 7), dtype=torch.float64, device="cuda"); d_inl = torch.full((B, cap), 7, dtype=torch.uint8, device="cuda")
+        d_ninl = torch.zeros(B, dtype=torch.int32, device="cuda"); d_it = torch.zeros(B, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(2):   # twice: the scratch is reused
+            ctx.pnp_ransac_dev(d_xyz.data_ptr(), d_uv.data_ptr(), d_n.data_ptr(), cap, B, d_T.data_ptr(), 100, 4.0, 0.99, d_inl.data_ptr(), d_ninl.data_ptr(), d_it.data_ptr())
+            ctx.sync()
+        T, inl, ninl, it = d_T.cpu().numpy(), d_inl.cpu().numpy(), d_ninl.cpu().numpy(), d_it.cpu().numpy()
+        for b, (M, outl, seed) in enumerate(cases):
+            if M < 5:
+                assert ninl[b] == 0 and (inl[b] == 0).all() and np.array_equal(T[b], [0, 0, 0, 1, 0, 0, 0])
+                continue
+            wT, winl, wn, wit = oracle.pnp_ransac(probs[b]["xyz"], probs[b]["uv"], lm_iters=0)
+            assert it[b] == wit and ninl[b] == wn, (b, it[b], wit, ninl[b], wn)
+            assert np.array_equal(inl[b][:M], winl) and (inl[b][M:] == 0).all()
+            if wn > 0:
+                assert np.allclose(T[b], wT, rtol=1e-12, atol=1e-14), b
+            # and the host-buffer call of the same library gives the same answer
+            hT, hinl, hn, hit = ctx.motion_estimation_ransac(probs[b]["xyz"], probs[b]["uv"], lm_iters=0)
+            assert hit == it[b] and hn == ninl[b] and np.array_equal(hinl, winl) and np.array_equal(hT, T[b])
+    finally:
+        ctx.close()

@@ -73,12 +73,14 @@ def test_pipeline_matches_oracle_composite(oracle, synth, B, anms, n_lm):
         pipe.close()
 
 
-def test_pipeline_sgbm_depth_matches_oracle_composite(oracle, synth):
+@pytest.mark.parametrize("pose", ["lm", "ransac"])
+def test_pipeline_sgbm_depth_matches_oracle_composite(oracle, synth, pose):
     """throughput pipeline with the reference's own depth path: batched SGBM + Frame::find_3d on the left keypoints, then the
-    frame-to-frame stage on those landmarks (visual_odometry.cpp:159-217, :253-314)"""
+    frame-to-frame stage on those landmarks (visual_odometry.cpp:159-217, :253-314); pose = "ransac": with the reference's own pose
+    stage too, cv::solvePnPRansac(..., 100, 4.0, 0.99) batched on the device (vslam_pnp_ransac_dev, :277) -- the REFERENCE pipeline"""
     from stereo_visual_slam_amd.pipeline import KeyframePipeline
     B, anms = 3, 500
-    pipe = KeyframePipeline(B, anms_num=anms, unique_frames=B, seed=4, with_ba=False, depth="sgbm")
+    pipe = KeyframePipeline(B, anms_num=anms, unique_frames=B, seed=4, with_ba=False, depth="sgbm", pose=pose)
     try:
         pipe.step()
         out = pipe.download()
@@ -106,6 +108,11 @@ def test_pipeline_sgbm_depth_matches_oracle_composite(oracle, synth):
                 assert out["pn"][i] == okm.sum()
                 p3 = pxyz[f["queryIdx"][okm]]; p2 = np.stack([kL["x"][f["trainIdx"][okm]], kL["y"][f["trainIdx"][okm]]], 1)
                 assert np.allclose(out["pxyz"][i][:okm.sum()], p3, rtol=1e-4, atol=1e-5) and np.array_equal(out["puv"][i][:okm.sum()], p2)
+                if pose == "ransac":   # on the GPU's own (f32, 1e-4-equal) points: the discrete outputs of RANSAC are not continuous in them
+                    g3 = out["pxyz"][i][:okm.sum()]
+                    wT, winl, wn, wit = oracle.pnp_ransac(g3, p2, lm_iters=0)
+                    assert out["ninl"][i] == wn and np.array_equal(out["inl"][i][:okm.sum()], winl)
+                    assert np.allclose(out["Tpnp"][i], wT, rtol=1e-9, atol=1e-12) and wn > 30
             prev = (kL, dL, xyz, valid)
     finally:
         pipe.close()
