@@ -782,12 +782,21 @@ def main():
             info, have_cv2 = host_info()
             res["cpu_baseline"]["host"] = info
             if have_cv2:
+                try:   # ... and, the day a box has OpenCV, the oracle is compared with it (tests/test_reference_libs_pin.py) and the outcome recorded here
+                    sys.path.insert(0, os.path.join(ROOT, "tests"))
+                    import oracle as O
+                    from stereo_visual_slam_amd import synth as S
+                    from test_reference_libs_pin import compare_all
+                    res["cpu_baseline"]["host"]["reference_libs_pin"] = compare_all(O, S, n_images=2)
+                except Exception as e:
+                    res["cpu_baseline"]["host"]["reference_libs_pin"] = "cv2 present but the comparison failed: %r" % (e,)
                 try:
                     res["cpu_baseline"]["reference_libs_timing"] = reference_lib_timing(pipe, args.anms)
                 except Exception as e:
                     res["cpu_baseline"]["reference_libs_timing"] = "cv2 present but failed: %r" % (e,)
             else:
                 res["cpu_baseline"]["reference_libs_timing"] = "unavailable on this host (no cv2 / OpenCV / g2o found at run time)"
+                res["cpu_baseline"]["host"]["reference_libs_pin"] = "skipped: no cv2 on this host (tests/test_reference_libs_pin.py)"
         print(json.dumps(res), flush=True)
     if pipe.vo.h:
         pipe.close()
