@@ -68,7 +68,7 @@ constexpr int kMaxNp = 6 * kMaxKf;
 constexpr int kMaxPairs = kMaxKf * (kMaxKf + 1) / 2;
 constexpr int kHitsPerEdge = (kMaxKf + 1) / 2 + 1;
 #ifndef VSLAM_LM_DINV_LDS
-#define VSLAM_LM_DINV_LDS 2000
+#define VSLAM_LM_DINV_LDS 1950
 #endif
 constexpr int kDinvLds = VSLAM_LM_DINV_LDS;  // landmarks whose Dinv stays in LDS (48 B each: the 96 KB the static state leaves free)
 constexpr int kLin = 2;        // doubles per edge of linearisation scratch: the Huber weight at the current state / at the trial state
@@ -78,6 +78,7 @@ constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work 
 #ifndef VSLAM_LM_SLOTS
 #define VSLAM_LM_SLOTS 5
 #endif
+constexpr int kDbgSlots = 24;               // phase cycle counters per window (VSLAM_LM_PROFILE)
 constexpr int kLmSlots = VSLAM_LM_SLOTS;    // observations per landmark kept in the slot table (the rest is reached through the CSR)
 
 size_t lm_hits_per_edge() { return kHitsPerEdge; }
@@ -87,6 +88,7 @@ struct alignas(16) LmShared {
     double Hpp[kMaxKf * 36], HppT[kMaxKf * 36]; // pose blocks at the current state / at the state of the latest trial
     double bp[kMaxNp], bpT[kMaxNp], bs[kMaxNp], xp[kMaxNp];
     double rdiag[kMaxNp];                       // 1 / L_ii of the reduced system's Cholesky factor (the solves multiply)
+    double Ld[kMaxKf * 24];                     // the factored diagonal blocks L_JJ (lower triangle, 21 of 24 slots each): read by the backward substitution only
     double Rt[kMaxKf * 12], RtTrial[kMaxKf * 12];
     double T[kMaxKf * 7], TTrial[kMaxKf * 7];
     double red[kLmWaves * 2];
@@ -467,9 +469,10 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const int npairs = nk * (nk + 1) / 2;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int slot27 = wave_slot<27>(lane), slot36 = wave_slot<36>(lane); // which butterfly sum this lane ends up holding
-    long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + 16 * (size_t)w : nullptr;
+    long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + kDbgSlots * (size_t)w : nullptr;
     long long t_ph = cyc ? clock64() : 0;
-#define PH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); cyc[i] += t1__ - t_ph; t_ph = t1__; } } while (0)
+    // (a fire-and-forget atomic: `cyc[i] += ...` made thread 0 wait a global round trip per marker, which the NEXT phase was then charged with)
+#define PH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); atomicAdd(reinterpret_cast<unsigned long long*>(cyc) + (i), (unsigned long long)(t1__ - t_ph)); t_ph = t1__; } } while (0)
     // component-major (SoA) scratch: consecutive lanes touch consecutive addresses in every edge- or landmark-ordered loop.
     // The only per-edge linearisation state that is STORED is the Huber weight (8 B, keyframe-major): the camera-frame point
     // is re-derived from the landmark wherever it is needed -- the kernel is bound by the bytes it streams, and a stored 32-B
@@ -1172,29 +1175,16 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 }
                 __syncthreads();
                 PH(6);
-                // Cholesky S = L L^T, left-looking over 6x6 block columns (np = 6 nk): 3 barriers per block column
+                // Cholesky S = L L^T, RIGHT-looking over 6x6 block columns (np = 6 nk), two barriers per block column:
+                //   P1  every lane that owns a row of the panel below block (J, J) factors the 6x6 diagonal block in registers (redundantly:
+                //       cheaper than one lane + a broadcast) and solves its row against it, in place; the right-hand side rides along as one
+                //       more row (L y = b is solved by the factorisation itself: only the backward substitution is left afterwards)
+                //   P2  the trailing blocks (I, K), J < K <= I, take  -= X_I X_K^T  with one lane per block ROW: 6 outputs from 6 + 36 operands.
+                // The left-looking form it replaces recomputed every element of a block column as a dot product over all earlier columns with one
+                // lane per ELEMENT: 2 LDS operands per FMA, and its column update was bound by LDS bandwidth (in-kernel clocks, per block column:
+                // update 1.84 k cycles, diagonal + rows 2.4 k, barriers 0.55 k).  L_JJ goes to a side array (Ld): nothing reads it before the solve.
                 for (int J = 0; J < nk && ok2; ++J) {
-                    // (1) block column J -= L[.,0..J) L[J,0..J)^T   -- one lane per element of the (nk-J) x 1 block column
-                    const int nel = (nk - J) * 36;
-                    for (int t = tid; t < nel; t += kLmBlock) {
-                        const int I = J + t / 36, r = (t % 36) / 6, c = t % 6;
-                        double v = sm.S[(6 * I + r) * np + 6 * J + c];
-                        v = row_dot_sub(v, &sm.S[(6 * I + r) * np], &sm.S[(6 * J + c) * np], J);
-                        sm.S[(6 * I + r) * np + 6 * J + c] = v;
-                    }
-                    // the right-hand side rides along as one more row of the matrix: L y = bs is solved by the factorisation
-                    // itself (in place in bs), so only the backward substitution is left afterwards
-                    if (tid >= kLmBlock - 6) {
-                        const int c = tid - (kLmBlock - 6);
-                        double v = sm.bs[6 * J + c];
-                        v = row_dot_sub(v, &sm.bs[0], &sm.S[(6 * J + c) * np], J);
-                        sm.bs[6 * J + c] = v;
-                    }
-                    __syncthreads();
-                    // (2) every lane that owns a row below (lane 0, which stores L_JJ, and the last lane, which owns the
-                    //     right-hand-side row) factors the 6x6 diagonal block in registers (redundantly: cheaper than a serial
-                    //     thread + barrier), then solves its row against it
-                    const int nrows = (nk - J - 1) * 6;
+                    const int m = nk - J - 1, nrows = m * 6;
                     const bool rhs_row = tid == kLmBlock - 1;
                     if (tid < nrows || tid == 0 || rhs_row) {
                         double D[21]; // lower triangle, row-major: (i,j) -> i*(i+1)/2 + j
@@ -1220,9 +1210,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 D[i * (i + 1) / 2 + j] = v * rd[j];
                             }
                         }
-                        double x[6];
-                        double* rowv = rhs_row ? &sm.bs[6 * J] : &sm.S[(6 * (J + 1) + tid) * np + 6 * J];
                         if (tid < nrows || rhs_row) {
+                            double* rowv = rhs_row ? &sm.bs[6 * J] : &sm.S[(6 * (J + 1) + tid) * np + 6 * J];
+                            double x[6];
 #pragma unroll
                             for (int c = 0; c < 6; ++c) {
                                 double v = rowv[c];
@@ -1230,74 +1220,93 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                 for (int kk = 0; kk < c; ++kk) v -= x[kk] * D[c * (c + 1) / 2 + kk];
                                 x[c] = v * rd[c];
                             }
-                        }
-                        if (tid == 0 && !good) sm.flag[1] = 1;
-                        if (tid < nrows || rhs_row)
 #pragma unroll
                             for (int c = 0; c < 6; ++c) rowv[c] = x[c];
-                        // L_JJ is written only after the barrier below: other waves may still be reading the unfactored block
+                        }
                         if (tid == 0) {
+                            if (!good) sm.flag[1] = 1;
 #pragma unroll
-                            for (int i = 0; i < 21; ++i) sm.xp[i] = D[i]; // parked in xp (free until the solves)
+                            for (int i = 0; i < 21; ++i) sm.Ld[24 * J + i] = D[i];
 #pragma unroll
                             for (int i = 0; i < 6; ++i) sm.rdiag[6 * J + i] = rd[i];
                         }
                     }
+                    PH(16);
                     __syncthreads();
-                    if (tid < 21) { // unpack the parked lower triangle into S (J,J)
-                        int i = 0, rem = tid;
-                        while (rem > i) { rem -= i + 1; ++i; }
-                        sm.S[(6 * J + i) * np + 6 * J + rem] = sm.xp[tid];
-                    }
+                    PH(17);
                     if (sm.flag[1]) { ok2 = false; break; } // uniform
+                    // P2: trailing update.  Items: (block pair (a, b), a >= b, of the m block rows below; row r) and, for the right-hand side, one
+                    // item per block b
+                    const int npair = m * (m + 1) / 2, nitem = npair * 6 + m;
+                    for (int t = tid; t < nitem; t += kLmBlock) {
+                        const double* xi; double* out; int Kb;
+                        if (t < npair * 6) {
+                            const int pr = t / 6, r = t - 6 * pr;
+                            int a = 0, rem = pr;
+                            while (rem > a) { rem -= a + 1; ++a; }
+                            const int Ib = J + 1 + a; Kb = J + 1 + rem;
+                            xi = &sm.S[(6 * Ib + r) * np + 6 * J]; out = &sm.S[(6 * Ib + r) * np + 6 * Kb];
+                        } else { Kb = J + 1 + (t - npair * 6); xi = &sm.bs[6 * J]; out = &sm.bs[6 * Kb]; }
+                        const double2* xi2 = reinterpret_cast<const double2*>(xi);
+                        const double2 a0 = xi2[0], a1 = xi2[1], a2 = xi2[2];
+                        double2* o2 = reinterpret_cast<double2*>(out);
+                        double2 o[3] = {o2[0], o2[1], o2[2]};
+                        double v[6] = {o[0].x, o[0].y, o[1].x, o[1].y, o[2].x, o[2].y};
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            const double2* xk = reinterpret_cast<const double2*>(&sm.S[(6 * Kb + c) * np + 6 * J]);
+                            const double2 b0 = xk[0], b1 = xk[1], b2 = xk[2];
+                            v[c] -= (a0.x * b0.x + a0.y * b0.y) + (a1.x * b1.x + a1.y * b1.y) + (a2.x * b2.x + a2.y * b2.y);
+                        }
+                        o2[0] = make_double2(v[0], v[1]); o2[1] = make_double2(v[2], v[3]); o2[2] = make_double2(v[4], v[5]);
+                    }
+                    PH(18);
+                    __syncthreads();
+                    PH(19);
                 }
                 PH(7);
                 if (sm.flag[1]) ok2 = false;
                 __syncthreads();
+                PH(20);
                 if (tid == 0) sm.flag[1] = 0;
                 if (ok2) {
-                    // backward substitution L^T x = y by wave 0 with the unknowns in registers: lane i owns u_i = x_i-in-progress
-                    // scaled by 1/L_ii (and u_{i+64}: np <= 128), so a step is readlane(u, r) -> one FMA with the pre-scaled row
-                    // of L (zero on and above the diagonal: finished unknowns stay put, no select).  The rows a block needs are
-                    // fetched and scaled while the previous block resolves.
+                    // backward substitution L^T x = y by wave 0, block by block from the last: lane i carries t_i = y_i - sum over the finished
+                    // unknowns (and t_{i+64}: np <= 128).  Per block: its six right-hand sides go to every lane (readlane), every lane solves the
+                    // 6x6 triangle L_JJ^T x = t redundantly (L_JJ from the side array, wave-uniform reads), and the unknowns below take
+                    // t_i -= sum_c L[6J+c][i] x_c with the six rows of L read along i (consecutive lanes, consecutive addresses).
                     if (wave == 0) {
-                        const double rd0 = lane < np ? sm.rdiag[lane] : 0.0, rd1 = lane + 64 < np ? sm.rdiag[lane + 64] : 0.0;
-                        double u0 = lane < np ? sm.bs[lane] * rd0 : 0.0, u1 = lane + 64 < np ? sm.bs[lane + 64] * rd1 : 0.0;
-                        double Ln0[6], Ln1[6];
-                        auto fetch_rows = [&](int J) {
+                        double u0 = lane < np ? sm.bs[lane] : 0.0, u1 = lane + 64 < np ? sm.bs[lane + 64] : 0.0;
+                        for (int J = nk - 1; J >= 0; --J) {
+                            double Lr0[6], Lr1[6], Ld[21], rdj[6], t[6], x[6];
 #pragma unroll
                             for (int c = 0; c < 6; ++c) {
                                 const int r = 6 * J + c;
-                                Ln0[c] = lane < r ? -sm.S[r * np + lane] * rd0 : 0.0;
-                                Ln1[c] = (r > 64 && lane + 64 < r) ? -sm.S[r * np + lane + 64] * rd1 : 0.0;
+                                Lr0[c] = lane < 6 * J ? sm.S[r * np + lane] : 0.0;
+                                Lr1[c] = (6 * J > 64 && lane + 64 < 6 * J) ? sm.S[r * np + lane + 64] : 0.0;
+                                rdj[c] = sm.rdiag[r];
                             }
-                        };
-                        fetch_rows(nk - 1);
-                        int J = nk - 1;
-                        for (; 6 * J + 5 >= 64; --J) { // unknowns 64.. live in u1 (only windows of more than 10 keyframes)
-                            double L0[6], L1[6];
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) { L0[c] = Ln0[c]; L1[c] = Ln1[c]; }
-                            fetch_rows(J - 1);
+                            for (int i = 0; i < 21; ++i) Ld[i] = sm.Ld[24 * J + i];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) {
+                                const int r = 6 * J + c; // wave-uniform
+                                t[c] = r >= 64 ? readlane_f64(u1, r - 64) : readlane_f64(u0, r);
+                            }
 #pragma unroll
                             for (int c = 5; c >= 0; --c) {
-                                const int r = 6 * J + c; // wave-uniform
-                                const double xr = r >= 64 ? readlane_f64(u1, r - 64) : readlane_f64(u0, r);
-                                u1 = fma(L1[c], xr, u1);
-                                u0 = fma(L0[c], xr, u0);
+                                double v = t[c];
+#pragma unroll
+                                for (int k = c + 1; k < 6; ++k) v -= Ld[k * (k + 1) / 2 + c] * x[k];
+                                x[c] = v * rdj[c];
                             }
-                        }
-                        for (; J >= 0; --J) {
-                            double L0[6];
+                            if (lane == 0)
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) L0[c] = Ln0[c];
-                            if (J > 0) fetch_rows(J - 1);
+                                for (int c = 0; c < 6; ++c) sm.xp[6 * J + c] = x[c];
 #pragma unroll
-                            for (int c = 5; c >= 0; --c) u0 = fma(L0[c], readlane_f64(u0, 6 * J + c), u0);
+                            for (int c = 0; c < 6; ++c) { u0 = fma(-Lr0[c], x[c], u0); u1 = fma(-Lr1[c], x[c], u1); }
                         }
-                        if (lane < np) sm.xp[lane] = u0;
-                        if (lane + 64 < np) sm.xp[lane + 64] = u1;
                     }
+                    PH(21);
                 } else {
                     for (int i = tid; i < np; i += kLmBlock) sm.xp[i] = 0;
                 }
@@ -1679,7 +1688,7 @@ __global__ __launch_bounds__(kPoBlock) void pose_only_wave_kernel(LmKernelArgs k
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (ka.status[w] != VSLAM_OK) return; // uniform: the first pass of the schedule rejected this window
-    long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + 16 * (size_t)w : nullptr; // tuning aid (VSLAM_LM_PROFILE=1): slots 0..6 of this pass
+    long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + kDbgSlots * (size_t)w : nullptr; // tuning aid (VSLAM_LM_PROFILE=1): slots 0..8 of this pass
     long long t_ph = cyc ? clock64() : 0;
 #define POH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); cyc[i] += t1__ - t_ph; t_ph = t1__; } } while (0)
     const int nk = a.n_kf_w ? min(max(a.n_kf_w[w], 1), a.n_kf) : a.n_kf; // (a.n_kf: the pose stride)
@@ -2041,8 +2050,8 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     }
     static long long* d_cyc = nullptr; static int cyc_n = 0;
     if (getenv("VSLAM_LM_PROFILE")) {
-        if (cyc_n < a.n_windows) { if (d_cyc) hipFree(d_cyc); hipMalloc((void**)&d_cyc, sizeof(long long) * 16 * a.n_windows); cyc_n = a.n_windows; }
-        hipMemsetAsync(d_cyc, 0, sizeof(long long) * 16 * a.n_windows, stream);
+        if (cyc_n < a.n_windows) { if (d_cyc) hipFree(d_cyc); hipMalloc((void**)&d_cyc, sizeof(long long) * kDbgSlots * a.n_windows); cyc_n = a.n_windows; }
+        hipMemsetAsync(d_cyc, 0, sizeof(long long) * kDbgSlots * a.n_windows, stream);
         ka.dbg_cycles = d_cyc;
     }
     int rc = carve(*scratch, ka, total_lm, total_edge, a.n_windows, true, stream);
@@ -2057,7 +2066,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         const bool po_window = scratch->tune && scratch->tune->pose_only_window > 0;
         if (po_window) hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1);
         else {
-            if (ka.dbg_cycles && getenv("VSLAM_PO_PROFILE")) hipMemsetAsync(ka.dbg_cycles, 0, sizeof(long long) * 16 * a.n_windows, stream); // show only this pass
+            if (ka.dbg_cycles && getenv("VSLAM_PO_PROFILE")) hipMemsetAsync(ka.dbg_cycles, 0, sizeof(long long) * kDbgSlots * a.n_windows, stream); // show only this pass
             hipLaunchKernelGGL(pose_only_wave_kernel, dim3(a.n_windows), dim3(kPoBlock), 0, stream, ka, 10, 1);
         }
     } else {
@@ -2066,11 +2075,12 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     VS_HIP(hipGetLastError());
     if (ka.dbg_cycles) {
         hipStreamSynchronize(stream);
-        std::vector<long long> h(16 * (size_t)a.n_windows);
+        std::vector<long long> h(kDbgSlots * (size_t)a.n_windows);
         hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        static const char* names[16] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky", "solve", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(probe slot, unused)"};
+        static const char* names[kDbgSlots] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky (rest)", "solve (rest)", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(probe slot, unused)",
+                                               "chol: diag+rows", "chol: barrier 1", "chol: trailing update", "chol: barrier 2", "solve: barrier", "solve: back-subst", "-", "-"};
         double tot = 0;
-        for (int i = 0; i < 16; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[16 * (size_t)w + i]; s /= a.n_windows; if (i < 13) tot += s; fprintf(stderr, "  [lm profile] %-14s %10.0f ticks/window\n", names[i], s); }
+        for (int i = 0; i < kDbgSlots; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[kDbgSlots * (size_t)w + i]; s /= a.n_windows; if (i < 13 || i >= 16) tot += s; fprintf(stderr, "  [lm profile] %-20s %10.0f ticks/window\n", names[i], s); }
         fprintf(stderr, "  [lm profile] total %.0f cycles (clock64 = shader clock, thread 0 of every window; setup sub-splits not included)\n", tot);
     }
     return VSLAM_OK;
