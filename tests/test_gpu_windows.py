@@ -102,3 +102,85 @@ def test_ba_schedule_on_built_windows_matches_oracle(oracle, synth):
                 assert not np.allclose(done["ba_T"][b][:nk], built["ba_T"][b][:nk], atol=1e-9)   # the BA moved the poses
     finally:
         pipe.close()
+
+
+def _random_tracks(rng, F, cap, n_kp_max):
+    """random front-end results with the invariants the real stages guarantee: an association list has distinct keypoints, a frame-to-frame
+    match list is one-to-one (cross-checked), everything else -- counts, depth flags, inlier flags, poses -- is arbitrary"""
+    import oracle as O
+    kps = np.zeros((F, cap), O.KEYPOINT_DTYPE); nk = rng.integers(1, n_kp_max + 1, F)
+    for f in range(F):
+        kps["x"][f, :nk[f]] = rng.uniform(0, 1241, nk[f]).astype(np.float32); kps["y"][f, :nk[f]] = rng.uniform(0, 376, nk[f]).astype(np.float32)
+    lr = np.zeros((F, cap), O.DMATCH_DTYPE); nlr = np.zeros(F, np.int32)
+    xyz = rng.uniform(-20, 20, (F, cap, 3)).astype(np.float32); xyz[..., 2] = rng.uniform(5, 60, (F, cap)).astype(np.float32)
+    valid = (rng.random((F, cap)) < rng.uniform(0.3, 0.95)).astype(np.uint8); rel = (rng.random((F, cap)) < rng.uniform(0.1, 0.9)).astype(np.uint8)
+    for f in range(F):
+        n = int(rng.integers(0, nk[f] + 1)); q = rng.permutation(nk[f])[:n]
+        if rng.random() < 0.5:
+            q = np.sort(q)
+        lr["queryIdx"][f, :n] = q; lr["trainIdx"][f, :n] = rng.integers(0, cap, n); nlr[f] = n
+    f2f = np.zeros((F - 1, cap), O.DMATCH_DTYPE); nf2f = np.zeros(F - 1, np.int32)
+    for i in range(F - 1):
+        n = int(rng.integers(0, min(nk[i], nk[i + 1]) + 1))
+        f2f["queryIdx"][i, :n] = np.sort(rng.permutation(nk[i])[:n]); f2f["trainIdx"][i, :n] = rng.permutation(nk[i + 1])[:n]; nf2f[i] = n
+    inl = (rng.random((F - 1, cap)) < rng.uniform(0.2, 1.0)).astype(np.uint8)
+    T_rel = np.stack([O.se3_exp(np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 0.02, 3)])) for _ in range(F - 1)]) if F > 1 else np.zeros((0, 7))
+    return kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, nk.astype(np.int32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_build_windows_random_tracks_vs_oracle(pkg, oracle, seed):
+    """the builder alone, on random association / match / flag tables (chains of every length, unreliable -> reliable updates mid-chain,
+    dropped links, empty frames, n_kf from 1 to 12, capacity overflow), through vslam_build_windows_dev against oracle/windows.c"""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    ctx = pkg.VO(device=0, max_batch=1)
+    try:
+        for case in range(12):
+            F = int(rng.integers(1, 40)); cap = int(rng.choice([64, 100, 256])); n_kf = int(rng.integers(1, 13))
+            kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, nk = _random_tracks(rng, F, cap, int(rng.integers(1, cap + 1)))
+            full = oracle.build_windows(kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, n_kf=n_kf, lm_capacity=F * cap * (n_kf + 1),
+                                        edge_capacity=2 * F * cap * (n_kf + 1))   # (a landmark is in up to n_kf windows)
+            assert full["status"] == 0
+            nl_tot, ne_tot = int(full["lm_off"][F]), int(full["edge_off"][F])
+            shrink = rng.random() < 0.3 and nl_tot > 4
+            lm_cap = max(int(nl_tot * rng.uniform(0.3, 0.9)), 1) if shrink else nl_tot + 7
+            e_cap = ne_tot + 5
+            w = oracle.build_windows(kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, n_kf=n_kf, lm_capacity=lm_cap, edge_capacity=e_cap)
+            d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            t_kps, t_lr, t_nlr, t_xyz, t_valid, t_rel, t_nk = d(kps.view(np.uint8)), d(lr.view(np.uint8)), d(nlr), d(xyz), d(valid), d(rel), d(nk)
+            t_f2f = d(f2f.view(np.uint8)) if F > 1 else torch.zeros(16, dtype=torch.uint8, device="cuda")
+            t_nf2f = d(nf2f) if F > 1 else torch.zeros(1, dtype=torch.int32, device="cuda")
+            t_inl = d(inl) if F > 1 else torch.zeros(1, dtype=torch.uint8, device="cuda")
+            t_T = d(T_rel) if F > 1 else torch.zeros(7, dtype=torch.float64, device="cuda")
+            tr = pkg.TracksIn()
+            tr.n_frames = F; tr.kp_capacity = cap; tr.lr_capacity = cap; tr.match_capacity = cap; tr.pnp_capacity = cap
+            tr.d_kps = t_kps.data_ptr(); tr.d_lr = t_lr.data_ptr(); tr.d_nlr = t_nlr.data_ptr(); tr.d_xyz = t_xyz.data_ptr(); tr.d_valid = t_valid.data_ptr()
+            tr.d_reliable = t_rel.data_ptr(); tr.d_f2f = t_f2f.data_ptr(); tr.d_nf2f = t_nf2f.data_ptr(); tr.d_pose_inlier = t_inl.data_ptr()
+            tr.d_T_rel = t_T.data_ptr(); tr.d_nkps = t_nk.data_ptr() if case % 2 == 0 else None
+            o = dict(lm_off=torch.zeros(F + 1, dtype=torch.int32, device="cuda"), e_off=torch.zeros(F + 1, dtype=torch.int32, device="cuda"),
+                     nkf=torch.zeros(F, dtype=torch.int32, device="cuda"), T=torch.zeros((F, n_kf, 7), dtype=torch.float64, device="cuda"),
+                     xyz=torch.zeros((lm_cap, 3), dtype=torch.float32, device="cuda"), rel=torch.zeros(lm_cap, dtype=torch.uint8, device="cuda"),
+                     inl=torch.zeros(lm_cap, dtype=torch.uint8, device="cuda"), kf=torch.full((e_cap,), -7, dtype=torch.int32, device="cuda"),
+                     lm=torch.zeros(e_cap, dtype=torch.int32, device="cuda"), uv=torch.zeros((e_cap, 2), dtype=torch.float32, device="cuda"),
+                     st=torch.zeros(1, dtype=torch.int32, device="cuda"))
+            bb = pkg.BaBatch()
+            bb.d_lm_off = o["lm_off"].data_ptr(); bb.d_edge_off = o["e_off"].data_ptr(); bb.d_T_c_w = o["T"].data_ptr(); bb.d_xyz = o["xyz"].data_ptr()
+            bb.d_reliable = o["rel"].data_ptr(); bb.d_lm_inlier = o["inl"].data_ptr(); bb.d_kf_idx = o["kf"].data_ptr(); bb.d_lm_idx = o["lm"].data_ptr()
+            bb.d_uv = o["uv"].data_ptr(); bb.d_n_kf = o["nkf"].data_ptr()
+            torch.cuda.synchronize()
+            ctx.build_windows_dev(tr, n_kf, lm_cap, e_cap, bb, o["st"].data_ptr())
+            ctx.sync()
+            g = {k: v.cpu().numpy() for k, v in o.items()}
+            tag = (seed, case, F, cap, n_kf, shrink)
+            assert g["st"][0] == w["status"] and (w["status"] == 1) == (shrink and lm_cap < nl_tot), tag
+            assert np.array_equal(g["lm_off"], w["lm_off"]) and np.array_equal(g["e_off"], w["edge_off"]) and np.array_equal(g["nkf"], w["n_kf"]), tag
+            nl, ne = int(w["lm_off"][F]), int(w["edge_off"][F])
+            assert np.array_equal(g["kf"][:ne], w["kf_idx"][:ne]) and np.array_equal(g["lm"][:ne], w["lm_idx"][:ne]) and np.array_equal(g["uv"][:ne], w["uv"][:ne]), tag
+            assert (g["kf"][ne:] == -7).all(), tag
+            assert np.array_equal(g["rel"][:nl], w["reliable"][:nl]) and (g["inl"][:nl] == 1).all(), tag
+            assert np.allclose(g["xyz"][:nl], w["xyz"][:nl], rtol=3e-6, atol=2e-5), (tag, np.abs(g["xyz"][:nl] - w["xyz"][:nl]).max())
+            assert np.allclose(g["T"], w["T"], rtol=1e-9, atol=1e-11), tag
+            assert bb.n_windows == F and bb.n_kf == n_kf and bb.total_lm == lm_cap and bb.total_edge == e_cap
+    finally:
+        ctx.close()
