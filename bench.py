@@ -601,7 +601,8 @@ def main():
     from stereo_visual_slam_amd import sharding
     B = args.batch
     seq_mode = args.sequence > 0
-    ba_windows = "synthetic" if seq_mode else args.ba_windows  # (sequence mode: a chunk has a 1-frame halo, not the 9 frames a full first window needs)
+    ba_windows = args.ba_windows  # (sequence mode: a chunk's map starts at its halo frame, like the map of a sequence starts at frame 0; the BA
+                                  # results are not fed back into the gathered trajectory in either mode)
     if seq_mode:  # config 5: this rank's contiguous chunk of ONE sequence, plus the frame before it (halo)
         assert args.sequence >= 2 * world, "--sequence needs at least two frames per rank"
         lo, hi = sharding.shard_range(args.sequence, rank, world)

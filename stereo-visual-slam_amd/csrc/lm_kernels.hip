@@ -48,6 +48,9 @@ namespace vslam {
 #ifndef VSLAM_LM_BLOCK
 #define VSLAM_LM_BLOCK 512
 #endif
+#ifndef VSLAM_LM_ITEM_FIXED
+#define VSLAM_LM_ITEM_FIXED 128 // fixed cost of a Schur work item, in hits (see the item balance)
+#endif
 #ifndef VSLAM_LM_MIN_WAVES
 #define VSLAM_LM_MIN_WAVES 2 // waves per SIMD the register allocation must leave room for
 #endif
@@ -100,6 +103,8 @@ struct alignas(16) LmShared {
     int kfp[kMaxKf + 4];                   // kf_ptr (keyframe-major range starts), for the per-edge keyframe lookup
     int rowp[kMaxKf + 4];                  // first 64-edge row of every keyframe's list (rows never straddle keyframes)
     int flag[8];
+    int pairp[kMaxPairs + 2];              // pair_ptr (first hit of every keyframe pair): read at every Schur item start -- from global memory that
+                                           // was one dependent round trip per item before its first operand could even be requested
 };
 static_assert(kMaxKf * kPoseParts >= kMaxKf + kLmWaves - 1, "part[] must hold one slot per (keyframe, wave) segment");
 static_assert(kLmWaves <= 16, "cnt rows");
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     __syncthreads();
                     if (tid < npairs) { int t = 0; for (int ww = 0; ww < kLmWaves; ++ww) t += sm.cnt[ww * kCntStride + tid]; sm.ptot[tid] = t; }
                     __syncthreads();
-                    if (tid == 0) { int acc = 0; for (int p = 0; p < npairs; ++p) { pair_ptr[p] = acc; acc += sm.ptot[p]; } pair_ptr[npairs] = acc; }
+                    if (tid == 0) { int acc = 0; for (int p = 0; p < npairs; ++p) { pair_ptr[p] = acc; sm.pairp[p] = acc; acc += sm.ptot[p]; } pair_ptr[npairs] = acc; sm.pairp[npairs] = acc; }
                     __syncthreads();
                     if (tid < npairs) { int run = pair_ptr[tid]; for (int ww = 0; ww < kLmWaves; ++ww) { const int c = sm.cnt[ww * kCntStride + tid]; sm.cnt[ww * kCntStride + tid] = run; run += c; } }
                     __syncthreads();
@@ -726,7 +731,13 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             __syncthreads();
             // (work per item staged in LDS first: ranking straight from kf_ptr costs a global round trip per comparison)
             int* s_work = sm.cnt; // free after the list build
-            if (tid < nitems) { const int a1 = sm.pk1[tid]; s_work[tid] = a1 == sm.pk2[tid] ? sm.kfp[a1 + 1] - sm.kfp[a1] : (int)sm.ptot[tid]; }
+            // (cost of an item in hit-equivalents: its rows of 64 hits plus a fixed part -- the first-row round trips and the 36-value butterfly
+            // are worth about two rows; with the short lists of a real sequence the fixed part is most of an item)
+            if (tid < nitems) {
+                const int a1 = sm.pk1[tid];
+                const int hits_i = a1 == sm.pk2[tid] ? sm.kfp[a1 + 1] - sm.kfp[a1] : (int)sm.ptot[tid];
+                s_work[tid] = hits_i > 0 ? ((hits_i + 63) & ~63) + VSLAM_LM_ITEM_FIXED : 0;
+            }
             __syncthreads();
             if (tid < nitems) {
                 const int mine = s_work[tid];
@@ -1035,6 +1046,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 for (int slot = 0; slot < kItemSlots; ++slot) {
                     const int p = sm.item[wave * kItemSlots + slot];
                     if (p == 0xFF) continue; // uniform per wave
+                    PH(23); // (item boundary: what came before was the previous item's reduction + store)
                     const int k1 = sm.pk1[p], k2 = sm.pk2[p];
                     double R1[12], R2[12]; // poses of the pair, wave-uniform
 #pragma unroll
@@ -1045,7 +1057,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     if (k1 == k2) { // every edge of keyframe k1 pairs with itself: one Jacobian, symmetric 2x2 core, upper triangle only
                         // software-pipelined: streams the keyframe's own list (j) with the landmark ids two steps and the weight, the
                         // landmark, Dinv and b_l one step ahead
-                        const int jbeg = kf_ptr[k1], jend = kf_ptr[k1 + 1];
+                        const int jbeg = sm.kfp[k1], jend = sm.kfp[k1 + 1];
                         int j = jbeg + lane;
                         double accb[6] = {0, 0, 0, 0, 0, 0}; // this keyframe's share of W Dinv b_l (reduced right-hand side)
                         if (jbeg < jend) { // (an empty list has no valid record to prefetch)
@@ -1055,6 +1067,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         double2 Da, Db, Dc;
                         loadD(ln, Da, Db, Dc);
                         double g0 = PC(bl, 0, ln), g1 = PC(bl, 1, ln), g2 = PC(bl, 2, ln);
+                        PH(15); // (item prologue: first-row operands requested)
                         for (; j < jend; j += 64) {
                             LM_PRIO_TICK(prio_cnt);
                             double2 Dan, Dbn, Dcn;
@@ -1105,6 +1118,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
                             for (int r = 0; r < 6; ++r) red[21 + r] = accb[r];
                         }
+                        PH(22); // (rows)
                         wave_reduce_scatter<27>(red, lane);
                         if (slot27 >= 21) sm.bs[6 * k1 + slot27 - 21] = sm.bp[6 * k1 + slot27 - 21] - red[0];
                         else if (slot27 >= 0) {
@@ -1117,9 +1131,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         }
                         continue;
                     } else {
-                        const int jend = pair_ptr[p + 1];
-                        int j = pair_ptr[p] + lane;
-                        if (pair_ptr[p] >= jend) continue; // no common landmark: the block stays zero (S was cleared), no butterfly
+                        const int jbeg = sm.pairp[p], jend = sm.pairp[p + 1];
+                        int j = jbeg + lane;
+                        if (jbeg >= jend) continue; // no common landmark: the block stays zero (S was cleared), no butterfly
                         {
                         int2 h = hits[min(j, jend - 1)];
                         int2 hn = hits[min(j + 64, jend - 1)];
@@ -1127,6 +1141,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         double pax = PC(P, 0, h.y), pay = PC(P, 1, h.y), paz = PC(P, 2, h.y);
                         double2 Da, Db, Dc;
                         loadD(h.y, Da, Db, Dc);
+                        PH(15);
                         for (; j < jend; j += 64) {
                             LM_PRIO_TICK(prio_cnt);
                             double2 Dan, Dbn, Dcn;
@@ -1166,6 +1181,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         }
                         }
                     }
+                    PH(22);
                     wave_reduce_scatter<36>(acc, lane);
                     if (slot36 >= 0) {
                         const int r = slot36 / 6, c = slot36 - 6 * r;
@@ -2077,8 +2093,8 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         hipStreamSynchronize(stream);
         std::vector<long long> h(kDbgSlots * (size_t)a.n_windows);
         hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        static const char* names[kDbgSlots] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky (rest)", "solve (rest)", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "(probe slot, unused)",
-                                               "chol: diag+rows", "chol: barrier 1", "chol: trailing update", "chol: barrier 2", "solve: barrier", "solve: back-subst", "-", "-"};
+        static const char* names[kDbgSlots] = {"setup", "eval+lin", "lm blocks", "pose blocks", "lambda/Dinv", "bs", "schur", "cholesky (rest)", "solve (rest)", "update+scale", "eval trial", "loop tail", "classify+wb", "(setup: csr)", "(setup: kf-major)", "schur: item prologue",
+                                               "chol: diag+rows", "chol: barrier 1", "chol: trailing update", "chol: barrier 2", "solve: barrier", "solve: back-subst", "schur: rows", "schur: reduce+store"};
         double tot = 0;
         for (int i = 0; i < kDbgSlots; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[kDbgSlots * (size_t)w + i]; s /= a.n_windows; if (i < 13 || i >= 16) tot += s; fprintf(stderr, "  [lm profile] %-20s %10.0f ticks/window\n", names[i], s); }
         fprintf(stderr, "  [lm profile] total %.0f cycles (clock64 = shader clock, thread 0 of every window; setup sub-splits not included)\n", tot);
