@@ -345,7 +345,7 @@ def ba_config4_measure(args, local, torch):
     """the BA schedule alone on B canned windows of the BASELINE config-4 shape (10 keyframes x 3000 landmarks, ~10 k edges: SURVEY 8d) -- the
     shape lm_window_kernel's roofline figures have been quoted on since round 1; the default step's windows come from real tracks and are smaller"""
     from stereo_visual_slam_amd.pipeline import KeyframePipeline
-    B = args.batch
+    B = 256   # (one window per CU: the shape and batch every earlier round quoted, whatever --batch is)
     pipe = KeyframePipeline(B, device=local, anms_num=500, n_lm=3000, unique_frames=2, seed=0, ba_windows="synthetic")
     try:
         for _ in range(2):
@@ -534,7 +534,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is repeated this many times; the median is reported")
-    ap.add_argument("--batch", type=int, default=256, help="stereo keyframes per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="stereo keyframes per GPU per step (two BA windows per CU one after the other: 39.5 k keyframes/s against "
+                                                            "37.5 k at 256, 34.5 k at 384, 40.3 k at 1024 -- profiles/r04_batch_sweep.json)")
     ap.add_argument("--anms", type=int, default=1500, help="keypoints per image after ANMS (BASELINE config 2: ~1500; reference: 500)")
     ap.add_argument("--landmarks", type=int, default=3000)
     ap.add_argument("--unique-frames", type=int, default=256, help="rendered stereo keyframes (one sequence, laid over the batch as a ping-pong)")

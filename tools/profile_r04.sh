@@ -8,8 +8,8 @@ STEPS=3
 COMMON="--steps $STEPS --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-reference-pipeline --render-workers 0 --unique-frames 64 --inputs resident"
 for CFG in ${@:-tracks config4 sgbm}; do
   case $CFG in
-    tracks)  ARGS="$COMMON";                                   BATCH=256;;
-    config4) ARGS="$COMMON --ba-windows synthetic";            BATCH=256;;
+    tracks)  ARGS="$COMMON";                                   BATCH=512;;
+    config4) ARGS="$COMMON --ba-windows synthetic --batch 256"; BATCH=256;;
     sgbm)    ARGS="$COMMON --depth sgbm --pose ransac --batch 64"; BATCH=64;;
   esac
   OUT=gpurun_out/prof_r04_$CFG; mkdir -p $OUT
@@ -54,7 +54,7 @@ root = os.environ.get("GRAFT_REPO_ROOT", ".")
 p = os.path.join(root, "gpurun_out", "prof_r04_tracks", "sq_summary.txt")
 if os.path.exists(p):
     per = {}
-    n_img = 512 * 7   # 2 x 256 images per step, 7 steps in the profiled command
+    n_img = 1024 * 7   # 2 x 512 images per step, 7 steps in the profiled command
     for line in open(p):
         name = line.split()[0]
         m = re.search(r"valu_insts ([0-9.e+]+)", line)
@@ -62,7 +62,7 @@ if os.path.exists(p):
             per[re.sub(r"<.*", "", name)] = float(m.group(1)) / n_img
     sha = hashlib.sha256(open(os.path.join(root, "stereo-visual-slam_amd", "csrc", "orb_kernels.hip"), "rb").read()).hexdigest()[:16]
     out = {"anms": 1500, "valu_wave_insts_per_image": per, "source_sha16": {"orb_kernels.hip": sha},
-           "source": "rocprofv3 --pmc SQ_INSTS_VALU (tools/profile_r04.sh, default bench step, 3584 images of 1241x376)"}
+           "source": "rocprofv3 --pmc SQ_INSTS_VALU (tools/profile_r04.sh, default bench step, 7168 images of 1241x376)"}
     json.dump(out, open(os.path.join(root, "profiles", "orb_valu.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(root, "gpurun_out", "prof_r04_tracks", "orb_valu.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
