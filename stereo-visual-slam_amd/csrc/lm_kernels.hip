@@ -48,6 +48,9 @@ namespace vslam {
 #ifndef VSLAM_LM_BLOCK
 #define VSLAM_LM_BLOCK 512
 #endif
+#ifndef VSLAM_LM_DYNAMIC_ITEMS
+#define VSLAM_LM_DYNAMIC_ITEMS 1
+#endif
 #ifndef VSLAM_LM_ITEM_FIXED
 #define VSLAM_LM_ITEM_FIXED 128 // fixed cost of a Schur work item, in hits (see the item balance)
 #endif
@@ -743,8 +746,12 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                 const int mine = s_work[tid];
                 int rank = 0;
                 for (int j = 0; j < nitems; ++j) { const int c = s_work[j]; rank += (c > mine) || (c == mine && j < tid); }
+#if VSLAM_LM_DYNAMIC_ITEMS
+                sm.item[rank] = (uint8_t)tid; // costliest first: the waves draw the items from this list as they become free (below)
+#else
                 const int row = rank / kLmWaves, col = rank % kLmWaves;
                 sm.item[((row & 1) ? kLmWaves - 1 - col : col) * kItemSlots + row] = (uint8_t)tid;
+#endif
             }
         }
     }
@@ -1039,12 +1046,26 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     if (bad) sm.flag[1] = 1;
                 }
                 for (int i = tid; i < np * np; i += kLmBlock) sm.S[i] = 0;
+                if (tid == 0) sm.flag[6] = 0; // next Schur item to hand out
                 __syncthreads(); // Dinv visible (global, same workgroup) + S zeroed
                 PH(4);
                 PH(5);
                 // Schur blocks: S[k1][k2] = [k1==k2](Hpp + lambda I) - sum_hits W1 Dinv W2^T.  item = (pair, row half), owned by one wave
+                // Items are handed out DYNAMICALLY, costliest first: a wave that is done draws the next one from an LDS counter.  (A static deal by
+                // estimated cost left the waves 22-27 % of the pass waiting for the slowest one: the older wave of a SIMD runs faster than its
+                // partner, and an item's fixed cost is not proportional to its hits.)  Which wave computes an item does not change its result: one
+                // wave owns a block and reduces it in a fixed order.
+#if VSLAM_LM_DYNAMIC_ITEMS
+                for (;;) {
+                    int slot = 0;
+                    if (lane == 0) slot = atomicAdd(&sm.flag[6], 1);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    if (slot >= npairs) break;
+                    const int p = sm.item[slot];
+#else
                 for (int slot = 0; slot < kItemSlots; ++slot) {
                     const int p = sm.item[wave * kItemSlots + slot];
+#endif
                     if (p == 0xFF) continue; // uniform per wave
                     PH(23); // (item boundary: what came before was the previous item's reduction + store)
                     const int k1 = sm.pk1[p], k2 = sm.pk2[p];
