@@ -248,6 +248,29 @@ def cpu_baseline(pipe, out, anms_num, n_single=24, per_core=2, chunk_len=8):
     return res, parity
 
 
+def usable_cores():
+    """CPUs this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one (a box that shows 256 logical CPUs may
+    grant 64), and by 128 (the workers are numpy / C single-threaded compute: SMT siblings add nothing but memory pressure)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 128))
+
+
 def cpu_baseline_tracks(pipe, out, anms_num, n_single=24, per_core=2):
     """tracks mode (the default step): the CPU oracle on the SAME pipeline -- front end per frame, frame-to-frame stage per pair, the map
     bookkeeping of oracle/windows.c, the BA schedule on every built window -- one thread in-process on the first n_single keyframes of the
@@ -303,14 +326,10 @@ def cpu_baseline_tracks(pipe, out, anms_num, n_single=24, per_core=2):
                       note="GPU step vs oracle on the same inputs: counts of keypoints / LR / f2f matches / pose inputs / pose inliers, the landmark and "
                            "edge offsets of the built windows and the BA landmark flags must be identical (integer_mismatches = 0); poses: motion-only LM "
                            "of keyframe b-1 -> b, and every window's poses after the 5+5+10+10 schedule")
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
+        cores = usable_cores()
         all_cores = None
         if cores > 1:
-            n_all = int(min(max(per_core * cores, 64), 1024))
+            n_all = int(min(max(4 * cores, 64), 1024))
             period = max(2 * (U - 1), 1)
             frames = [(t if t < U else period - t) for t in (b % period for b in range(n_all))]
             ctx = mp.get_context("spawn")
