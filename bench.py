@@ -611,10 +611,7 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == args.gpus
-    try:
-        host_cores = len(os.sched_getaffinity(0))
-    except Exception:
-        host_cores = os.cpu_count() or 1
+    host_cores = usable_cores()   # (affinity cut by the cgroup quota: a box that shows 256 CPUs may grant 16)
     render_workers = max(1, min(host_cores // max(world, 1), 32)) if args.render_workers < 0 else args.render_workers
 
     from stereo_visual_slam_amd.pipeline import KeyframePipeline
