@@ -39,6 +39,27 @@ def test_bench_line_contract():
     assert r["pose_rmse_vs_oracle"]["integer_mismatches"] == 0
     assert r["inputs_from_host"]["value"] > 0 and r["inputs_from_host"]["h2d_ms_per_step"] > 0
     assert r["stats"]["orb_status_nonzero"] == 0 and r["stats"]["ba_status_nonzero"] == 0
+    # round 4: the step is one pipeline -- the BA consumes windows built on the device from the step's own tracks, and the line says so
+    assert r["config"]["ba_windows"] == "tracks" and "built on the device" in r["config"]["workload"]
+    w = r["stats"]["ba_windows"]
+    assert w["builder_status"] == 0 and w["landmarks_per_window_mean"] > 100 and w["edges_per_window_mean"] >= w["landmarks_per_window_mean"]
+    assert "build_windows_kernels" in r["kernels_ms_per_step"]
+    # ... the same run measures the BA schedule on the config-4 shape and the reference's own stages (SGBM depth + RANSAC pose)
+    c4 = r["ba_config4"]
+    assert c4["ms_per_schedule_batch"] > 0 and c4["roofline"]["kernel"] == "lm_window_kernel" and "traffic" in c4["roofline"]
+    rp = r["reference_pipeline"]
+    assert rp["value"] > 0 and rp["unit"] == "keyframes/s" and rp["roofline"]["kernel"].startswith("sgbm_*") and rp["stats"]["ransac_inliers"] > 10
+    assert "pnp_epnp_kernel" in rp["kernels_ms_per_step"] and "sgbm_down_kernel" in rp["kernels_ms_per_step"] or rp["batch"] < 8
+    assert "reference_libs_pin" in cb["host"]
+
+
+def test_bench_synthetic_windows_and_ransac_pose():
+    """--ba-windows synthetic keeps the config-4 shape of rounds 1-3; --pose ransac swaps in the reference's pose stage"""
+    r = _bench("--ba-windows", "synthetic", "--landmarks", "600", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "8", "--unique-frames", "8",
+               "--no-cpu-baseline", "--inputs", "resident")
+    assert r["config"]["ba_windows"] == "synthetic" and "ba_windows" not in r["stats"] and "reference_pipeline" not in r
+    r = _bench("--pose", "ransac", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "8", "--unique-frames", "8", "--no-cpu-baseline", "--inputs", "resident")
+    assert "solvePnPRansac" in r["config"]["workload"] and "pnp_epnp_kernel" in r["kernels_ms_per_step"] and r["stats"]["pnp_inliers"] > 10
 
 
 def test_bench_sgbm_depth_line():
