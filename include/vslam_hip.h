@@ -37,7 +37,8 @@ extern "C" {
 
 /* ABI revision of this header.  Bumped whenever a struct grows or a signature changes position-wise (revision 2 inserted K4 into
  * vslam_local_ba / vslam_pose_only_window; revision 3 added struct_size / abi_version to vslam_params and the alignment contract
- * of vslam_feature_matching_dev).  vslam_create refuses a vslam_params whose struct_size / abi_version do not match the library's,
+ * of vslam_feature_matching_dev; revision 4 appended d_n_kf to vslam_ba_batch and added vslam_build_windows_dev, vslam_pnp_ransac_dev,
+ * vslam_set_tuning, vslam_sgbm_status_dev).  vslam_create refuses a vslam_params whose struct_size / abi_version do not match the library's,
  * so a caller compiled against an older header fails with VSLAM_ERR_ARG instead of having its arguments reinterpreted. */
 #define VSLAM_ABI_VERSION 4
 
