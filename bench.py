@@ -396,10 +396,11 @@ def ba_config4_measure(args, local, torch):
         pipe.close()
 
 
-def reference_pipeline_measure(args, local, torch, seq, B=64):
+def reference_pipeline_measure(args, local, torch, seq, B=256):
     """The REFERENCE's own stages in throughput mode, measured in the default run so that the driver records it: depth from StereoSGBM +
     Frame::find_3d on the left keypoints (visual_odometry.cpp:159-217) instead of L/R match + DLT, pose from cv::solvePnPRansac(..., 100, 4.0,
-    0.99) (:277) instead of the motion-only LM, then the same device-built windows and BA schedule.  B keyframes per step, a few steps."""
+    0.99) (:277) instead of the motion-only LM, then the same device-built windows and BA schedule.  B keyframes per step (256: SGBM is at 0.14 ms per
+    pair there against 0.17 at 64, and the BA has one window per CU), a few steps."""
     from stereo_visual_slam_amd.pipeline import KeyframePipeline
     B = min(B, len(seq))
     pipe = KeyframePipeline(B, device=local, anms_num=args.anms, unique_frames=B, sequence=seq[:B], depth="sgbm", pose="ransac", ba_windows="tracks")

@@ -10,7 +10,7 @@ for CFG in ${@:-tracks config4 sgbm}; do
   case $CFG in
     tracks)  ARGS="$COMMON";                                   BATCH=512;;
     config4) ARGS="$COMMON --ba-windows synthetic --batch 256"; BATCH=256;;
-    sgbm)    ARGS="$COMMON --depth sgbm --pose ransac --batch 64"; BATCH=64;;
+    sgbm)    ARGS="$COMMON --depth sgbm --pose ransac --batch 256"; BATCH=256;;
   esac
   OUT=gpurun_out/prof_r04_$CFG; mkdir -p $OUT
   timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py $ARGS > $OUT/bench.json 2> $OUT/trace.log
