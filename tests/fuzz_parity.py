@@ -6,7 +6,7 @@ import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-KINDS = ["match", "sgbm", "orb", "ba", "pnp", "ransac"]
+KINDS = ["match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev"]
 
 
 class Mismatch(AssertionError):
@@ -75,6 +75,76 @@ def one_case(kind, rng, vo, pkg, O, synth):
         wT, wi, wn, _ = O.pnp_motion_only(p["xyz"], p["uv"], p["T0"], iters=10)
         if not (np.allclose(gT, wT, rtol=1e-4, atol=1e-6) and gn == wn):
             fail("pnp", M=M, seed=seed)
+    elif kind == "windows":
+        # vslam_build_windows_dev on random association / match / flag tables vs oracle/windows.c (round 4)
+        import torch
+        F = int(rng.integers(1, 24)); cap = int(rng.choice([64, 128, 256])); n_kf = int(rng.integers(1, 13))
+        kps = np.zeros((F, cap), O.KEYPOINT_DTYPE); nk = rng.integers(1, cap + 1, F).astype(np.int32)
+        for f in range(F):
+            kps["x"][f, :nk[f]] = rng.uniform(0, 1241, nk[f]).astype(np.float32); kps["y"][f, :nk[f]] = rng.uniform(0, 376, nk[f]).astype(np.float32)
+        lr = np.zeros((F, cap), O.DMATCH_DTYPE); nlr = np.zeros(F, np.int32)
+        xyz = rng.uniform(-20, 20, (F, cap, 3)).astype(np.float32); xyz[..., 2] = rng.uniform(5, 60, (F, cap)).astype(np.float32)
+        valid = (rng.random((F, cap)) < rng.uniform(0.3, 0.95)).astype(np.uint8); rel = (rng.random((F, cap)) < rng.uniform(0.1, 0.9)).astype(np.uint8)
+        for f in range(F):
+            n = int(rng.integers(0, nk[f] + 1)); lr["queryIdx"][f, :n] = rng.permutation(nk[f])[:n]; nlr[f] = n
+        Fm = max(F - 1, 1)
+        f2f = np.zeros((Fm, cap), O.DMATCH_DTYPE); nf2f = np.zeros(Fm, np.int32)
+        for i in range(F - 1):
+            n = int(rng.integers(0, min(nk[i], nk[i + 1]) + 1))
+            f2f["queryIdx"][i, :n] = np.sort(rng.permutation(nk[i])[:n]); f2f["trainIdx"][i, :n] = rng.permutation(nk[i + 1])[:n]; nf2f[i] = n
+        inl = (rng.random((Fm, cap)) < rng.uniform(0.2, 1.0)).astype(np.uint8)
+        T_rel = np.stack([O.se3_exp(np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 0.02, 3)])) for _ in range(Fm)])
+        lm_cap, e_cap = F * cap * (n_kf + 1), 2 * F * cap * (n_kf + 1)
+        w = O.build_windows(kps, lr, nlr, xyz, valid, rel, f2f[:F - 1], nf2f[:F - 1], inl[:F - 1], T_rel[:F - 1], n_kf=n_kf, lm_capacity=lm_cap, edge_capacity=e_cap)
+        dd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        t = dict(kps=dd(kps.view(np.uint8)), lr=dd(lr.view(np.uint8)), nlr=dd(nlr), xyz=dd(xyz), valid=dd(valid), rel=dd(rel), f2f=dd(f2f.view(np.uint8)), nf2f=dd(nf2f),
+                 inl=dd(inl), T=dd(T_rel), nk=dd(nk))
+        tr = pkg.TracksIn()
+        tr.n_frames = F; tr.kp_capacity = cap; tr.lr_capacity = cap; tr.match_capacity = cap; tr.pnp_capacity = cap
+        tr.d_kps = t["kps"].data_ptr(); tr.d_lr = t["lr"].data_ptr(); tr.d_nlr = t["nlr"].data_ptr(); tr.d_xyz = t["xyz"].data_ptr(); tr.d_valid = t["valid"].data_ptr()
+        tr.d_reliable = t["rel"].data_ptr(); tr.d_f2f = t["f2f"].data_ptr(); tr.d_nf2f = t["nf2f"].data_ptr(); tr.d_pose_inlier = t["inl"].data_ptr()
+        tr.d_T_rel = t["T"].data_ptr(); tr.d_nkps = t["nk"].data_ptr() if rng.random() < 0.5 else None
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+        o = dict(lm_off=z(F + 1, torch.int32), e_off=z(F + 1, torch.int32), nkf=z(F, torch.int32), T=z((F, n_kf, 7), torch.float64), xyz=z((lm_cap, 3), torch.float32),
+                 rel=z(lm_cap, torch.uint8), inl=z(lm_cap, torch.uint8), kf=z(e_cap, torch.int32), lm=z(e_cap, torch.int32), uv=z((e_cap, 2), torch.float32), st=z(1, torch.int32))
+        bb = pkg.BaBatch()
+        bb.d_lm_off = o["lm_off"].data_ptr(); bb.d_edge_off = o["e_off"].data_ptr(); bb.d_T_c_w = o["T"].data_ptr(); bb.d_xyz = o["xyz"].data_ptr()
+        bb.d_reliable = o["rel"].data_ptr(); bb.d_lm_inlier = o["inl"].data_ptr(); bb.d_kf_idx = o["kf"].data_ptr(); bb.d_lm_idx = o["lm"].data_ptr()
+        bb.d_uv = o["uv"].data_ptr(); bb.d_n_kf = o["nkf"].data_ptr()
+        torch.cuda.synchronize()
+        vo.build_windows_dev(tr, n_kf, lm_cap, e_cap, bb, o["st"].data_ptr()); vo.sync()
+        g = {k: v.cpu().numpy() for k, v in o.items()}
+        nl, ne = int(w["lm_off"][F]), int(w["edge_off"][F])
+        ok = (g["st"][0] == w["status"] == 0 and np.array_equal(g["lm_off"], w["lm_off"]) and np.array_equal(g["e_off"], w["edge_off"]) and np.array_equal(g["nkf"], w["n_kf"])
+              and np.array_equal(g["kf"][:ne], w["kf_idx"][:ne]) and np.array_equal(g["lm"][:ne], w["lm_idx"][:ne]) and np.array_equal(g["uv"][:ne], w["uv"][:ne])
+              and np.array_equal(g["rel"][:nl], w["reliable"][:nl]) and np.allclose(g["xyz"][:nl], w["xyz"][:nl], rtol=3e-6, atol=2e-5) and np.allclose(g["T"], w["T"], rtol=1e-9, atol=1e-11))
+        if not ok:
+            fail("windows", F=F, cap=cap, n_kf=n_kf, seed=seed)
+    elif kind == "ransac_dev":
+        # vslam_pnp_ransac_dev: a batch of problems of random sizes in one call vs oracle/ransac.c problem by problem (round 4)
+        import torch
+        B = int(rng.integers(1, 7)); cap = 1280
+        Ms = [int(rng.choice([0, 3, 5, 6, int(rng.integers(7, 1200))])) for _ in range(B)]
+        xyz = np.zeros((B, cap, 3), np.float32); uv = np.zeros((B, cap, 2), np.float32); probs = []
+        for b, M in enumerate(Ms):
+            p = synth.pnp_problem(M=max(M, 1), seed=seed + b, outlier_frac=float(rng.choice([0.0, 0.2, 0.45])), sigma_px=0.4) if M > 0 else None
+            if M > 0:
+                xyz[b, :M] = p["xyz"][:M]; uv[b, :M] = p["uv"][:M]
+            probs.append(p)
+        d_xyz, d_uv, d_n = torch.from_numpy(xyz).cuda(), torch.from_numpy(uv).cuda(), torch.tensor(Ms, dtype=torch.int32, device="cuda")
+        d_T = torch.zeros((B, 7), dtype=torch.float64, device="cuda"); d_inl = torch.zeros((B, cap), dtype=torch.uint8, device="cuda")
+        d_ni = torch.zeros(B, dtype=torch.int32, device="cuda"); d_it = torch.zeros(B, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        vo.pnp_ransac_dev(d_xyz.data_ptr(), d_uv.data_ptr(), d_n.data_ptr(), cap, B, d_T.data_ptr(), 100, 4.0, 0.99, d_inl.data_ptr(), d_ni.data_ptr(), d_it.data_ptr()); vo.sync()
+        T, inl, ni, itr = d_T.cpu().numpy(), d_inl.cpu().numpy(), d_ni.cpu().numpy(), d_it.cpu().numpy()
+        for b, M in enumerate(Ms):
+            if M < 5:
+                if ni[b] != 0 or inl[b].any():
+                    fail("ransac_dev small", Ms=Ms, seed=seed)
+                continue
+            wT, wi, wn, wit = O.pnp_ransac(probs[b]["xyz"][:M], probs[b]["uv"][:M], lm_iters=0)
+            if not (itr[b] == wit and ni[b] == wn and np.array_equal(inl[b][:M], wi) and not inl[b][M:].any() and (wn == 0 or np.allclose(T[b], wT, rtol=1e-12, atol=1e-14))):
+                fail("ransac_dev", Ms=Ms, b=b, seed=seed, got=(int(ni[b]), int(itr[b])), want=(wn, wit))
     else:
         M = int(rng.integers(5, 1200))
         p = synth.pnp_problem(M=M, seed=seed, outlier_frac=float(rng.choice([0.0, 0.2, 0.45])), sigma_px=0.4)
@@ -101,7 +171,7 @@ def run(seconds=120.0, seed=0, only="", vo=None, max_cases=None, schedule=None):
     i = 0
     try:
         while time.time() < t_end and (max_cases is None or i < max_cases):
-            kind = only or (schedule[i % len(schedule)] if schedule else rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac"]))
+            kind = only or (schedule[i % len(schedule)] if schedule else rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev"]))
             one_case(kind, rng, vo, pkg, O, synth)
             n[kind] += 1
             i += 1
