@@ -401,24 +401,34 @@ def reference_pipeline_measure(args, local, torch, seq, B=256):
     Frame::find_3d on the left keypoints (visual_odometry.cpp:159-217) instead of L/R match + DLT, pose from cv::solvePnPRansac(..., 100, 4.0,
     0.99) (:277) instead of the motion-only LM, then the same device-built windows and BA schedule.  B keyframes per step (256: SGBM is at 0.14 ms per
     pair there against 0.17 at 64, and the BA has one window per CU), a few steps."""
-    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    from stereo_visual_slam_amd.pipeline import PipelineRing
     B = min(B, len(seq))
-    pipe = KeyframePipeline(B, device=local, anms_num=args.anms, unique_frames=B, sequence=seq[:B], depth="sgbm", pose="ransac", ba_windows="tracks")
+    n_flight = max(1, args.in_flight)
+    ring = PipelineRing(n_flight, B, device=local, anms_num=args.anms, unique_frames=B, sequence=seq[:B], depth="sgbm", pose="ransac", ba_windows="tracks")
+    pipe = ring.pipes[0]
     try:
-        for _ in range(2):
-            pipe.step()
+        for _ in range(2 * n_flight):
+            ring.step()
         torch.cuda.synchronize(pipe.dev)
         n = max(args.steps // 2, 3)
         t0 = time.perf_counter()
         for _ in range(n):
-            pipe.step()
+            ring.step()
         torch.cuda.synchronize(pipe.dev)
         el = time.perf_counter() - t0
+        el1 = None
+        if n_flight > 1:   # one batch in flight (the figure of the earlier rounds)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pipe.step()
+            torch.cuda.synchronize(pipe.dev)
+            el1 = time.perf_counter() - t0
         pipe.vo.profile_enable(True); pipe.vo.profile_read()
         for _ in range(n):
             pipe.step()
         prof = pipe.vo.profile_read(); pipe.vo.profile_enable(False)
-        bad = int((pipe.vo.orb_status(B) != 0).sum()) + int((pipe.vo.ba_status(B) != 0).sum()) + int(pipe.ba_build_status.item()) + int(pipe.vo.sgbm_status() != 0)
+        bad = sum(int((p_.vo.orb_status(B) != 0).sum()) + int((p_.vo.ba_status(B) != 0).sum()) + int(p_.ba_build_status.item()) + int(p_.vo.sgbm_status() != 0)
+                  for p_ in ring.pipes)
         if bad:
             return {"error": "status words non-zero (%d)" % bad}
         out = pipe.download()
@@ -433,7 +443,10 @@ def reference_pipeline_measure(args, local, torch, seq, B=256):
                             "frame-to-frame match, solvePnPRansac(100, 4.0, 0.99) pose (EPnP hypotheses, OpenCV 3.2.0 return value), device-built BA windows, "
                             "BA schedule 5+5+10+10; %d keyframes per step" % (args.anms, B),
                 "value": round(B * n / el, 2), "unit": "keyframes/s", "ms_per_step": round(1e3 * el / n, 4), "steps": n, "batch": B,
+                "batches_in_flight": n_flight,
+                "one_batch_in_flight": None if el1 is None else {"value": round(B * n / el1, 2), "ms_per_step": round(1e3 * el1 / n, 4)},
                 "kernels_ms_per_step": {k: round(v[0] / n, 4) for k, v in kern[:14]},
+                "kernels_note": "per-kernel durations and the roofline: HIP-event brackets in a repeat with ONE batch in flight",
                 "roofline": {"bound": "hbm", "kernel": "sgbm_* (family)", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                              "ms_per_pair": round(fam_ms / B, 4), "algorithmic_bytes_per_launch_set": int(alg),
                              "formula": "B pairs x ((w-96)*h*96*2 B cost volume once + 2*w*h B images in + 4*w*h B f32 disparity out)",
@@ -442,64 +455,75 @@ def reference_pipeline_measure(args, local, torch, seq, B=256):
                           "f2f_matches": float(out["nf2f"][:nt].mean()), "pose_inputs": float(out["pn"][:nt].mean()), "ransac_inliers": float(out["ninl"][:nt].mean()),
                           "landmarks_per_window_mean": float(np.diff(out["ba_lm_off"]).mean()), "edges_per_window_mean": float(np.diff(out["ba_e_off"]).mean())}}
     finally:
-        pipe.close()
+        ring.close()
 
 
-def host_input_region(pipe, args, timed_region, one_step, torch):
-    """--inputs host: the same steps with every step's 2B images arriving from pinned host memory: ring of two device batches, the
-    hipMemcpyAsync of step k+1 on a copy stream overlapped with step k (the reference reads its pairs from disk per frame,
-    visual_odometry.cpp:37-68).  Returns keyframes/s with the upload inside the timed region, and the H2D time per step alone."""
-    dev = pipe.dev
-    h_ring = [torch.from_numpy(pipe.h_imgs).pin_memory(), torch.from_numpy(pipe.h_imgs.copy()).pin_memory()]
-    d_ring = [pipe.d_imgs, torch.empty_like(pipe.d_imgs)]
+def host_input_region(ring, args, timed_region, torch):
+    """--inputs host: the same steps with every step's 2B images arriving from pinned host memory: every pipeline owns a ring of two
+    device batches, the hipMemcpyAsync of the pipeline's NEXT step goes onto a copy stream as soon as its current step is queued and is
+    overlapped with the steps in flight (the reference reads its pairs from disk per frame, visual_odometry.cpp:37-68).
+    Returns keyframes/s with the upload inside the timed region, and the H2D time per step alone."""
+    pipe0 = ring.pipes[0]
+    dev = pipe0.dev
     copy_stream = torch.cuda.Stream(dev)
-    copied = [torch.cuda.Event(), torch.cuda.Event()]
-    consumed = [torch.cuda.Event(), torch.cuda.Event()]
+    st = []
+    for pipe in ring.pipes:
+        st.append({"pipe": pipe, "k": 0,
+                   "h": [torch.from_numpy(pipe.h_imgs).pin_memory(), torch.from_numpy(pipe.h_imgs.copy()).pin_memory()],
+                   "d": [pipe.d_imgs, torch.empty_like(pipe.d_imgs)],
+                   "copied": [torch.cuda.Event(), torch.cuda.Event()], "consumed": [torch.cuda.Event(), torch.cuda.Event()]})
     # H2D alone: one batch, synchronous bracket
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(copy_stream):
-        d_ring[1].copy_(h_ring[1], non_blocking=True)
+        st[0]["d"][1].copy_(st[0]["h"][1], non_blocking=True)
         e0.record(copy_stream)
         for _ in range(3):
-            d_ring[1].copy_(h_ring[1], non_blocking=True)
+            st[0]["d"][1].copy_(st[0]["h"][1], non_blocking=True)
         e1.record(copy_stream)
     torch.cuda.synchronize(dev)
     h2d_ms = e0.elapsed_time(e1) / 3.0
-    nbytes = pipe.h_imgs.nbytes
+    nbytes = pipe0.h_imgs.nbytes
+    for q in st:
+        with torch.cuda.stream(copy_stream):       # prologue: every pipeline's first batch in flight
+            q["d"][0].copy_(q["h"][0], non_blocking=True)
+            q["copied"][0].record(copy_stream)
+        for ev in q["consumed"]:
+            ev.record(q["pipe"].stream)
     state = {"k": 0}
-    with torch.cuda.stream(copy_stream):       # prologue: batch 0 in flight
-        d_ring[0].copy_(h_ring[0], non_blocking=True)
-        copied[0].record(copy_stream)
-    for ev in consumed:
-        ev.record(pipe.stream)
 
     def step_from_host():
-        cur = state["k"] & 1
+        q = st[state["k"] % len(st)]
+        pipe = q["pipe"]
+        cur = q["k"] & 1
         nxt = cur ^ 1
-        with torch.cuda.stream(copy_stream):   # upload of the NEXT step's images, once the step that last read that buffer has finished its ORB stage
-            copy_stream.wait_event(consumed[nxt])
-            d_ring[nxt].copy_(h_ring[nxt], non_blocking=True)
-            copied[nxt].record(copy_stream)
-        pipe.stream.wait_event(copied[cur])
-        pipe.d_imgs = d_ring[cur]
+        with torch.cuda.stream(copy_stream):   # upload of this pipeline's NEXT batch, once the step that last read that buffer has finished its ORB stage
+            copy_stream.wait_event(q["consumed"][nxt])
+            q["d"][nxt].copy_(q["h"][nxt], non_blocking=True)
+            q["copied"][nxt].record(copy_stream)
+        pipe.stream.wait_event(q["copied"][cur])
+        pipe.d_imgs = q["d"][cur]
         pipe.stage_orb()
         if pipe.depth == "sgbm":
-            pipe.stage_stereo_match(); consumed[cur].record(pipe.stream)
+            pipe.stage_stereo_match(); q["consumed"][cur].record(pipe.stream)
         else:
-            consumed[cur].record(pipe.stream); pipe.stage_stereo_match()
+            q["consumed"][cur].record(pipe.stream); pipe.stage_stereo_match()
         pipe.stage_track()
         pipe.stage_ba()
+        q["k"] += 1
         state["k"] += 1
 
-    for _ in range(2):
+    for _ in range(2 * len(st)):
         step_from_host()
     el = timed_region(step_from_host)
     torch.cuda.synchronize(dev)
-    pipe.d_imgs = d_ring[0]
-    return {"value": round(pipe.B * args.steps / el, 3), "unit": "keyframes/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+    for q in st:
+        q["pipe"].d_imgs = q["d"][0]
+    return {"value": round(pipe0.B * args.steps / el, 3), "unit": "keyframes/s", "ms_per_step": round(1e3 * el / args.steps, 4),
             "h2d_ms_per_step": round(h2d_ms, 4), "h2d_gbs": round(nbytes / (h2d_ms * 1e-3) / 1e9, 2), "h2d_bytes_per_step": int(nbytes),
-            "how": "pinned host ring of 2 batches; hipMemcpyAsync of step k+1 on a copy stream overlapped with step k; the upload is inside the timed region"}
+            "batches_in_flight": len(st),
+            "how": "pinned host ring of 2 batches per pipeline; hipMemcpyAsync of a pipeline's next batch on a copy stream overlapped with the steps in flight; "
+                   "the upload is inside the timed region"}
 
 
 def _rccl_version(torch):
@@ -508,6 +532,10 @@ def _rccl_version(torch):
         return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
     except Exception as e:
         return "unknown (%r)" % (e,)
+
+
+def units_per_step(args, seq_mode, world, B):
+    return args.sequence if seq_mode else world * B
 
 
 def host_info():
@@ -556,6 +584,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is repeated this many times; the median is reported")
     ap.add_argument("--batch", type=int, default=512, help="stereo keyframes per GPU per step (two BA windows per CU one after the other: 39.5 k keyframes/s against "
                                                             "37.5 k at 256, 34.5 k at 384, 40.3 k at 1024 -- profiles/r04_batch_sweep.json)")
+    ap.add_argument("--in-flight", type=int, default=2, metavar="P",
+                    help="batches in flight per GPU: P pipelines (context + HIP stream + buffers each), step k goes to pipeline k mod P without waiting for "
+                         "step k - 1 (pipeline.PipelineRing): 41.6 k keyframes/s at 2 x 512 against 38.6 k at 1 x 512; per-kernel durations and the roofline "
+                         "always come from a repeat with ONE batch in flight (kernels of two batches sharing the chip have no duration of their own)")
     ap.add_argument("--anms", type=int, default=1500, help="keypoints per image after ANMS (BASELINE config 2: ~1500; reference: 500)")
     ap.add_argument("--landmarks", type=int, default=3000)
     ap.add_argument("--unique-frames", type=int, default=256, help="rendered stereo keyframes (one sequence, laid over the batch as a ping-pong)")
@@ -615,10 +647,11 @@ def main():
     host_cores = usable_cores()   # (affinity cut by the cgroup quota: a box that shows 256 CPUs may grant 16)
     render_workers = max(1, min(host_cores // max(world, 1), 32)) if args.render_workers < 0 else args.render_workers
 
-    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline, PipelineRing
     from stereo_visual_slam_amd import sharding
     B = args.batch
     seq_mode = args.sequence > 0
+    n_flight = 1 if seq_mode else max(1, args.in_flight)   # (sequence mode: a step is one pass over THE sequence; kept at one pass in flight)
     ba_windows = args.ba_windows  # (sequence mode: a chunk's map starts at its halo frame, like the map of a sequence starts at frame 0; the BA
                                   # results are not fed back into the gathered trajectory in either mode)
     if seq_mode:  # config 5: this rank's contiguous chunk of ONE sequence, plus the frame before it (halo)
@@ -626,18 +659,23 @@ def main():
         lo, hi = sharding.shard_range(args.sequence, rank, world)
         h_lo = sharding.halo_start(lo)
         B = hi - h_lo
-        pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=0, verbose=args.verbose and rank == 0,
-                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence),
-                                render_workers=render_workers, ba_windows=ba_windows, pose=args.pose)
+        ring = PipelineRing(1, B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=0, verbose=args.verbose and rank == 0,
+                            with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence),
+                            render_workers=render_workers, ba_windows=ba_windows, pose=args.pose)
     else:
-        pipe = KeyframePipeline(B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
-                                with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, render_workers=render_workers,
-                                ba_windows=ba_windows, pose=args.pose)
+        ring = PipelineRing(n_flight, B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
+                            with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, render_workers=render_workers,
+                            ba_windows=ba_windows, pose=args.pose)
+    pipe = ring.pipes[0]
     dev = pipe.dev
     chained = [None]
 
-    def one_step():
+    def one_step(serial=False):
+        """one pass of the hot path over one batch; step k runs on pipeline k mod P (serial: always on pipeline 0, i.e. one batch in flight)"""
+        pipe = ring.pipes[0] if serial else ring.next_pipe()
         pipe.step()
+        if not serial:
+            ring.k += 1
         if seq_mode:   # ragged gather of the per-frame relative poses (56 B each), chained into one trajectory on rank 0
             with torch.cuda.stream(pipe.stream):
                 rel = pipe.d_Tpnp[:max(B - 1, 0)]  # item i = T_{h_lo+i+1, h_lo+i}: exactly the poses this rank owns (sharding.owned_pose_range)
@@ -646,6 +684,8 @@ def main():
             with torch.cuda.stream(pipe.stream):
                 sharding.gather_poses(pipe.d_Tpnp, dist)
 
+    for p_ in ring.pipes[1:]:   # (every pipeline has run once before the W warmup steps: none of them meets the timed region cold)
+        p_.step()
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
@@ -673,30 +713,45 @@ def main():
 
     # the timed repeats run WITHOUT the stage profiler (its hipEvent brackets sit between the kernels) ...
     rep_s = [timed_region(one_step) for _ in range(max(args.repeats, 1))]
-    # ... and one extra, untimed-for-the-headline repeat of the same `steps` steps WITH it: per-kernel durations from HIP events on the launch stream
+    one_step_serial = lambda: one_step(serial=True)
+    serial_s = timed_region(one_step_serial) if n_flight > 1 else None   # the same steps with ONE batch in flight (the figure of the earlier rounds)
+    # ... and one extra, untimed-for-the-headline repeat of the same `steps` steps WITH it, one batch in flight: per-kernel durations from HIP events
+    # on the launch stream (with two batches in flight the kernels of both share the CUs and an event bracket measures the mix)
     pipe.vo.profile_enable(True)
     pipe.vo.profile_read()
-    profiled_s = timed_region(one_step)
+    profiled_s = timed_region(one_step_serial)
     prof = pipe.vo.profile_read()
     pipe.vo.profile_enable(False)
     n_prof_steps = args.steps
     host_inputs = None
     if args.inputs == "host" and not seq_mode and world == 1:
         try:
-            host_inputs = host_input_region(pipe, args, timed_region, one_step, torch)
+            host_inputs = host_input_region(ring, args, timed_region, torch)
         except Exception as e:  # the extra measurement must never cost the headline
             host_inputs = {"error": repr(e)}
     elapsed = float(np.median(rep_s))
     # a step that overflowed an ORB capacity or whose BA windows were rejected must not count as processed keyframes
     n_img = pipe.B if args.depth == "sgbm" else 2 * pipe.B
-    orb_bad = int((pipe.vo.orb_status(n_img) != 0).sum())
-    ba_bad = int((pipe.vo.ba_status(pipe.B) != 0).sum()) if pipe.with_ba else 0
-    build_bad = int(pipe.ba_build_status.item()) if (pipe.with_ba and pipe.ba_windows == "tracks") else 0
+    orb_bad = sum(int((p_.vo.orb_status(n_img) != 0).sum()) for p_ in ring.pipes)
+    ba_bad = sum(int((p_.vo.ba_status(p_.B) != 0).sum()) for p_ in ring.pipes) if pipe.with_ba else 0
+    build_bad = sum(int(p_.ba_build_status.item()) for p_ in ring.pipes) if (pipe.with_ba and pipe.ba_windows == "tracks") else 0
     if orb_bad or ba_bad or build_bad:
         raise SystemExit("bench invalid: %d images overflowed an ORB capacity, %d BA windows were rejected, window builder status %d" % (orb_bad, ba_bad, build_bad))
 
     if rank == 0:
         out = pipe.download()
+        flight_same = None
+        if len(ring) > 1:   # the pipelines were handed the same images: whatever ran beside them, their results must be the same bits
+            keys = ["kps", "desc", "lr", "f2f", "Tpnp", "inl"] + (["ba_T", "ba_inl"] if pipe.with_ba else [])
+            flight_same = True
+            for p_ in ring.pipes[1:]:
+                o2 = p_.download()
+                flight_same = flight_same and all(np.array_equal(out[k_], o2[k_]) for k_ in keys)
+                del o2
+            if not flight_same:
+                raise SystemExit("bench invalid: pipelines in flight together produced different results on the same inputs")
+        for p_ in ring.pipes[1:]:
+            p_.close()
         pipe.ba_shape = None
         win_stats = None
         if pipe.with_ba and pipe.ba_windows == "tracks":
@@ -754,6 +809,7 @@ def main():
             "dtype": "u8+f64", "data": "synthetic",
             "config": {"workload": workload,
                        "batch_keyframes_per_gpu": B, "image": "1241x376 u8",
+                       "batches_in_flight_per_gpu": len(ring),
                        "ba_windows": pipe.ba_windows if pipe.with_ba else None,
                        "unique_inputs": "%d rendered stereo keyframes of one sequence (ping-pong over the batch), %d BA windows (%s)" % (
                            pipe.unique_frames, pipe.unique_windows if pipe.with_ba else 0, "built from the step's tracks" if pipe.ba_windows == "tracks" else "canned"),
@@ -761,8 +817,14 @@ def main():
                                       if seq_mode else "%d independent replicas, sharded keyframes" % world},
             "timing": {"repeats": len(rep_s), "ms_per_step_each": [round(1e3 * x / args.steps, 4) for x in rep_s], "reported": "median",
                        "spread_pct": round(100.0 * (max(rep_s) - min(rep_s)) / elapsed, 2),
-                       "stage_profiler": "off in the timed repeats; on in one extra repeat of the same %d steps (%.4f ms/step) that feeds `roofline` and "
-                                         "`kernels_ms_per_step`" % (args.steps, 1e3 * profiled_s / args.steps)},
+                       "in_flight": {"batches": len(ring),
+                                     "how": "step k is queued on pipeline k mod %d (own context, HIP stream and buffers) without waiting for step k - 1; every step is "
+                                            "the whole hot path over one batch of %d keyframes; the timed region ends with a device-wide synchronize" % (len(ring), B),
+                                     "one_batch_in_flight": None if serial_s is None else {"ms_per_step": round(1e3 * serial_s / args.steps, 4),
+                                                                                            "value": round(units_per_step(args, seq_mode, world, B) * args.steps / serial_s, 3)},
+                                     "results_identical_across_pipelines": flight_same},
+                       "stage_profiler": "off in the timed repeats; on in one extra repeat of the same %d steps with ONE batch in flight (%.4f ms/step) that feeds "
+                                         "`roofline` and `kernels_ms_per_step`" % (args.steps, 1e3 * profiled_s / args.steps)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_gbs": round(copy_gbs, 1), "copy_probe": copy_probe, "copy_ceiling_guide_gbs": 6290.0, "frac_of_copy_ceiling": round(achieved / copy_gbs, 6) if copy_gbs > 0 else None,
@@ -817,8 +879,7 @@ def main():
                 res["cpu_baseline"]["reference_libs_timing"] = "unavailable on this host (no cv2 / OpenCV / g2o found at run time)"
                 res["cpu_baseline"]["host"]["reference_libs_pin"] = "skipped: no cv2 on this host (tests/test_reference_libs_pin.py)"
         print(json.dumps(res), flush=True)
-    if pipe.vo.h:
-        pipe.close()
+    ring.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

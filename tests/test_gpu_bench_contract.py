@@ -51,6 +51,12 @@ def test_bench_line_contract():
     assert rp["value"] > 0 and rp["unit"] == "keyframes/s" and rp["roofline"]["kernel"].startswith("sgbm_*") and rp["stats"]["ransac_inliers"] > 10
     assert "pnp_epnp_kernel" in rp["kernels_ms_per_step"] and "sgbm_down_kernel" in rp["kernels_ms_per_step"] or rp["batch"] < 8
     assert "reference_libs_pin" in cb["host"]
+    # two batches in flight by default (pipeline.PipelineRing): the line says so, carries the one-batch figure beside it, and the run itself
+    # checked that the pipelines produced the same bits
+    fl = r["timing"]["in_flight"]
+    assert fl["batches"] == 2 and r["config"]["batches_in_flight_per_gpu"] == 2 and fl["results_identical_across_pipelines"] is True
+    assert fl["one_batch_in_flight"]["value"] > 0 and r["inputs_from_host"]["batches_in_flight"] == 2
+    assert rp["batches_in_flight"] == 2 and rp["one_batch_in_flight"]["value"] > 0
 
 
 def test_bench_synthetic_windows_and_ransac_pose():
@@ -58,6 +64,9 @@ def test_bench_synthetic_windows_and_ransac_pose():
     r = _bench("--ba-windows", "synthetic", "--landmarks", "600", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "8", "--unique-frames", "8",
                "--no-cpu-baseline", "--inputs", "resident")
     assert r["config"]["ba_windows"] == "synthetic" and "ba_windows" not in r["stats"] and "reference_pipeline" not in r
+    r1 = _bench("--in-flight", "1", "--ba-windows", "synthetic", "--landmarks", "600", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "8",
+                "--unique-frames", "8", "--no-cpu-baseline", "--inputs", "resident")
+    assert r1["timing"]["in_flight"]["batches"] == 1 and r1["timing"]["in_flight"]["one_batch_in_flight"] is None
     r = _bench("--pose", "ransac", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "8", "--unique-frames", "8", "--no-cpu-baseline", "--inputs", "resident")
     assert "solvePnPRansac" in r["config"]["workload"] and "pnp_epnp_kernel" in r["kernels_ms_per_step"] and r["stats"]["pnp_inliers"] > 10
 

@@ -116,3 +116,34 @@ def test_pipeline_sgbm_depth_matches_oracle_composite(oracle, synth, pose):
             prev = (kL, dL, xyz, valid)
     finally:
         pipe.close()
+
+
+@pytest.mark.parametrize("depth,pose", [("match", "lm"), ("sgbm", "ransac")])
+def test_pipelines_in_flight_together_give_the_same_bits(synth, depth, pose):
+    """pipeline.PipelineRing: P contexts on P HIP streams with their steps queued back to back (what bench.py times by default).  The
+    kernels of the batches share CUs, L2 and -- in the SGBM sweep -- compete for residency while they wait on each other's slabs; none
+    of that may change a result: every pipeline must produce exactly what one pipeline stepping alone produces on the same images."""
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline, PipelineRing
+    B, anms = 24, 1500
+    seq = synth.stereo_sequence(8, seed=21, w=1241, h=376)
+    kw = dict(anms_num=anms, unique_frames=8, sequence=seq, ba_windows="tracks", depth=depth, pose=pose)
+    alone = KeyframePipeline(B, **kw)
+    try:
+        alone.step()
+        ref = alone.download()
+    finally:
+        alone.close()
+    ring = PipelineRing(3, B, **kw)
+    try:
+        for _ in range(7):   # steps 0..6: pipelines 0, 1, 2, 0, 1, 2, 0 -- queued without a synchronisation in between
+            ring.step()
+        ring.sync()
+        keys = ["cnt", "kps", "desc", "nlr", "lr", "nf2f", "f2f", "xyz", "valid", "rel", "pn", "Tpnp", "inl", "ninl", "ba_lm_off", "ba_e_off", "ba_nkf",
+                "ba_kf", "ba_lm", "ba_uv", "ba_xyz", "ba_rel", "ba_T", "ba_inl"]
+        for p in ring.pipes:
+            out = p.download()
+            assert int(out["ba_build_status"][0]) == 0
+            for k in keys:
+                assert np.array_equal(out[k], ref[k]), k
+    finally:
+        ring.close()

@@ -1,11 +1,12 @@
 #!/bin/bash
 # Round-4 rocprofv3 evidence (run through gpurun): for each of three bench configurations a kernel trace + stats, FETCH_SIZE and WRITE_SIZE
 # passes (separate --pmc runs, no other trace domains) and one SQ pass; summaries under gpurun_out/prof_r04_<cfg>/ (copy the ones to be
-# judged into profiles/).   usage: tools/profile_r04.sh [cfg ...]   cfg in: tracks config4 sgbm
+# judged into profiles/).  --in-flight 1: kernels of two batches in flight share the chip and have no duration / counters of their own.
+# usage: tools/profile_r04.sh [cfg ...]   cfg in: tracks config4 sgbm
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 STEPS=3
-COMMON="--steps $STEPS --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-reference-pipeline --render-workers 0 --unique-frames 64 --inputs resident"
+COMMON="--steps $STEPS --warmup 1 --repeats 1 --in-flight 1 --no-cpu-baseline --no-config4 --no-reference-pipeline --render-workers 0 --unique-frames 64 --inputs resident"
 for CFG in ${@:-tracks config4 sgbm}; do
   case $CFG in
     tracks)  ARGS="$COMMON";                                   BATCH=512;;
