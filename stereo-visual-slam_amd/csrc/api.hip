@@ -203,7 +203,7 @@ const char* vslam_kernel_names(void) { // the ProfScope names of csrc/*.hip (tes
            "match_train_nearest_kernel match_finalize_kernel sgbm_prefilter_kernel sgbm_down_kernel sgbm_forward_kernel sgbm_hsum_kernel sgbm_vsum_kernel sgbm_path_kernel "
            "sgbm_wta_kernel sgbm_lrcheck_kernel sgbm_median3_kernel sgbm_ccl_rows_kernel sgbm_ccl_union_kernel sgbm_ccl_count_kernel "
            "sgbm_ccl_apply_kernel sgbm_ccl_kernels triangulate_kernel find3d_disparity_kernel gather_uv_kernel build_pnp_inputs_kernel lm_window_kernel pose_only_wave_kernel "
-           "lm_window_kernel<pnp> pnp_wave_kernel pnp_inlier_kernel pnp_epnp_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel "
+           "lm_window_kernel<pnp> pnp_wave_kernel pnp_inlier_kernel pnp_epnp_kernels epnp_front_kernel epnp_jacobi_kernel epnp_back_kernel pnp_count_inliers_kernel hbm_copy_probe_kernel "
            "pnp_ransac_subsets_kernel pnp_ransac_count_kernel pnp_ransac_select_kernel "
            "build_windows_kernels track_init_kernel track_pose_chain_kernel track_link_kernel track_chain_kernel window_count_kernel window_scan_kernel window_rank_kernel window_emit_kernel";
 }
@@ -734,7 +734,7 @@ static int pnp_ransac_impl(vslam_ctx* ctx, const float* xyz_w, const float* uv, 
     }
     int rc;
     if ((rc = arena_reserve(c, al256(hx.size() * 4) + al256(hu.size() * 4) + al256((size_t)H * 96) + al256((size_t)H * 56) + 2 * al256((size_t)H * 4) +
-                                   2 * al256(12 * (size_t)n) + 2 * al256(8 * (size_t)n) + 2 * al256(n) + 4096))) return rc;
+                                   2 * al256(12 * (size_t)n) + 2 * al256(8 * (size_t)n) + 2 * al256(n) + al256(pnp_epnp_ws_bytes(H)) + 4096))) return rc;
     Arena ar(c);
     float* d_hx = arena_take<float>(ar, hx.size()); float* d_hu = arena_take<float>(ar, hu.size());
     double* d_Rt = arena_take<double>(ar, (size_t)H * 12); double* d_hT = arena_take<double>(ar, (size_t)H * 7);
@@ -742,6 +742,7 @@ static int pnp_ransac_impl(vslam_ctx* ctx, const float* xyz_w, const float* uv, 
     float* d_x = arena_take<float>(ar, 3 * (size_t)n); float* d_u = arena_take<float>(ar, 2 * (size_t)n);
     float* d_ix = arena_take<float>(ar, 3 * (size_t)n); float* d_iu = arena_take<float>(ar, 2 * (size_t)n);
     uint8_t* d_mask = arena_take<uint8_t>(ar, n); double* d_T = arena_take<double>(ar, 7); int32_t* d_n1 = arena_take<int32_t>(ar, 2);
+    uint8_t* d_ws = arena_take<uint8_t>(ar, pnp_epnp_ws_bytes(H));
     VS_HIP(hipMemcpyAsync(d_hx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_hu, hu.data(), hu.size() * 4, hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemcpyAsync(d_x, xyz_w, 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -749,7 +750,7 @@ static int pnp_ransac_impl(vslam_ctx* ctx, const float* xyz_w, const float* uv, 
     // 2. every hypothesis: EPnP on its 5 points (one wave each), then its inlier count over all points
     double K[4];
     fill_K(c, K);
-    if ((rc = launch_pnp_epnp(d_hx, d_hu, H, K, d_Rt, d_hT, d_ok, c->stream))) return rc;
+    if ((rc = launch_pnp_epnp(d_hx, d_hu, H, K, d_Rt, d_hT, d_ok, d_ws, c->stream))) return rc;
     std::vector<int32_t> cnt(H), okv(H);
     if (!single && (rc = launch_pnp_count_inliers(d_x, d_u, n, d_Rt, d_ok, 0, H, K, reproj_err, d_cnt, nullptr, c->stream))) return rc;
     if (!single) VS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));

@@ -5,12 +5,17 @@
 // (solvepnp.cpp: SOLVEPNP_EPNP for more than four points; epnp.cpp = Lepetit / Moreno-Noguer / Fua 2009) and counts the points
 // whose f32 squared reprojection error is <= (float)(4 * 4) (PnPRansacCallback::computeError, ptsetreg.cpp findInliers).
 //
-// gfx950 mapping: the hypotheses do not depend on each other, so ALL of them are solved at once, ONE WAVE PER HYPOTHESIS:
-//   - the 12 x 12 symmetric eigenproblem of M^T M (the only O(n^3) piece) runs wave-parallel in LDS: cyclic Jacobi with a
-//     round-robin ordering, 6 disjoint rotations per round, three element-parallel phases (J^T A, (.) J, V J) of 144 elements
-//     over the 64 lanes;
-//   - the small sequential algebra around it (3 x 3 eigenproblems, 6 x {3,4,5} least squares, five Gauss-Newton steps on the
-//     betas, absolute orientation) is done by lane 0.
+// gfx950 mapping: the hypotheses do not depend on each other, so ALL of them are solved at once, in three launches that each give the
+// work the shape it has (one wave per hypothesis with lane 0 doing the sequential algebra -- the first version -- left 63 lanes idle for
+// two thirds of its ~100 k wave-instructions: 8.8 ms for the 25.5 k hypotheses of a 256-keyframe batch):
+//   epnp_front_kernel   ONE LANE PER HYPOTHESIS: control points (3 x 3 Jacobi), barycentric coordinates, the rows of M and M^T M
+//                       (144 sums of 10 products); hands M^T M and the per-hypothesis constants on through a structure-of-arrays
+//                       workspace (hypothesis index fastest: coalesced for lane-per-hypothesis kernels);
+//   epnp_jacobi_kernel  the 12 x 12 symmetric eigenproblem, the only O(n^3) piece, EIGHT HYPOTHESES PER WAVE in LDS: cyclic Jacobi with a
+//                       round-robin ordering, 6 disjoint rotations per hypothesis and round (48 lanes compute a rotation each), then the
+//                       three element-parallel updates (J^T A, (.) J, V J) of 8 x 144 elements = 18 per lane;
+//   epnp_back_kernel    ONE LANE PER HYPOTHESIS again: L (6 x 10), rho, and for N = 1, 2, 3 the betas (Householder least squares), five
+//                       Gauss-Newton steps, absolute orientation (3 x 3 Jacobi) and the reprojection error; best of the three.
 // Every floating-point operation is performed in the same order as the CPU oracle's restatement, with IEEE division / sqrt and
 // no FMA contraction (this file is compiled with -ffp-contract=off): the hypothesis poses agree to the bit, so the inlier masks
 // (integers) can be compared exactly.  The basis of the 2-dimensional null space of a 5-point system is a property of the
@@ -96,17 +101,16 @@ __device__ inline double dist2(const double* a, const double* b) {
 
 constexpr int kMp = 5; // model points of solvePnPRansac for n > 4
 
-struct EpnpShared {
-    double A[144], V[144], B[144];
-    double m[kMp][2][12];               // rows of M
-    double cc[12], ss[12];
-    int partner[12];
+// per-hypothesis state of the lane-per-hypothesis kernels (private memory)
+struct EpnpLane {
     double pws[kMp * 3], us[kMp * 2], alphas[kMp * 4], pcs[kMp * 3];
     double cws[4][3], ccs[4][3];
     double v[4][12];
     double L[60], rho[6];
-    int ok;
 };
+// workspace between the three launches, structure of arrays: field f of hypothesis h at ws[f * Hs + h] (Hs = H rounded up to 64)
+constexpr int kWsMtM = 0, kWsPws = 144, kWsUs = kWsPws + 15, kWsAlphas = kWsUs + 10, kWsCws = kWsAlphas + 20, kWsV = kWsCws + 12, kWsFields = kWsV + 48;
+constexpr int kJacG = 8; // hypotheses per wave in epnp_jacobi_kernel: 8 x 144 elements = 18 per lane, 48 of 64 lanes own a rotation
 
 __device__ inline void find_betas(int N, const double* L, const double* rho, double* betas) {
     const int nc = N == 1 ? 4 : (N == 2 ? 3 : 5);
@@ -149,7 +153,7 @@ __device__ inline void gauss_newton(const double* L, const double* rho, double* 
     }
 }
 
-__device__ inline void estimate_R_and_t(const EpnpShared& e, double fu, double fv, double uc, double vc, double R[9], double t[3]) {
+__device__ inline void estimate_R_and_t(const EpnpLane& e, double fu, double fv, double uc, double vc, double R[9], double t[3]) {
     const int n = kMp;
     double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
     for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
@@ -177,7 +181,7 @@ __device__ inline void estimate_R_and_t(const EpnpShared& e, double fu, double f
     for (int i = 0; i < 3; ++i) t[i] = pc0[i] - dot3(R + 3 * i, pw0);
 }
 
-__device__ inline double compute_R_and_t(EpnpShared& e, const double* betas, double fu, double fv, double uc, double vc, double R[9], double t[3]) {
+__device__ inline double compute_R_and_t(EpnpLane& e, const double* betas, double fu, double fv, double uc, double vc, double R[9], double t[3]) {
     for (int j = 0; j < 4; ++j) for (int k = 0; k < 3; ++k) e.ccs[j][k] = 0;
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j)
@@ -213,162 +217,230 @@ __device__ inline void rotmat_to_quat(const double R[9], double q[4]) {
     for (int i = 0; i < 4; ++i) q[i] = sgn * q[i] / n;
 }
 
-// one wave (= one 64-thread workgroup) per hypothesis: hx / hu hold the 5 points of every subset (H x 5 x 3 f32, H x 5 x 2 f32)
-__global__ __launch_bounds__(64) void pnp_epnp_kernel(const float* __restrict__ hx, const float* __restrict__ hu, double fu, double fv, double uc, double vc,
-                                                     double* __restrict__ Rt /* H x 12: R row-major, t */, double* __restrict__ T /* H x 7 */,
-                                                     int32_t* __restrict__ ok_out, const int32_t* __restrict__ nh_of, int h_per) {
-    __shared__ EpnpShared e;
-    const int h = blockIdx.x, lane = threadIdx.x;
-    // batched form: problem h / h_per draws only nh_of[.] of its h_per hypothesis slots (0: fewer than 5 points, 1: exactly 5)
-    if (nh_of && (h % h_per) >= nh_of[h / h_per]) { if (lane == 0) ok_out[h] = 0; return; }
+// hx / hu hold the 5 points of every subset (H x 5 x 3 f32, H x 5 x 2 f32).  Batched form: problem h / h_per draws only nh_of[.] of its h_per
+// hypothesis slots (0: fewer than 5 points, 1: exactly 5); the other slots get ok = 0 and are skipped by the later launches.
+__global__ __launch_bounds__(64) void epnp_front_kernel(const float* __restrict__ hx, const float* __restrict__ hu, int H, int Hs, double fu, double fv, double uc,
+                                                       double vc, double* __restrict__ ws, int32_t* __restrict__ ok_out, const int32_t* __restrict__ nh_of,
+                                                       int h_per) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H) return;
+    if (nh_of && (h % h_per) >= nh_of[h / h_per]) { ok_out[h] = 0; return; }
     const float* xyz = hx + (size_t)h * kMp * 3;
     const float* uv = hu + (size_t)h * kMp * 2;
-    if (lane == 0) {
-        e.ok = 1;
-        for (int i = 0; i < kMp; ++i) {
-            for (int j = 0; j < 3; ++j) e.pws[3 * i + j] = (double)xyz[3 * i + j];
-            const float xn = (float)(((double)uv[2 * i] - uc) * (1.0 / fu)), yn = (float)(((double)uv[2 * i + 1] - vc) * (1.0 / fv));
-            e.us[2 * i] = (double)xn * fu + uc;
-            e.us[2 * i + 1] = (double)yn * fv + vc;
-        }
-        // choose_control_points
-        e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
-        for (int i = 0; i < kMp; ++i) for (int j = 0; j < 3; ++j) e.cws[0][j] += e.pws[3 * i + j];
-        for (int j = 0; j < 3; ++j) e.cws[0][j] /= kMp;
-        double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V3[9];
-        for (int i = 0; i < kMp; ++i) {
-            double d[3];
-            for (int j = 0; j < 3; ++j) d[j] = e.pws[3 * i + j] - e.cws[0][j];
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a * 3 + b] += d[a] * d[b];
-        }
-        jacobi_eig3(C, V3);
-        int ord[3] = {0, 1, 2};
-        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2 - a; ++b) if (C[ord[b + 1] * 4] > C[ord[b] * 4]) { const int tt = ord[b]; ord[b] = ord[b + 1]; ord[b + 1] = tt; }
-        for (int i = 1; i < 4; ++i) {
-            const int col = ord[i - 1];
-            const double ev = C[col * 4] > 0 ? C[col * 4] : 0.0;
-            const double k = sqrt(ev / kMp);
-            int big = 0; // sign convention of the principal directions: largest-magnitude component positive (first on ties)
-            for (int j = 1; j < 3; ++j) if (fabs(V3[j * 3 + col]) > fabs(V3[big * 3 + col])) big = j;
-            const double sg = V3[big * 3 + col] < 0 ? -1.0 : 1.0;
-            for (int j = 0; j < 3; ++j) e.cws[i][j] = e.cws[0][j] + k * (sg * V3[j * 3 + col]);
-        }
-        // compute_barycentric_coordinates
-        double cc[9], ci[9];
-        for (int i = 0; i < 3; ++i) for (int j = 1; j < 4; ++j) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
-        const double c00 = cc[4] * cc[8] - cc[5] * cc[7], c01 = cc[5] * cc[6] - cc[3] * cc[8], c02 = cc[3] * cc[7] - cc[4] * cc[6];
-        const double det = cc[0] * c00 + cc[1] * c01 + cc[2] * c02;
-        if (det == 0.0 || !isfinite(det)) e.ok = 0;
-        const double id = 1.0 / det;
-        ci[0] = c00 * id; ci[1] = (cc[2] * cc[7] - cc[1] * cc[8]) * id; ci[2] = (cc[1] * cc[5] - cc[2] * cc[4]) * id;
-        ci[3] = c01 * id; ci[4] = (cc[0] * cc[8] - cc[2] * cc[6]) * id; ci[5] = (cc[2] * cc[3] - cc[0] * cc[5]) * id;
-        ci[6] = c02 * id; ci[7] = (cc[1] * cc[6] - cc[0] * cc[7]) * id; ci[8] = (cc[0] * cc[4] - cc[1] * cc[3]) * id;
-        for (int i = 0; i < kMp; ++i) {
-            const double* pi = e.pws + 3 * i;
-            double* a = e.alphas + 4 * i;
-            for (int j = 0; j < 3; ++j)
-                a[1 + j] = ci[3 * j] * (pi[0] - e.cws[0][0]) + ci[3 * j + 1] * (pi[1] - e.cws[0][1]) + ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
-            a[0] = 1.0 - a[1] - a[2] - a[3];
-            for (int j = 0; j < 4; ++j) { // fill_M
-                e.m[i][0][3 * j] = a[j] * fu; e.m[i][0][3 * j + 1] = 0.0; e.m[i][0][3 * j + 2] = a[j] * (uc - e.us[2 * i]);
-                e.m[i][1][3 * j] = 0.0; e.m[i][1][3 * j + 1] = a[j] * fv; e.m[i][1][3 * j + 2] = a[j] * (vc - e.us[2 * i + 1]);
-            }
+    double pws[kMp * 3], us[kMp * 2], alphas[kMp * 4], cws[4][3];
+    double m[kMp][2][12]; // rows of M
+    int ok = 1;
+    for (int i = 0; i < kMp; ++i) {
+        for (int j = 0; j < 3; ++j) pws[3 * i + j] = (double)xyz[3 * i + j];
+        const float xn = (float)(((double)uv[2 * i] - uc) * (1.0 / fu)), yn = (float)(((double)uv[2 * i + 1] - vc) * (1.0 / fv));
+        us[2 * i] = (double)xn * fu + uc;
+        us[2 * i + 1] = (double)yn * fv + vc;
+    }
+    // choose_control_points
+    cws[0][0] = cws[0][1] = cws[0][2] = 0;
+    for (int i = 0; i < kMp; ++i) for (int j = 0; j < 3; ++j) cws[0][j] += pws[3 * i + j];
+    for (int j = 0; j < 3; ++j) cws[0][j] /= kMp;
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V3[9];
+    for (int i = 0; i < kMp; ++i) {
+        double d[3];
+        for (int j = 0; j < 3; ++j) d[j] = pws[3 * i + j] - cws[0][j];
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a * 3 + b] += d[a] * d[b];
+    }
+    jacobi_eig3(C, V3);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2 - a; ++b) if (C[ord[b + 1] * 4] > C[ord[b] * 4]) { const int tt = ord[b]; ord[b] = ord[b + 1]; ord[b + 1] = tt; }
+    for (int i = 1; i < 4; ++i) {
+        const int col = ord[i - 1];
+        const double ev = C[col * 4] > 0 ? C[col * 4] : 0.0;
+        const double k = sqrt(ev / kMp);
+        int big = 0; // sign convention of the principal directions: largest-magnitude component positive (first on ties)
+        for (int j = 1; j < 3; ++j) if (fabs(V3[j * 3 + col]) > fabs(V3[big * 3 + col])) big = j;
+        const double sg = V3[big * 3 + col] < 0 ? -1.0 : 1.0;
+        for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * (sg * V3[j * 3 + col]);
+    }
+    // compute_barycentric_coordinates
+    double cc[9], ci[9];
+    for (int i = 0; i < 3; ++i) for (int j = 1; j < 4; ++j) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
+    const double c00 = cc[4] * cc[8] - cc[5] * cc[7], c01 = cc[5] * cc[6] - cc[3] * cc[8], c02 = cc[3] * cc[7] - cc[4] * cc[6];
+    const double det = cc[0] * c00 + cc[1] * c01 + cc[2] * c02;
+    if (det == 0.0 || !isfinite(det)) ok = 0;
+    ok_out[h] = ok; // (the back-end clears it again when the pose is not finite)
+    if (!ok) return;
+    const double id = 1.0 / det;
+    ci[0] = c00 * id; ci[1] = (cc[2] * cc[7] - cc[1] * cc[8]) * id; ci[2] = (cc[1] * cc[5] - cc[2] * cc[4]) * id;
+    ci[3] = c01 * id; ci[4] = (cc[0] * cc[8] - cc[2] * cc[6]) * id; ci[5] = (cc[2] * cc[3] - cc[0] * cc[5]) * id;
+    ci[6] = c02 * id; ci[7] = (cc[1] * cc[6] - cc[0] * cc[7]) * id; ci[8] = (cc[0] * cc[4] - cc[1] * cc[3]) * id;
+    for (int i = 0; i < kMp; ++i) {
+        const double* pi = pws + 3 * i;
+        double* a = alphas + 4 * i;
+        for (int j = 0; j < 3; ++j)
+            a[1 + j] = ci[3 * j] * (pi[0] - cws[0][0]) + ci[3 * j + 1] * (pi[1] - cws[0][1]) + ci[3 * j + 2] * (pi[2] - cws[0][2]);
+        a[0] = 1.0 - a[1] - a[2] - a[3];
+        for (int j = 0; j < 4; ++j) { // fill_M
+            m[i][0][3 * j] = a[j] * fu; m[i][0][3 * j + 1] = 0.0; m[i][0][3 * j + 2] = a[j] * (uc - us[2 * i]);
+            m[i][1][3 * j] = 0.0; m[i][1][3 * j + 1] = a[j] * fv; m[i][1][3 * j + 2] = a[j] * (vc - us[2 * i + 1]);
         }
     }
-    __syncthreads();
-    if (!e.ok) { // wave-uniform
-        if (lane == 0) ok_out[h] = 0;
-        return;
-    }
-    // M^T M, element-parallel; per element the same sum order as the sequential accumulation over the points
-    for (int el = lane; el < 144; el += 64) {
-        const int a = el / 12, b = el % 12;
-        double acc = 0;
-        for (int i = 0; i < kMp; ++i) acc += e.m[i][0][a] * e.m[i][0][b] + e.m[i][1][a] * e.m[i][1][b];
-        e.A[el] = acc;
-        e.V[el] = a == b ? 1.0 : 0.0;
+    double* w = ws + h;
+    // M^T M: per element the sum over the points in their order
+    for (int a = 0; a < 12; ++a)
+        for (int b = 0; b < 12; ++b) {
+            double acc = 0;
+            for (int i = 0; i < kMp; ++i) acc += m[i][0][a] * m[i][0][b] + m[i][1][a] * m[i][1][b];
+            w[(size_t)(kWsMtM + a * 12 + b) * Hs] = acc;
+        }
+    for (int i = 0; i < 15; ++i) w[(size_t)(kWsPws + i) * Hs] = pws[i];
+    for (int i = 0; i < 10; ++i) w[(size_t)(kWsUs + i) * Hs] = us[i];
+    for (int i = 0; i < 20; ++i) w[(size_t)(kWsAlphas + i) * Hs] = alphas[i];
+    for (int i = 0; i < 12; ++i) w[(size_t)(kWsCws + i) * Hs] = cws[i / 3][i % 3];
+}
+
+// one wave = kJacG hypotheses.  A round: (0) lane 6 g + k computes rotation k of hypothesis g from A; (1) B = J^T A and V' = V J into registers,
+// written back in place once every lane has read; (2) A = B J the same way.  Each element sees the operations of the sequential solver in
+// its order (an element is touched by exactly one rotation per side and round).
+__global__ __launch_bounds__(64) void epnp_jacobi_kernel(int H, int Hs, double* __restrict__ ws, const int32_t* __restrict__ ok) {
+    __shared__ double A[kJacG * 144], V[kJacG * 144];
+    __shared__ double cc[kJacG * 12], ss[kJacG * 12];
+    __shared__ int partner[kJacG * 12];
+    const int lane = threadIdx.x, h0 = blockIdx.x * kJacG;
+    constexpr int kPer = kJacG * 144 / 64; // 18
+    static_assert(kJacG * 144 % 64 == 0, "elements per lane");
+    int any = 0;
+    if (lane < kJacG && h0 + lane < H) any = ok[h0 + lane];
+    if (__ballot(any != 0) == 0) return; // (uniform) nothing to solve in this group
+    // element u of this lane: flat = lane + 64 u -> hypothesis g = flat / 144, (i, j) inside its matrix
+    int eg[kPer], ei[kPer], ej[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int flat = lane + 64 * u, g = flat / 144, e = flat - 144 * g;
+        eg[u] = g; ei[u] = e / 12; ej[u] = e - 12 * (e / 12);
+        const int h = min(h0 + g, H - 1);
+        A[flat] = ws[(size_t)(kWsMtM + e) * Hs + h];
+        V[flat] = ei[u] == ej[u] ? 1.0 : 0.0;
     }
     __syncthreads();
     for (int sweep = 0; sweep < kSweeps12; ++sweep)
         for (int round = 0; round < 11; ++round) {
-            if (lane < 6) {
+            if (lane < 6 * kJacG) {
+                const int g = lane / 6, k = lane - 6 * g;
                 int p, q; double c, s;
-                rr_pair(round, lane, p, q);
-                jacobi_cs(e.A[p * 12 + p], e.A[q * 12 + q], e.A[p * 12 + q], c, s);
-                e.partner[p] = q; e.partner[q] = p; e.cc[p] = c; e.cc[q] = c; e.ss[p] = -s; e.ss[q] = s;
+                rr_pair(round, k, p, q);
+                const double* Ag = A + 144 * g;
+                jacobi_cs(Ag[p * 12 + p], Ag[q * 12 + q], Ag[p * 12 + q], c, s);
+                partner[12 * g + p] = q; partner[12 * g + q] = p; cc[12 * g + p] = c; cc[12 * g + q] = c; ss[12 * g + p] = -s; ss[12 * g + q] = s;
             }
             __syncthreads();
-            for (int el = lane; el < 144; el += 64) { const int i = el / 12, j = el % 12; e.B[el] = e.cc[i] * e.A[el] + e.ss[i] * e.A[e.partner[i] * 12 + j]; }
+            double tb[kPer], tv[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int g = eg[u], i = ei[u], j = ej[u], el = lane + 64 * u;
+                tb[u] = cc[12 * g + i] * A[el] + ss[12 * g + i] * A[144 * g + partner[12 * g + i] * 12 + j];
+                tv[u] = cc[12 * g + j] * V[el] + ss[12 * g + j] * V[144 * g + i * 12 + partner[12 * g + j]];
+            }
             __syncthreads();
-            for (int el = lane; el < 144; el += 64) { const int i = el / 12, j = el % 12; e.A[el] = e.cc[j] * e.B[el] + e.ss[j] * e.B[i * 12 + e.partner[j]]; }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) { A[lane + 64 * u] = tb[u]; V[lane + 64 * u] = tv[u]; }
             __syncthreads();
-            double nv[3];
-            for (int u = 0, el = lane; el < 144; el += 64, ++u) { const int i = el / 12, j = el % 12; nv[u] = e.cc[j] * e.V[el] + e.ss[j] * e.V[i * 12 + e.partner[j]]; }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int g = eg[u], i = ei[u], j = ej[u], el = lane + 64 * u;
+                tb[u] = cc[12 * g + j] * A[el] + ss[12 * g + j] * A[144 * g + i * 12 + partner[12 * g + j]];
+            }
             __syncthreads();
-            for (int u = 0, el = lane; el < 144; el += 64, ++u) e.V[el] = nv[u];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) A[lane + 64 * u] = tb[u];
             __syncthreads();
         }
-    if (lane == 0) {
+    // the four eigenvectors of the smallest eigenvalues, in ascending order (stable selection)
+    if (lane < kJacG && h0 + lane < H) {
+        const double* Ag = A + 144 * lane;
+        const double* Vg = V + 144 * lane;
         int ord[12];
         for (int i = 0; i < 12; ++i) ord[i] = i;
         for (int a = 0; a < 4; ++a) {
             int best = a;
-            for (int b = a + 1; b < 12; ++b) if (e.A[ord[b] * 13] < e.A[ord[best] * 13]) best = b;
+            for (int b = a + 1; b < 12; ++b) if (Ag[ord[b] * 13] < Ag[ord[best] * 13]) best = b;
             const int tmp = ord[best];
             for (int b = best; b > a; --b) ord[b] = ord[b - 1];
             ord[a] = tmp;
         }
-        for (int i = 0; i < 4; ++i) for (int r = 0; r < 12; ++r) e.v[i][r] = e.V[r * 12 + ord[i]];
-        // compute_L_6x10, compute_rho
-        {
-            double dv[4][6][3];
-            for (int i = 0; i < 4; ++i) {
-                int a = 0, b = 1;
-                for (int j = 0; j < 6; ++j) {
-                    for (int c = 0; c < 3; ++c) dv[i][j][c] = e.v[i][3 * a + c] - e.v[i][3 * b + c];
-                    b++;
-                    if (b > 3) { a++; b = a + 1; }
-                }
-            }
-            for (int i = 0; i < 6; ++i) {
-                double* row = e.L + 10 * i;
-                row[0] = dot3(dv[0][i], dv[0][i]);
-                row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
-                row[2] = dot3(dv[1][i], dv[1][i]);
-                row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
-                row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
-                row[5] = dot3(dv[2][i], dv[2][i]);
-                row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
-                row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
-                row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
-                row[9] = dot3(dv[3][i], dv[3][i]);
-            }
-        }
-        e.rho[0] = dist2(e.cws[0], e.cws[1]); e.rho[1] = dist2(e.cws[0], e.cws[2]); e.rho[2] = dist2(e.cws[0], e.cws[3]);
-        e.rho[3] = dist2(e.cws[1], e.cws[2]); e.rho[4] = dist2(e.cws[1], e.cws[3]); e.rho[5] = dist2(e.cws[2], e.cws[3]);
-        double best_err = -1, R[9], t[3];
-        for (int N = 1; N <= 3; ++N) {
-            double betas[4], Rn[9], tn[3];
-            find_betas(N, e.L, e.rho, betas);
-            gauss_newton(e.L, e.rho, betas);
-            const double err = compute_R_and_t(e, betas, fu, fv, uc, vc, Rn, tn);
-            if (N == 1 || err < best_err) {
-                best_err = err;
-                for (int i = 0; i < 9; ++i) R[i] = Rn[i];
-                for (int i = 0; i < 3; ++i) t[i] = tn[i];
-            }
-        }
-        bool fin = true;
-        for (int i = 0; i < 9; ++i) fin = fin && isfinite(R[i]);
-        for (int i = 0; i < 3; ++i) fin = fin && isfinite(t[i]);
-        double q[4] = {0, 0, 0, 1};
-        if (fin) rotmat_to_quat(R, q);
-        for (int i = 0; i < 9; ++i) Rt[(size_t)h * 12 + i] = R[i];
-        for (int i = 0; i < 3; ++i) Rt[(size_t)h * 12 + 9 + i] = t[i];
-        for (int i = 0; i < 4; ++i) T[(size_t)h * 7 + i] = q[i];
-        for (int i = 0; i < 3; ++i) T[(size_t)h * 7 + 4 + i] = t[i];
-        ok_out[h] = fin ? 1 : 0;
+        double* w = ws + h0 + lane;
+        for (int i = 0; i < 4; ++i) for (int r = 0; r < 12; ++r) w[(size_t)(kWsV + 12 * i + r) * Hs] = Vg[r * 12 + ord[i]];
     }
+}
+
+__global__ __launch_bounds__(64) void epnp_back_kernel(int H, int Hs, double fu, double fv, double uc, double vc, const double* __restrict__ ws,
+                                                      double* __restrict__ Rt /* H x 12: R row-major, t */, double* __restrict__ T /* H x 7 */,
+                                                      int32_t* __restrict__ ok_out) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H || !ok_out[h]) return;
+    EpnpLane e;
+    const double* w = ws + h;
+    for (int i = 0; i < 15; ++i) e.pws[i] = w[(size_t)(kWsPws + i) * Hs];
+    for (int i = 0; i < 10; ++i) e.us[i] = w[(size_t)(kWsUs + i) * Hs];
+    for (int i = 0; i < 20; ++i) e.alphas[i] = w[(size_t)(kWsAlphas + i) * Hs];
+    for (int i = 0; i < 12; ++i) e.cws[i / 3][i % 3] = w[(size_t)(kWsCws + i) * Hs];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 12; ++r) e.v[i][r] = w[(size_t)(kWsV + 12 * i + r) * Hs];
+    // compute_L_6x10, compute_rho
+    {
+        double dv[4][6][3];
+        for (int i = 0; i < 4; ++i) {
+            int a = 0, b = 1;
+            for (int j = 0; j < 6; ++j) {
+                for (int c = 0; c < 3; ++c) dv[i][j][c] = e.v[i][3 * a + c] - e.v[i][3 * b + c];
+                b++;
+                if (b > 3) { a++; b = a + 1; }
+            }
+        }
+        for (int i = 0; i < 6; ++i) {
+            double* row = e.L + 10 * i;
+            row[0] = dot3(dv[0][i], dv[0][i]);
+            row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
+            row[2] = dot3(dv[1][i], dv[1][i]);
+            row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
+            row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
+            row[5] = dot3(dv[2][i], dv[2][i]);
+            row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
+            row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
+            row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
+            row[9] = dot3(dv[3][i], dv[3][i]);
+        }
+    }
+    e.rho[0] = dist2(e.cws[0], e.cws[1]); e.rho[1] = dist2(e.cws[0], e.cws[2]); e.rho[2] = dist2(e.cws[0], e.cws[3]);
+    e.rho[3] = dist2(e.cws[1], e.cws[2]); e.rho[4] = dist2(e.cws[1], e.cws[3]); e.rho[5] = dist2(e.cws[2], e.cws[3]);
+    double best_err = -1, R[9], t[3];
+    for (int N = 1; N <= 3; ++N) {
+        double betas[4], Rn[9], tn[3];
+        find_betas(N, e.L, e.rho, betas);
+        gauss_newton(e.L, e.rho, betas);
+        const double err = compute_R_and_t(e, betas, fu, fv, uc, vc, Rn, tn);
+        if (N == 1 || err < best_err) {
+            best_err = err;
+            for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+            for (int i = 0; i < 3; ++i) t[i] = tn[i];
+        }
+    }
+    bool fin = true;
+    for (int i = 0; i < 9; ++i) fin = fin && isfinite(R[i]);
+    for (int i = 0; i < 3; ++i) fin = fin && isfinite(t[i]);
+    double q[4] = {0, 0, 0, 1};
+    if (fin) rotmat_to_quat(R, q);
+    for (int i = 0; i < 9; ++i) Rt[(size_t)h * 12 + i] = R[i];
+    for (int i = 0; i < 3; ++i) Rt[(size_t)h * 12 + 9 + i] = t[i];
+    for (int i = 0; i < 4; ++i) T[(size_t)h * 7 + i] = q[i];
+    for (int i = 0; i < 3; ++i) T[(size_t)h * 7 + 4 + i] = t[i];
+    ok_out[h] = fin ? 1 : 0;
+}
+
+size_t pnp_epnp_ws_bytes(int H) { return (size_t)kWsFields * (size_t)((H + 63) & ~63) * sizeof(double); }
+
+// the three launches for H hypotheses (ws: pnp_epnp_ws_bytes(H) bytes)
+static void launch_epnp_stages(const float* d_hx, const float* d_hu, int H, const double K[4], double* ws, double* d_Rt, double* d_T, int32_t* d_ok,
+                               const int32_t* nh_of, int h_per, hipStream_t stream) {
+    const int Hs = (H + 63) & ~63;
+    hipLaunchKernelGGL(epnp_front_kernel, dim3(Hs / 64), dim3(64), 0, stream, d_hx, d_hu, H, Hs, K[0], K[1], K[2], K[3], ws, d_ok, nh_of, h_per);
+    hipLaunchKernelGGL(epnp_jacobi_kernel, dim3((H + kJacG - 1) / kJacG), dim3(64), 0, stream, H, Hs, ws, (const int32_t*)d_ok);
+    hipLaunchKernelGGL(epnp_back_kernel, dim3(Hs / 64), dim3(64), 0, stream, H, Hs, K[0], K[1], K[2], K[3], (const double*)ws, d_Rt, d_T, d_ok);
 }
 
 // PnPRansacCallback::computeError + findInliers: inliers of every hypothesis over the shared point set (block = hypothesis);
@@ -407,10 +479,10 @@ __global__ __launch_bounds__(256) void pnp_count_inliers_kernel(const float* __r
     if (threadIdx.x == 0 && counts) counts[hyp] = cnt;
 }
 
-int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[4], double* d_Rt, double* d_T, int32_t* d_ok, hipStream_t stream) {
+int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[4], double* d_Rt, double* d_T, int32_t* d_ok, uint8_t* ws, hipStream_t stream) {
     if (H <= 0) return VSLAM_OK;
-    ProfScope prof__(stream, "pnp_epnp_kernel");
-    hipLaunchKernelGGL(pnp_epnp_kernel, dim3(H), dim3(64), 0, stream, d_hx, d_hu, K[0], K[1], K[2], K[3], d_Rt, d_T, d_ok, (const int32_t*)nullptr, 1);
+    ProfScope prof__(stream, "pnp_epnp_kernels", 3);
+    launch_epnp_stages(d_hx, d_hu, H, K, (double*)ws, d_Rt, d_T, d_ok, nullptr, 1, stream);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
@@ -558,7 +630,7 @@ __global__ __launch_bounds__(128) void pnp_ransac_select_kernel(const float* __r
 size_t pnp_ransac_scratch_bytes(int B, int H) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t nh = (size_t)B * H;
-    return al(nh * kMp * 3 * 4) + al(nh * kMp * 2 * 4) + al(nh * 12 * 8) + al(nh * 7 * 8) + 2 * al(nh * 4) + al((size_t)B * 4);
+    return al(nh * kMp * 3 * 4) + al(nh * kMp * 2 * 4) + al(nh * 12 * 8) + al(nh * 7 * 8) + 2 * al(nh * 4) + al((size_t)B * 4) + al(pnp_epnp_ws_bytes((int)nh));
 }
 
 int launch_pnp_ransac_batch(const float* d_xyz, const float* d_uv, const int32_t* d_n, int capacity, int B, int H, const double K[4], double reproj_err,
@@ -572,12 +644,13 @@ int launch_pnp_ransac_batch(const float* d_xyz, const float* d_uv, const int32_t
     double* hT = (double*)scratch; scratch += al(nh * 7 * 8);
     int32_t* ok = (int32_t*)scratch; scratch += al(nh * 4);
     int32_t* cnt = (int32_t*)scratch; scratch += al(nh * 4);
-    int32_t* nh_of = (int32_t*)scratch;
+    int32_t* nh_of = (int32_t*)scratch; scratch += al((size_t)B * 4);
+    double* ws = (double*)scratch;
     const float thr2 = (float)(reproj_err * reproj_err);
     { ProfScope p(stream, "pnp_ransac_subsets_kernel");
       hipLaunchKernelGGL(pnp_ransac_subsets_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_xyz, d_uv, d_n, capacity, B, H, hx, hu, nh_of); }
-    { ProfScope p(stream, "pnp_epnp_kernel");
-      hipLaunchKernelGGL(pnp_epnp_kernel, dim3((unsigned)nh), dim3(64), 0, stream, hx, hu, K[0], K[1], K[2], K[3], Rt, hT, ok, nh_of, H); }
+    { ProfScope p(stream, "pnp_epnp_kernels", 3);
+      launch_epnp_stages(hx, hu, (int)nh, K, ws, Rt, hT, ok, nh_of, H, stream); }
     { ProfScope p(stream, "pnp_ransac_count_kernel");
       hipLaunchKernelGGL(pnp_ransac_count_kernel, dim3(H, B), dim3(128), 0, stream, d_xyz, d_uv, d_n, capacity, H, Rt, ok, K[0], K[1], K[2], K[3], thr2, cnt); }
     { ProfScope p(stream, "pnp_ransac_select_kernel");

@@ -225,7 +225,8 @@ struct PnpArgs {
 };
 int launch_pnp(const PnpArgs& a, LmScratch* scratch, hipStream_t stream);
 // pnp_kernels.hip: EPnP of H 5-point subsets (one wave each) -> R|t (H x 12), pose (H x 7), ok flag; f32 inlier scoring of hypotheses
-int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[4], double* d_Rt, double* d_T, int32_t* d_ok, hipStream_t stream);
+size_t pnp_epnp_ws_bytes(int H);
+int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[4], double* d_Rt, double* d_T, int32_t* d_ok, uint8_t* ws, hipStream_t stream);
 int launch_pnp_count_inliers(const float* d_xyz, const float* d_uv, int n, const double* d_Rt, const int32_t* d_ok, int hyp0, int n_hyp, const double K[4],
                              double reproj_thr, int32_t* d_counts, uint8_t* d_mask, hipStream_t stream);
 

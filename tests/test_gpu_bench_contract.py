@@ -49,7 +49,7 @@ def test_bench_line_contract():
     assert c4["ms_per_schedule_batch"] > 0 and c4["roofline"]["kernel"] == "lm_window_kernel" and "traffic" in c4["roofline"]
     rp = r["reference_pipeline"]
     assert rp["value"] > 0 and rp["unit"] == "keyframes/s" and rp["roofline"]["kernel"].startswith("sgbm_*") and rp["stats"]["ransac_inliers"] > 10
-    assert "pnp_epnp_kernel" in rp["kernels_ms_per_step"] and "sgbm_down_kernel" in rp["kernels_ms_per_step"] or rp["batch"] < 8
+    assert "pnp_epnp_kernels" in rp["kernels_ms_per_step"] and "sgbm_down_kernel" in rp["kernels_ms_per_step"] or rp["batch"] < 8
     assert "reference_libs_pin" in cb["host"]
     # two batches in flight by default (pipeline.PipelineRing): the line says so, carries the one-batch figure beside it, and the run itself
     # checked that the pipelines produced the same bits
@@ -68,7 +68,7 @@ def test_bench_synthetic_windows_and_ransac_pose():
                 "--unique-frames", "8", "--no-cpu-baseline", "--inputs", "resident")
     assert r1["timing"]["in_flight"]["batches"] == 1 and r1["timing"]["in_flight"]["one_batch_in_flight"] is None
     r = _bench("--pose", "ransac", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "8", "--unique-frames", "8", "--no-cpu-baseline", "--inputs", "resident")
-    assert "solvePnPRansac" in r["config"]["workload"] and "pnp_epnp_kernel" in r["kernels_ms_per_step"] and r["stats"]["pnp_inliers"] > 10
+    assert "solvePnPRansac" in r["config"]["workload"] and "pnp_epnp_kernels" in r["kernels_ms_per_step"] and r["stats"]["pnp_inliers"] > 10
 
 
 def test_bench_sgbm_depth_line():
