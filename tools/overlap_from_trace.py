@@ -21,15 +21,17 @@ ev = []
 for s, e, _, _ in rows:
     ev.append((s, 1)); ev.append((e, -1))
 ev.sort()
-depth, last, busy1, busy2 = 0, ev[0][0], 0, 0
+depth, last, busy1, busy2, big_gaps = 0, ev[0][0], 0, 0, 0
 for t, d in ev:
     if depth >= 1: busy1 += t - last
     if depth >= 2: busy2 += t - last
+    if depth == 0 and t - last >= 500000: big_gaps += t - last   # >= 0.5 ms with nothing running: between the timed regions (synchronise, copy probe, downloads)
     depth += d; last = t
-span = max(r[1] for r in rows) - rows[0][0]
+span = max(r[1] for r in rows) - rows[0][0] - big_gaps
 tot = sum(e - s for s, e, _, _ in rows)
 queues = sorted(set(r[3] for r in rows))
 print("dispatches %d on queues/streams %s" % (len(rows), ",".join(queues)))
+print("(idle gaps >= 0.5 ms between the regions, %.3f ms, are not part of the span)" % (big_gaps / 1e6))
 print("span %.3f ms | >=1 kernel running %.3f ms (%.1f%%) | >=2 running %.3f ms (%.1f%%) | sum of kernel durations %.3f ms (%.2fx the span)" % (
     span / 1e6, busy1 / 1e6, 100.0 * busy1 / span, busy2 / 1e6, 100.0 * busy2 / span, tot / 1e6, tot / span))
 per = {}
