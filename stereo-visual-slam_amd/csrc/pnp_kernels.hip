@@ -12,8 +12,8 @@
 //                       (144 sums of 10 products); hands M^T M and the per-hypothesis constants on through a structure-of-arrays
 //                       workspace (hypothesis index fastest: coalesced for lane-per-hypothesis kernels);
 //   epnp_jacobi_kernel  the 12 x 12 symmetric eigenproblem, the only O(n^3) piece, EIGHT HYPOTHESES PER WAVE in LDS: cyclic Jacobi with a
-//                       round-robin ordering, 6 disjoint rotations per hypothesis and round (48 lanes compute a rotation each), then the
-//                       three element-parallel updates (J^T A, (.) J, V J) of 8 x 144 elements = 18 per lane;
+//                       round-robin ordering, 6 disjoint rotations per hypothesis and round; a lane owns one rotation (48 of 64 lanes) and applies
+//                       it to its two rows (J^T A), then to its two columns of A and V ((.) J, V J): two barriers per round;
 //   epnp_back_kernel    ONE LANE PER HYPOTHESIS again: L (6 x 10), rho, and for N = 1, 2, 3 the betas (Householder least squares), five
 //                       Gauss-Newton steps, absolute orientation (3 x 3 Jacobi) and the reprojection error; best of the three.
 // Every floating-point operation is performed in the same order as the CPU oracle's restatement, with IEEE division / sqrt and
@@ -295,77 +295,71 @@ __global__ __launch_bounds__(64) void epnp_front_kernel(const float* __restrict_
     for (int i = 0; i < 12; ++i) w[(size_t)(kWsCws + i) * Hs] = cws[i / 3][i % 3];
 }
 
-// one wave = kJacG hypotheses.  A round: (0) lane 6 g + k computes rotation k of hypothesis g from A; (1) B = J^T A and V' = V J into registers,
-// written back in place once every lane has read; (2) A = B J the same way.  Each element sees the operations of the sequential solver in
-// its order (an element is touched by exactly one rotation per side and round).
+// one wave = kJacG hypotheses; lane 6 g + k owns rotation k of hypothesis g for the round (48 of the 64 lanes).  A round: the owner computes (c, s)
+// from its pair's rows, then B = J^T A on ITS two rows (nobody else touches them: no exchange, (c, s) stay in registers); barrier; A = B J and
+// V = V J on ITS two columns; barrier.  Each element sees the operations of the sequential solver in its order (an element is touched by
+// exactly one rotation per side and round): B[p][j] = c A[p][j] - s A[q][j], B[q][j] = c A[q][j] + s A[p][j], likewise for the columns.
+// (First version of this kernel: all 64 lanes, 18 flat elements each, the rotations handed over through LDS tables -- 324 LDS instructions and five
+// barriers per round against 120 and two here; 1.44 ms per 25.5 k hypotheses.)
 __global__ __launch_bounds__(64) void epnp_jacobi_kernel(int H, int Hs, double* __restrict__ ws, const int32_t* __restrict__ ok) {
-    __shared__ double A[kJacG * 144], V[kJacG * 144];
-    __shared__ double cc[kJacG * 12], ss[kJacG * 12];
-    __shared__ int partner[kJacG * 12];
+    __shared__ __attribute__((aligned(16))) double A[kJacG * 144];
+    __shared__ __attribute__((aligned(16))) double V[kJacG * 144];
     const int lane = threadIdx.x, h0 = blockIdx.x * kJacG;
     constexpr int kPer = kJacG * 144 / 64; // 18
-    static_assert(kJacG * 144 % 64 == 0, "elements per lane");
+    static_assert(kJacG * 144 % 64 == 0 && 6 * kJacG <= 64, "elements per lane / one lane per rotation");
     int any = 0;
     if (lane < kJacG && h0 + lane < H) any = ok[h0 + lane];
     if (__ballot(any != 0) == 0) return; // (uniform) nothing to solve in this group
-    // element u of this lane: flat = lane + 64 u -> hypothesis g = flat / 144, (i, j) inside its matrix
-    int eg[kPer], ei[kPer], ej[kPer];
 #pragma unroll
-    for (int u = 0; u < kPer; ++u) {
+    for (int u = 0; u < kPer; ++u) { // flat = lane + 64 u -> hypothesis flat / 144, element flat % 144
         const int flat = lane + 64 * u, g = flat / 144, e = flat - 144 * g;
-        eg[u] = g; ei[u] = e / 12; ej[u] = e - 12 * (e / 12);
         const int h = min(h0 + g, H - 1);
         A[flat] = ws[(size_t)(kWsMtM + e) * Hs + h];
-        V[flat] = ei[u] == ej[u] ? 1.0 : 0.0;
+        V[flat] = (e / 12) == (e % 12) ? 1.0 : 0.0;
     }
     __syncthreads();
+    const bool own = lane < 6 * kJacG;
+    const int g = own ? lane / 6 : 0, k = lane - 6 * (lane / 6);
+    double* Ag = A + 144 * g;
+    double* Vg = V + 144 * g;
     for (int sweep = 0; sweep < kSweeps12; ++sweep)
         for (int round = 0; round < 11; ++round) {
-            if (lane < 6 * kJacG) {
-                const int g = lane / 6, k = lane - 6 * g;
-                int p, q; double c, s;
-                rr_pair(round, k, p, q);
-                const double* Ag = A + 144 * g;
+            int p, q; double c = 1.0, s = 0.0;
+            rr_pair(round, k, p, q);
+            if (own) {
                 jacobi_cs(Ag[p * 12 + p], Ag[q * 12 + q], Ag[p * 12 + q], c, s);
-                partner[12 * g + p] = q; partner[12 * g + q] = p; cc[12 * g + p] = c; cc[12 * g + q] = c; ss[12 * g + p] = -s; ss[12 * g + q] = s;
+                double rp[12], rq[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) { rp[j] = Ag[p * 12 + j]; rq[j] = Ag[q * 12 + j]; }
+#pragma unroll
+                for (int j = 0; j < 12; ++j) { Ag[p * 12 + j] = c * rp[j] - s * rq[j]; Ag[q * 12 + j] = c * rq[j] + s * rp[j]; }
             }
             __syncthreads();
-            double tb[kPer], tv[kPer];
+            if (own) {
 #pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int g = eg[u], i = ei[u], j = ej[u], el = lane + 64 * u;
-                tb[u] = cc[12 * g + i] * A[el] + ss[12 * g + i] * A[144 * g + partner[12 * g + i] * 12 + j];
-                tv[u] = cc[12 * g + j] * V[el] + ss[12 * g + j] * V[144 * g + i * 12 + partner[12 * g + j]];
+                for (int i = 0; i < 12; ++i) {
+                    const double bp = Ag[i * 12 + p], bq = Ag[i * 12 + q], vp = Vg[i * 12 + p], vq = Vg[i * 12 + q];
+                    Ag[i * 12 + p] = c * bp - s * bq; Ag[i * 12 + q] = c * bq + s * bp;
+                    Vg[i * 12 + p] = c * vp - s * vq; Vg[i * 12 + q] = c * vq + s * vp;
+                }
             }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) { A[lane + 64 * u] = tb[u]; V[lane + 64 * u] = tv[u]; }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int g = eg[u], i = ei[u], j = ej[u], el = lane + 64 * u;
-                tb[u] = cc[12 * g + j] * A[el] + ss[12 * g + j] * A[144 * g + i * 12 + partner[12 * g + j]];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) A[lane + 64 * u] = tb[u];
             __syncthreads();
         }
     // the four eigenvectors of the smallest eigenvalues, in ascending order (stable selection)
     if (lane < kJacG && h0 + lane < H) {
-        const double* Ag = A + 144 * lane;
-        const double* Vg = V + 144 * lane;
+        const double* Al = A + 144 * lane;
+        const double* Vl = V + 144 * lane;
         int ord[12];
         for (int i = 0; i < 12; ++i) ord[i] = i;
         for (int a = 0; a < 4; ++a) {
             int best = a;
-            for (int b = a + 1; b < 12; ++b) if (Ag[ord[b] * 13] < Ag[ord[best] * 13]) best = b;
+            for (int b = a + 1; b < 12; ++b) if (Al[ord[b] * 13] < Al[ord[best] * 13]) best = b;
             const int tmp = ord[best];
             for (int b = best; b > a; --b) ord[b] = ord[b - 1];
             ord[a] = tmp;
         }
         double* w = ws + h0 + lane;
-        for (int i = 0; i < 4; ++i) for (int r = 0; r < 12; ++r) w[(size_t)(kWsV + 12 * i + r) * Hs] = Vg[r * 12 + ord[i]];
+        for (int i = 0; i < 4; ++i) for (int r = 0; r < 12; ++r) w[(size_t)(kWsV + 12 * i + r) * Hs] = Vl[r * 12 + ord[i]];
     }
 }
 
