@@ -130,6 +130,7 @@ struct LmKernelArgs {
     uint8_t* lcnt;    // total_lm: observations of an ACTIVE landmark, 0 = not in the graph
     int dinv_lds;     // landmarks per window whose Dinv is kept in dynamic LDS (0 = none)
     int want_chi2;    // the caller passed a chi2 output array: scatter chi2 back to its edge order at the end
+    const int32_t* order; // n_windows: workgroup i takes window order[i] (largest first, lm_order_kernel), or null: window i
 };
 
 __device__ inline double wave_sum(double v) {
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                                                             int classify, int reuse_csr) {
     const LmWindowArgs& a = ka.a;
     __shared__ LmShared sm;
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // tell the compiler it is wave-uniform: wave-indexed control flow goes scalar
     int prio_cnt = 0; (void)prio_cnt;
     // keyframes of this window: a.n_kf slots (the pose stride), of which window w uses the first n_kf_w[w] (a growing map)
@@ -1722,7 +1723,7 @@ struct PoShared {
 __global__ __launch_bounds__(kPoBlock) void pose_only_wave_kernel(LmKernelArgs ka, int iters, int update_poses) {
     const LmWindowArgs& a = ka.a;
     __shared__ PoShared sm;
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (ka.status[w] != VSLAM_OK) return; // uniform: the first pass of the schedule rejected this window
     long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + kDbgSlots * (size_t)w : nullptr; // tuning aid (VSLAM_LM_PROFILE=1): slots 0..8 of this pass
@@ -2055,6 +2056,7 @@ static int carve(LmScratch& g_lm, LmKernelArgs& ka, size_t total_lm, size_t tota
     const size_t o_suv = need; need += with_lm ? al(total_lm * kLmSlots * 8) : 256;
     const size_t o_skf = need; need += with_lm ? al(total_lm * kLmSlots) : 256;
     const size_t o_lcnt = need; need += al(total_lm);
+    const size_t o_ord = need; need += al((size_t)n_windows * 4);
     // hipFree/hipMalloc are synchronising; growth only happens on the first call of a given size
     if (g_lm.bytes < need) { hipStreamSynchronize(stream); int rc = ensure(&g_lm.buf, &g_lm.bytes, need); if (rc) return rc; }
     uint8_t* base = (uint8_t*)g_lm.buf;
@@ -2067,7 +2069,37 @@ static int carve(LmScratch& g_lm, LmKernelArgs& ka, size_t total_lm, size_t tota
     if (!ka.a.chi2) ka.a.chi2 = (double*)(base + o_chi);
     ka.chi2k = (double*)(base + o_chik); ka.uvk = (float*)(base + o_uvk);
     ka.slot_uv = (float*)(base + o_suv); ka.slot_kf = base + o_skf; ka.lcnt = base + o_lcnt;
+    ka.order = (const int32_t*)(base + o_ord); // (filled by lm_order_kernel when the launcher wants it; cleared to null otherwise)
     return VSLAM_OK;
+}
+
+// Largest window first.  A batch has more windows than the chip has CUs (one workgroup per CU), a window's time grows with its edge count, and
+// the hardware hands the next workgroup to the first CU that frees up: in batch order a big window can be the last one started and the
+// whole launch waits for it while 255 CUs idle; in descending order the last ones started are the smallest (longest-processing-time-first list
+// scheduling).  One workgroup sorts (edge count descending, window index ascending) keys in LDS; which workgroup computes a window changes nothing
+// in its result.
+#ifndef VSLAM_LM_LPT
+#define VSLAM_LM_LPT 1
+#endif
+constexpr int kOrderCap = 4096;
+__global__ __launch_bounds__(1024) void lm_order_kernel(const int32_t* __restrict__ edge_off, int n, int32_t* __restrict__ order) {
+    __shared__ unsigned long long key[kOrderCap];
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += 1024)
+        key[i] = i < n ? ((unsigned long long)(0xFFFFFFFFu - (unsigned)max(edge_off[i + 1] - edge_off[i], 0)) << 32) | (unsigned)i : ~0ull;
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < np2 / 2; t += 1024) {
+                const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long x = key[lo], y = key[hi];
+                if ((x > y) == up) { key[lo] = y; key[hi] = x; }
+            }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) order[i] = (int32_t)(key[i] & 0xFFFFFFFFu);
 }
 
 int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms, LmScratch* scratch,
@@ -2094,6 +2126,9 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     int rc = carve(*scratch, ka, total_lm, total_edge, a.n_windows, true, stream);
     if (rc) return rc;
     ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1);
+    if (VSLAM_LM_LPT && a.n_windows > 1 && a.n_windows <= kOrderCap)
+        hipLaunchKernelGGL(lm_order_kernel, dim3(1), dim3(1024), 0, stream, a.edge_off, a.n_windows, const_cast<int32_t*>(ka.order));
+    else ka.order = nullptr;
     if (schedule) {
         // run_vslam.cpp:58-71: optimize_map(5) x2 without write-back, optimize_map(10) writing poses, optimize_pose_only(10)
         hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0);
@@ -2154,6 +2189,7 @@ int launch_pnp(const PnpArgs& p, LmScratch* scratch, hipStream_t stream) {
     const size_t tot = (size_t)p.B * p.capacity;
     int rc = carve(*scratch, ka, tot, tot, p.B, false, stream);
     if (rc) return rc;
+    ka.order = nullptr; // (problem b runs on workgroup b)
     ProfScope prof__(stream, "lm_window_kernel<pnp>", 2);
     hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0, 0);
     hipLaunchKernelGGL(pnp_inlier_kernel, dim3(p.B), dim3(256), 0, stream, p.xyz, p.uv, p.n, p.capacity, p.T, p.K[0], p.K[1], p.K[2], p.K[3],
