@@ -86,6 +86,7 @@ constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work 
 #endif
 constexpr int kDbgSlots = 24;               // phase cycle counters per window (VSLAM_LM_PROFILE)
 constexpr int kLmSlots = VSLAM_LM_SLOTS;    // observations per landmark kept in the slot table (the rest is reached through the CSR)
+constexpr int kRowCap = 512;                // 64-landmark rows with a slot-width entry in LDS (32 768 landmarks per window)
 
 size_t lm_hits_per_edge() { return kHitsPerEdge; }
 
@@ -108,6 +109,8 @@ struct alignas(16) LmShared {
     int flag[8];
     int pairp[kMaxPairs + 2];              // pair_ptr (first hit of every keyframe pair): read at every Schur item start -- from global memory that
                                            // was one dependent round trip per item before its first operand could even be requested
+    uint8_t rowmax[kRowCap];               // most observations of an active landmark among landmarks [64 r, 64 r + 64): the landmark-wise phases fetch
+                                           // slot q of a row only if q < rowmax[r] (rows beyond kRowCap: all slots)
 };
 static_assert(kMaxKf * kPoseParts >= kMaxKf + kLmWaves - 1, "part[] must hold one slot per (keyframe, wave) segment");
 static_assert(kLmWaves <= 16, "cnt rows");
@@ -132,6 +135,12 @@ struct LmKernelArgs {
     int want_chi2;    // the caller passed a chi2 output array: scatter chi2 back to its edge order at the end
     const int32_t* order; // n_windows: workgroup i takes window order[i] (largest first, lm_order_kernel), or null: window i
 };
+
+// slots of the landmark-wise slot table worth fetching for the 64-landmark row that starts at landmark `first` (wave-uniform)
+__device__ inline int slot_width(const uint8_t* rowmax, int first) {
+    const int row = first >> 6;
+    return __builtin_amdgcn_readfirstlane(row < kRowCap ? (int)rowmax[min(row, kRowCap - 1)] : kLmSlots);
+}
 
 __device__ inline double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -565,6 +574,15 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
 #pragma unroll
         for (int u = 0; u < 3; ++u)
             if (l0 + u * kLmBlock < nl) { act[l0 + u * kLmBlock] = on[u]; if (!IMPL) lcnt[l0 + u * kLmBlock] = on[u] ? (uint8_t)min(cn[u], 255) : 0; }
+        if (!IMPL) { // (a wave's lanes hold 64 consecutive, aligned landmarks per u: one row of the slot table)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                int m = (l0 + u * kLmBlock < nl && on[u]) ? min(cn[u], 255) : 0;
+                for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+                const int row = (l0 - lane + u * kLmBlock) >> 6;
+                if (lane == 0 && row < kRowCap && l0 + u * kLmBlock < nl) sm.rowmax[row] = (uint8_t)m;
+            }
+        }
     }
     // Slot table of the landmark-wise phases: observation q < kLmSlots of landmark l at [q * nl + l].  A lane that owns landmark l
     // fetches its position, its count and its first observations in ONE round trip, coalesced across the lanes (through the CSR it
@@ -973,8 +991,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                     const int l = min(l0 + u * kLmBlock, nl - 1);
                     cn[u] = lcnt[l];
                     px[u] = PC(P, 0, l); py[u] = PC(P, 1, l); pz[u] = PC(P, 2, l);
+                    const int rm = slot_width(sm.rowmax, l0 - lane + u * kLmBlock); // (uniform)
+                    // (slots nobody in the row has are redirected to slot 0, whose lines this batch fetches anyway: plain loads, all in flight
+                    // together -- a branch around them cost 3-8 % (the compiler waits per branch) -- and no line of the unused slots is touched)
 #pragma unroll
-                    for (int q = 0; q < kLmE; ++q) { kk[u][q] = skf[(size_t)q * nl + l]; zz[u][q] = suv[(size_t)q * nl + l]; }
+                    for (int q = 0; q < kLmE; ++q) { const size_t qo = (size_t)(q < rm ? q : 0) * nl + l; kk[u][q] = skf[qo]; zz[u][q] = suv[qo]; }
                 }
 #pragma unroll
                 for (int u = 0; u < kLmU; ++u) on[u] = cn[u] > 0 && l0 + u * kLmBlock < nl;
@@ -1381,8 +1402,9 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
                         loadD_row(l, da, dbb, dc); // (first: behind the batch's global loads its LDS reads would wait for all of them)
                         Dq[u][0] = da.x; Dq[u][1] = da.y; Dq[u][2] = dbb.x; Dq[u][3] = dbb.y; Dq[u][4] = dc.x; Dq[u][5] = dc.y;
                         cn[u] = lcnt[l];
+                        const int rm = slot_width(sm.rowmax, l0 - lane + u * kLmBlock); // (uniform)
 #pragma unroll
-                        for (int q = 0; q < kLmE; ++q) { kk[u][q] = skf[(size_t)q * nl + l]; zz[u][q] = suv[(size_t)q * nl + l]; }
+                        for (int q = 0; q < kLmE; ++q) { const size_t qo = (size_t)(q < rm ? q : 0) * nl + l; kk[u][q] = skf[qo]; zz[u][q] = suv[qo]; }
                         px[u] = PC(P, 0, l); py[u] = PC(P, 1, l); pz[u] = PC(P, 2, l);
                         g0[u] = PC(bl, 0, l); g1[u] = PC(bl, 1, l); g2[u] = PC(bl, 2, l);
                     }
