@@ -313,8 +313,13 @@ int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf,
 
 /* per-window status of the most recent window launch on this process (VSLAM_OK or VSLAM_ERR_ARG per window) */
 int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status);
+/* optimize_map passes the most recent vslam_ba_batch_dev(schedule = 1) call EXECUTED per window: 3 = all of run_vslam.cpp:61-66; 1 or 2 = the
+ * window's first / second pass flagged no new landmark, so the following passes would have repeated it bit for bit (all passes start from the same
+ * poses and landmarks; only the flags carry over) and it was continued to the last pass's 10 iterations instead -- same result, 10 or 15 LM
+ * iterations instead of 20.  vslam_set_tuning(ctx, "ba_adaptive", 0) runs every pass.  Synchronises the context stream. */
+int vslam_ba_schedule_passes_dev(vslam_ctx* ctx, int n_windows, int32_t* h_passes);
 /* Kernel-choice overrides of a context (tuning aid, and how the tests force every kernel path): name in {"orb_fuse_min", "sgbm_fuse_min",
- * "sgbm_fwd_min" (items per call from which the fused kernel is used), "sgbm_fw_rows" (32 | 64), "pose_only_window", "pnp_window" (0 | 1)};
+ * "sgbm_fwd_min" (items per call from which the fused kernel is used), "sgbm_fw_rows" (32 | 64), "pose_only_window", "pnp_window", "ba_adaptive" (0 | 1)};
  * value -1 = the library's batch-size rule.  vslam_create seeds them once from the environment variables VSLAM_<NAME> (an unparsable
  * or out-of-range value makes vslam_create fail with VSLAM_ERR_ARG); nothing reads the environment afterwards. */
 int vslam_set_tuning(vslam_ctx* ctx, const char* name, int value);

@@ -109,6 +109,7 @@ static const TuneKey kTuneKeys[] = {
     {"sgbm_fw_rows", "VSLAM_SGBM_FW_ROWS", &Tuning::sgbm_fw_rows, 32, 64},
     {"pose_only_window", "VSLAM_POSE_ONLY_WINDOW", &Tuning::pose_only_window, 0, 1},
     {"pnp_window", "VSLAM_PNP_WINDOW", &Tuning::pnp_window, 0, 1},
+    {"ba_adaptive", "VSLAM_BA_ADAPTIVE", &Tuning::ba_adaptive, 0, 1},
 };
 static int tune_set(Tuning& t, const TuneKey& k, long v) {
     if (v == -1) { t.*(k.field) = -1; return VSLAM_OK; } // back to the library's rule
@@ -972,6 +973,13 @@ int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status) {
     if (!c || !h_status || n_windows <= 0) return VSLAM_ERR_ARG;
     VS_ENTER(c);
     return lm_fetch_status(&c->lm, n_windows, h_status, c->stream);
+}
+
+int vslam_ba_schedule_passes_dev(vslam_ctx* ctx, int n_windows, int32_t* h_passes) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !h_passes || n_windows <= 0) return VSLAM_ERR_ARG;
+    VS_ENTER(c);
+    return lm_fetch_passes(&c->lm, n_windows, h_passes, c->stream);
 }
 
 // ---------------------------------------------------------------------------------------------- profiling + glue

@@ -86,6 +86,7 @@ constexpr int kItemSlots = (kMaxPairs + kLmWaves - 1) / kLmWaves; // Schur work 
 #endif
 constexpr int kDbgSlots = 24;               // phase cycle counters per window (VSLAM_LM_PROFILE)
 constexpr int kLmSlots = VSLAM_LM_SLOTS;    // observations per landmark kept in the slot table (the rest is reached through the CSR)
+constexpr int kSchedFinalIters = 10;        // iterations of the schedule's last optimize_map pass (run_vslam.cpp:66)
 constexpr int kRowCap = 512;                // 64-landmark rows with a slot-width entry in LDS (32 768 landmarks per window)
 
 size_t lm_hits_per_edge() { return kHitsPerEdge; }
@@ -134,6 +135,7 @@ struct LmKernelArgs {
     int dinv_lds;     // landmarks per window whose Dinv is kept in dynamic LDS (0 = none)
     int want_chi2;    // the caller passed a chi2 output array: scatter chi2 back to its edge order at the end
     const int32_t* order; // n_windows: workgroup i takes window order[i] (largest first, lm_order_kernel), or null: window i
+    int32_t* passes;      // n_windows: optimize_map passes of the current schedule that were EXECUTED for the window (0 while it is still open; see `sched`)
 };
 
 // slots of the landmark-wise slot table worth fetching for the 64-landmark row that starts at landmark `first` (wave-uniform)
@@ -424,7 +426,7 @@ __device__ inline double row_dot_sub(double v, const double* a, const double* b,
 
 template <bool IMPL>
 __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel(LmKernelArgs ka, int mode, int iters, int update_poses, int update_lms,
-                                                            int classify, int reuse_csr) {
+                                                            int classify, int reuse_csr, int sched) {
     const LmWindowArgs& a = ka.a;
     __shared__ LmShared sm;
     const int w = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -500,8 +502,24 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     double* recW_alt = lin + (size_t)ne;
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
 
+    // In-kernel ADAPTIVE schedule (sched == 1; run_vslam.cpp:58-71 = optimize_map(5), optimize_map(5), optimize_map(10), the first two without
+    // write-back).  Every pass starts from the SAME poses and landmarks; only the landmark flags carry over.  A pass whose classification flags
+    // nothing new therefore leaves the next pass the inputs it had itself: the next 5-iteration pass would repeat it bit for bit (the kernel is
+    // deterministic) and the 10-iteration pass would repeat its 5 iterations and then run 5 more.  Such a pass is simply CONTINUED to 10 iterations,
+    // classified again and written back -- it IS the last pass -- and the window is done: 10 or 15 LM iterations instead of 20, results identical
+    // to the plain schedule's (tests/test_gpu_lm.py::test_adaptive_schedule_is_bit_identical).  The passes of a window run back to back in ONE
+    // launch: a window that is done frees its CU for the next window at once (three launches would wait for the slowest window three times).
+    const int iters_early = iters, reuse_csr0 = reuse_csr;
+    const int npass = (!IMPL && sched == 1) ? 3 : 1;
+    bool done = false;       // (uniform) the schedule's last pass has been run, as a continued early pass
+    int pass = 0;
+    for (; pass < npass && !done; ++pass) {
+    if (!IMPL && sched == 1) {
+        iters = pass < 2 ? iters_early : kSchedFinalIters; update_poses = pass == 2; reuse_csr = reuse_csr0 || pass > 0;
+        if (pass > 0) __syncthreads(); // (the classification of the previous pass wrote the flags this pass's setup reads)
+    }
     // ------------------------------------------------------------------ setup
-    if (reuse_csr && ka.status[w] != VSLAM_OK) return; // a later launch of the schedule: the first one rejected this window's indices
+    if (reuse_csr0 && ka.status[w] != VSLAM_OK) return; // a later launch of the schedule: the first one rejected this window's indices
     if (tid < 8) sm.flag[tid] = 0;
     for (int i = tid; i < nk * 7; i += kLmBlock) sm.T[i] = a.T[Tbase + i];
     for (int i = tid; i < kLmWaves * kCntStride; i += kLmBlock) sm.cnt[i] = 0;
@@ -964,7 +982,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // cache two CUs share, so there is ONE call site: the initial state is evaluated by a pseudo-iteration (it = -1, "boot")
     // that skips the solve and runs the trial evaluation on the current buffers.  Every later iteration starts from an
     // accepted trial, which is already evaluated and linearised.
-    for (it = iters > 0 ? -1 : 0; it < iters; ++it) {
+    int bound = iters;       // iterations of this pass; raised to kSchedFinalIters when an adaptive pass is continued; 0 once the loop has ended by
+                             // g2o's own rule (ten failed trials / zero gain): more iterations would not run either
+    it = iters > 0 ? -1 : 0;
+    for (;;) { // (at most twice: a continued pass re-enters the loop where it left it)
+    for (; it < bound; ++it) {
         const bool boot = it < 0;
         PH(1);
         if (it == 0 && st && tid == 0) st->chi2_init = currentChi;
@@ -1495,13 +1517,14 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         if (boot) continue;
         total_trials += qmax;
         if (st && tid == 0 && it < VSLAM_LM_MAX_ITERS) { st->chi2_iter[it] = currentChi; st->lambda_iter[it] = lambda; st->trials_iter[it] = qmax; }
-        if (qmax == 10 || rho_gain == 0) { ++it; break; }
+        if (qmax == 10 || rho_gain == 0) { ++it; bound = 0; break; }
     }
     if (st && tid == 0) { st->iterations = it; st->total_trials = total_trials; st->chi2_final = currentChi; st->lambda_final = lambda; }
 
     PH(11);
     if (last_trial_is_current) chi_pass(sm.Rt, P); else chi_pass(sm.RtTrial, with_lm ? Pt : P);
     // ------------------------------------------------------------------ chi2 classification (optimization.cpp:224-266)
+    int newly_flagged = 0;   // this thread cleared the flag of a landmark that entered the pass flagged in
     if (classify && !IMPL) {
         double th = delta; // optimization.cpp:154: chi2_th is both the Huber delta and the initial classification threshold
         for (int iteration = 0; iteration < 5; ++iteration) {
@@ -1529,9 +1552,21 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             for (int u = 0; u < 4; ++u) cv[u] = chi2k[min(max(pp[u], 0), max(ne - 1, 0))];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (l0 + u * kLmBlock < nl && av[u]) a.lm_inlier[lm0 + la[u]] = !(cv[u] > th);
+                if (l0 + u * kLmBlock < nl && av[u]) { const bool keep = !(cv[u] > th); a.lm_inlier[lm0 + la[u]] = keep; newly_flagged |= !keep; } // (active = flagged in on entry)
         }
         if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
+    }
+    if (!IMPL && sched == 1 && pass < 2) {
+        if (!done) { // (done: this was the continuation -- the last pass, whatever its own classification flagged)
+            const bool repeatable = __syncthreads_or(newly_flagged) == 0; // (uniform) the next pass would see the inputs this one saw
+            if (repeatable) {
+                done = true; update_poses = 1;
+                if (bound > 0 && bound < kSchedFinalIters) { bound = kSchedFinalIters; continue; } // continue it as the last pass
+                // (bound == 0: the loop stopped by its own rule; the last pass would stop there too -- this state is the result)
+            }
+        }
+    }
+    break;
     }
     // ------------------------------------------------------------------ write-back (:272-287, :429-435)
     __syncthreads();
@@ -1542,6 +1577,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         for (int l = tid; l < nl; l += kLmBlock)
             if (act[l]) { a.xyz[3 * ((size_t)lm0 + l)] = (float)PC(P, 0, l); a.xyz[3 * ((size_t)lm0 + l) + 1] = (float)PC(P, 1, l); a.xyz[3 * ((size_t)lm0 + l) + 2] = (float)PC(P, 2, l); }
     PH(12);
+    } // passes
+    if (!IMPL && sched == 1 && tid == 0) ka.passes[w] = pass; // passes executed: 1 or 2 = an early pass was continued as the last one
     if (tid == 0) ka.status[w] = VSLAM_OK;
 #undef PH
 #undef PC
@@ -2079,6 +2116,7 @@ static int carve(LmScratch& g_lm, LmKernelArgs& ka, size_t total_lm, size_t tota
     const size_t o_skf = need; need += with_lm ? al(total_lm * kLmSlots) : 256;
     const size_t o_lcnt = need; need += al(total_lm);
     const size_t o_ord = need; need += al((size_t)n_windows * 4);
+    const size_t o_pass = need; need += al((size_t)n_windows * 4);
     // hipFree/hipMalloc are synchronising; growth only happens on the first call of a given size
     if (g_lm.bytes < need) { hipStreamSynchronize(stream); int rc = ensure(&g_lm.buf, &g_lm.bytes, need); if (rc) return rc; }
     uint8_t* base = (uint8_t*)g_lm.buf;
@@ -2092,6 +2130,7 @@ static int carve(LmScratch& g_lm, LmKernelArgs& ka, size_t total_lm, size_t tota
     ka.chi2k = (double*)(base + o_chik); ka.uvk = (float*)(base + o_uvk);
     ka.slot_uv = (float*)(base + o_suv); ka.slot_kf = base + o_skf; ka.lcnt = base + o_lcnt;
     ka.order = (const int32_t*)(base + o_ord); // (filled by lm_order_kernel when the launcher wants it; cleared to null otherwise)
+    ka.passes = (int32_t*)(base + o_pass); g_lm.passes = ka.passes;
     return VSLAM_OK;
 }
 
@@ -2103,6 +2142,7 @@ static int carve(LmScratch& g_lm, LmKernelArgs& ka, size_t total_lm, size_t tota
 #ifndef VSLAM_LM_LPT
 #define VSLAM_LM_LPT 1
 #endif
+__global__ void lm_fill_kernel(int32_t* __restrict__ p, int n, int v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 constexpr int kOrderCap = 4096;
 __global__ __launch_bounds__(1024) void lm_order_kernel(const int32_t* __restrict__ edge_off, int n, int32_t* __restrict__ order) {
     __shared__ unsigned long long key[kOrderCap];
@@ -2147,24 +2187,32 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     }
     int rc = carve(*scratch, ka, total_lm, total_edge, a.n_windows, true, stream);
     if (rc) return rc;
-    ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1);
+    ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1); // (launch-set size as in every earlier round; the adaptive schedule issues 2 launches)
     if (VSLAM_LM_LPT && a.n_windows > 1 && a.n_windows <= kOrderCap)
         hipLaunchKernelGGL(lm_order_kernel, dim3(1), dim3(1024), 0, stream, a.edge_off, a.n_windows, const_cast<int32_t*>(ka.order));
     else ka.order = nullptr;
     if (schedule) {
         // run_vslam.cpp:58-71: optimize_map(5) x2 without write-back, optimize_map(10) writing poses, optimize_pose_only(10)
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0);
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 1); // (the landmark CSR of the first launch is still valid)
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 10, 1, 0, 1, 1);
+        // Tuning::ba_adaptive (default on): ONE launch runs a window's passes back to back, and a pass that flags nothing new is continued to the last pass's
+        // 10 iterations instead of being repeated (see the kernel); 0: the three passes as three launches, every one of them for every window
+        const bool adaptive = !(scratch->tune && scratch->tune->ba_adaptive == 0);
+        if (adaptive) {
+            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0, 1);
+        } else {
+            hipLaunchKernelGGL(lm_fill_kernel, dim3((a.n_windows + 255) / 256), dim3(256), 0, stream, ka.passes, a.n_windows, 3);
+            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0, 0);
+            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 1, 0); // (the landmark CSR of the first launch is still valid)
+            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, kSchedFinalIters, 1, 0, 1, 1, 0);
+        }
         // the pose-only pass: one wave per keyframe (pose_only_wave_kernel); Tuning::pose_only_window = 1 (tuning aid / cross-check test) keeps the window kernel
         const bool po_window = scratch->tune && scratch->tune->pose_only_window > 0;
-        if (po_window) hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1);
+        if (po_window) hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1, 0);
         else {
             if (ka.dbg_cycles && getenv("VSLAM_PO_PROFILE")) hipMemsetAsync(ka.dbg_cycles, 0, sizeof(long long) * kDbgSlots * a.n_windows, stream); // show only this pass
             hipLaunchKernelGGL(pose_only_wave_kernel, dim3(a.n_windows), dim3(kPoBlock), 0, stream, ka, 10, 1);
         }
     } else {
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, mode, iters, update_poses, update_lms, 1, 0);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, mode, iters, update_poses, update_lms, 1, 0, 0);
     }
     VS_HIP(hipGetLastError());
     if (ka.dbg_cycles) {
@@ -2177,6 +2225,13 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         for (int i = 0; i < kDbgSlots; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[kDbgSlots * (size_t)w + i]; s /= a.n_windows; if (i < 13 || i >= 16) tot += s; fprintf(stderr, "  [lm profile] %-20s %10.0f ticks/window\n", names[i], s); }
         fprintf(stderr, "  [lm profile] total %.0f cycles (clock64 = shader clock, thread 0 of every window; setup sub-splits not included)\n", tot);
     }
+    return VSLAM_OK;
+}
+
+int lm_fetch_passes(const LmScratch* scratch, int n_windows, int32_t* h_passes, hipStream_t stream) {
+    if (!scratch->buf || !scratch->passes || !h_passes || n_windows > scratch->status_n) return VSLAM_ERR_ARG;
+    VS_HIP(hipMemcpyAsync(h_passes, scratch->passes, sizeof(int32_t) * n_windows, hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
     return VSLAM_OK;
 }
 
@@ -2213,7 +2268,7 @@ int launch_pnp(const PnpArgs& p, LmScratch* scratch, hipStream_t stream) {
     if (rc) return rc;
     ka.order = nullptr; // (problem b runs on workgroup b)
     ProfScope prof__(stream, "lm_window_kernel<pnp>", 2);
-    hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0, 0);
+    hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0, 0, 0);
     hipLaunchKernelGGL(pnp_inlier_kernel, dim3(p.B), dim3(256), 0, stream, p.xyz, p.uv, p.n, p.capacity, p.T, p.K[0], p.K[1], p.K[2], p.K[3],
                        p.reproj_thr * p.reproj_thr, p.inlier, p.n_inliers);
     VS_HIP(hipGetLastError());

@@ -200,6 +200,7 @@ struct Tuning {
     int sgbm_fw_rows = -1;    // VSLAM_SGBM_FW_ROWS: 32 or 64 image rows per slab of the forward sweep
     int pose_only_window = -1; // VSLAM_POSE_ONLY_WINDOW: 1 = the schedule's pose-only pass on lm_window_kernel instead of pose_only_wave_kernel
     int pnp_window = -1;      // VSLAM_PNP_WINDOW: 1 = single-pose problems on lm_window_kernel<pnp> instead of pnp_wave_kernel
+    int ba_adaptive = -1;     // VSLAM_BA_ADAPTIVE: 0 = the BA schedule runs all three optimize_map passes for every window (default: a pass that flags nothing new is continued instead of repeated)
 };
 int launch_sgbm(const Tuning& tune, const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
                 int16_t* d_disp_i16, int16_t* d_disp_raw, uint8_t** scratch, size_t* scratch_bytes, size_t* dev_bytes, hipStream_t stream);
@@ -209,6 +210,7 @@ size_t sgbm_scratch_bytes(int w, int h, int B);
 struct LmScratch {
     void* buf = nullptr; size_t bytes = 0;
     int32_t* status = nullptr; int status_n = 0;
+    int32_t* passes = nullptr; // optimize_map passes executed per window by the most recent schedule (lm_fetch_passes)
     const Tuning* tune = nullptr; // the owning context's overrides
     bool lds_opt_in = false; // the > 64 KB dynamic-LDS attribute of lm_window_kernel has been set on this context's device
 };
@@ -216,6 +218,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
                       hipStream_t stream);
 size_t lm_hits_per_edge();
 int lm_fetch_status(const LmScratch* scratch, int n_windows, int32_t* h_status, hipStream_t stream);
+int lm_fetch_passes(const LmScratch* scratch, int n_windows, int32_t* h_passes, hipStream_t stream);
 
 struct PnpArgs {
     const float* xyz; const float* uv; const int32_t* n; int capacity; int B;

@@ -239,3 +239,52 @@ def test_pnp_ransac_dev_batch_parity(pkg, oracle, synth):
             assert hit == it[b] and hn == ninl[b] and np.array_equal(hinl, winl) and np.array_equal(hT, T[b])
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["tracks", "synthetic", "outliers"])
+def test_adaptive_schedule_is_bit_identical(pkg, synth, kind):
+    """The BA schedule (run_vslam.cpp:58-71: optimize_map(5), optimize_map(5), optimize_map(10), the first two without write-back) starts every
+    pass from the same poses and landmarks; a pass that flags no new landmark is therefore CONTINUED to the last pass's 10 iterations instead of
+    being repeated (lm_window_kernel `sched`).  Poses, flags, chi2 and thresholds must equal, bit for bit, what the plain schedule -- all three
+    passes for every window, vslam_set_tuning("ba_adaptive", 0) -- produces; windows built from real tracks, synthetic windows of the
+    config-4 kind and synthetic windows with gross outliers (passes that do flag)."""
+    import torch
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    B = 24
+    if kind == "tracks":
+        pipe = KeyframePipeline(B, anms_num=1500, unique_frames=12, seed=31, ba_windows="tracks")
+        pipe.stage_orb(); pipe.stage_stereo_match(); pipe.stage_track(); pipe.stage_build_windows()
+    else:
+        pipe = KeyframePipeline(B, anms_num=500, n_lm=800, unique_frames=2, seed=32, ba_windows="synthetic")
+        if kind == "outliers":   # gross observation errors on ~1.5 % of the edges: the first passes flag them, later ones may not
+            uv = pipe.ba_uv.cpu().numpy().copy()
+            rng = np.random.default_rng(5)
+            bad = rng.random(len(uv)) < 0.015
+            uv[bad] += rng.normal(0, 25, (int(bad.sum()), 2)).astype(np.float32)
+            pipe.ba_uv.copy_(torch.from_numpy(uv))
+    try:
+        pipe.vo.sync(); torch.cuda.synchronize()
+        T0, inl0 = pipe.ba_T.clone(), pipe.ba_inl.clone()
+        chi2 = torch.zeros(int(pipe.ba_batch.total_edge), dtype=torch.float64, device=pipe.dev)
+        pipe.ba_batch.d_chi2 = chi2.data_ptr()
+        got = {}
+        for adaptive in (1, 0):
+            pipe.ba_T.copy_(T0); pipe.ba_inl.copy_(inl0); chi2.zero_()
+            torch.cuda.synchronize()
+            pipe.vo.set_tuning(ba_adaptive=adaptive)
+            pipe.vo.ba_batch_dev(pipe.ba_batch, schedule=1)
+            passes = pipe.vo.ba_schedule_passes(B)
+            assert (pipe.vo.ba_status(B) == 0).all()
+            got[adaptive] = (pipe.ba_T.cpu().numpy().copy(), pipe.ba_inl.cpu().numpy().copy(), chi2.cpu().numpy().copy(), passes)
+        assert (got[0][3] == 3).all()                      # plain: every pass ran
+        assert ((got[1][3] >= 1) & (got[1][3] <= 3)).all()
+        print(kind, "passes executed per window:", np.bincount(got[1][3], minlength=4)[1:])
+        if kind == "tracks":
+            assert (got[1][3] < 3).any()                   # real windows: most close after their first or second pass
+        if kind == "outliers":
+            assert (got[1][3] > 1).any() and (got[1][1] == 0).any()
+        for a, b in zip(got[1][:3], got[0][:3]):
+            assert np.array_equal(a, b)
+    finally:
+        pipe.vo.set_tuning(ba_adaptive=-1)
+        pipe.close()
