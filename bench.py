@@ -45,16 +45,32 @@ def algorithmic_bytes(kernel, pipe, anms_num):
     if kernel.startswith("lm_window_kernel<pnp>") or kernel.startswith("pnp_wave_kernel"):
         return (B - 1) * 10 * 20 * 500, "(B-1) x 10 its x 20 B/point x ~500 points"
     if kernel.startswith("lm_window_kernel"):
+        # LM linearisations a window's schedule EXECUTES: 10 of the pose-only pass + 20 of the three optimize_map passes -- or 10 / 15 when the
+        # adaptive schedule continued the window's first / second pass as the last one (pipe.ba_passes, vslam_ba_schedule_passes_dev)
+        passes = getattr(pipe, "ba_passes", None)
+        lin = 10.0 + (np.array([0, 10, 15, 20], np.float64)[np.clip(np.asarray(passes), 0, 3)] if passes is not None else 20.0)
+        lin_txt = "LM linearisations executed (10 pose-only + 10 / 15 / 20 of the optimize_map passes: mean %.1f)" % float(np.mean(lin))
         if getattr(pipe, "ba_shape", None) is not None:  # windows built from the step's tracks: their actual sizes
             E, L, K = (np.asarray(x, np.float64) for x in pipe.ba_shape)
             per_it = E * 16 + L * 12 + K * 56 + (6 * K) ** 2 * 8 + 6 * K * 8 + L * 12
-            return float(per_it.sum()) * 30, "sum over the B built windows of 30 LM linearisations x (E*16 + L*12 + K*56 + (6K)^2*8 + 6K*8 + L*12) B"
+            return float((per_it * lin).sum()), "sum over the B built windows of %s x (E*16 + L*12 + K*56 + (6K)^2*8 + 6K*8 + L*12) B" % lin_txt
         E, L, K = pipe.edges_per_window, pipe.lms_per_window, pipe.n_kf
         per_it = E * 16 + L * 12 + K * 56 + (6 * K) ** 2 * 8 + 6 * K * 8 + L * 12
-        return B * per_it * 30, "B windows x 30 LM linearisations x (E*16 + L*12 + K*56 + (6K)^2*8 + 6K*8 + L*12) B"
+        return float(np.sum(np.broadcast_to(lin, (B,)) * per_it)), "sum over the B windows of %s x (E*16 + L*12 + K*56 + (6K)^2*8 + 6K*8 + L*12) B" % lin_txt
     if kernel.startswith("triangulate"):
         return B * anms_num * 30, "B x N x 30 B"
     return 0, "n/a"
+
+
+def schedule_stats(passes):
+    """what the adaptive BA schedule did (vslam_ba_schedule_passes_dev): windows by passes executed, LM iterations run against the plain 20"""
+    p = np.clip(np.asarray(passes), 0, 3)
+    its = np.array([0, 10, 15, 20], np.float64)[p]
+    return {"windows_by_passes_executed": {"1": int((p == 1).sum()), "2": int((p == 2).sum()), "3": int((p == 3).sum())},
+            "lm_iterations_per_window_mean": round(float(its.mean()), 2), "lm_iterations_of_the_plain_schedule": 20,
+            "rule": "all three optimize_map passes start from the same poses and landmarks (run_vslam.cpp:61-64: the first two do not write back) and differ only "
+                    "by the landmark flags the previous pass left; a pass that flags nothing new is continued to the last pass's 10 iterations instead of "
+                    "being repeated -- bit-identical results (tests/test_gpu_lm.py::test_adaptive_schedule_is_bit_identical; --ba-plain-schedule runs every pass)"}
 
 
 def _sha16(path):
@@ -380,6 +396,14 @@ def ba_config4_measure(args, local, torch):
         prof = pipe.vo.profile_read(); pipe.vo.profile_enable(False)
         if int((pipe.vo.ba_status(B) != 0).sum()):
             return {"error": "windows rejected"}
+        pipe.ba_passes = pipe.vo.ba_schedule_passes(B)
+        pipe.vo.set_tuning(ba_adaptive=0)   # ... and every pass for every window, three launches (the schedule of rounds 1-3)
+        pipe.stage_ba(); pipe.vo.profile_read()
+        pipe.vo.profile_enable(True)
+        for _ in range(n):
+            pipe.stage_ba()
+        prof_plain = pipe.vo.profile_read(); pipe.vo.profile_enable(False)
+        pipe.vo.set_tuning(ba_adaptive=-1)
         ms = prof["lm_window_kernel"][0] / n
         alg, formula = algorithmic_bytes("lm_window_kernel", pipe, 500)
         achieved = alg / (ms / 1e3) / 1e9
@@ -387,6 +411,7 @@ def ba_config4_measure(args, local, torch):
         traffic = int(tj["hbm_bytes_per_launch_set"]) if tj and tj.get("batch") == B and tj.get("kernel") == "lm_window_kernel" else None
         res = {"workload": "BA schedule (5+5+10 LM + 10 pose-only) on %d unique synthetic windows, 10 KF x 3000 landmarks x %.0f edges" % (B, pipe.edges_per_window),
                "ms_per_schedule_batch": round(ms, 4), "wall_ms_per_schedule_batch": round(1e3 * wall, 4), "windows_per_s": round(B / (ms / 1e3), 1),
+               "schedule": schedule_stats(pipe.ba_passes), "plain_schedule_ms_per_batch": round(prof_plain["lm_window_kernel"][0] / n, 4),
                "roofline": {"bound": "hbm", "kernel": "lm_window_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": src,
                             "algorithmic_bytes_per_launch_set": int(alg), "formula": formula},
@@ -447,6 +472,7 @@ def reference_pipeline_measure(args, local, torch, seq, B=256):
                 "one_batch_in_flight": None if el1 is None else {"value": round(B * n / el1, 2), "ms_per_step": round(1e3 * el1 / n, 4)},
                 "kernels_ms_per_step": {k: round(v[0] / n, 4) for k, v in kern[:14]},
                 "kernels_note": "per-kernel durations and the roofline: HIP-event brackets in a repeat with ONE batch in flight",
+                "ba_schedule": schedule_stats(pipe.vo.ba_schedule_passes(B)),
                 "roofline": {"bound": "hbm", "kernel": "sgbm_* (family)", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                              "ms_per_pair": round(fam_ms / B, 4), "algorithmic_bytes_per_launch_set": int(alg),
                              "formula": "B pairs x ((w-96)*h*96*2 B cost volume once + 2*w*h B images in + 4*w*h B f32 disparity out)",
@@ -602,6 +628,9 @@ def main():
     ap.add_argument("--ba-windows", choices=["tracks", "synthetic"], default="tracks",
                     help="tracks (default): the BA windows are built on the device from the step's own matches and poses (one pipeline: window b = "
                          "keyframes [b-9, b] of the batch); synthetic: B canned windows of the BASELINE config-4 shape (10 KF x --landmarks)")
+    ap.add_argument("--ba-plain-schedule", action="store_true",
+                    help="run all three optimize_map passes for every window (three launches) instead of continuing a pass that flags nothing new "
+                         "(vslam_set_tuning ba_adaptive = 0); the default run reports this figure beside the headline")
     ap.add_argument("--no-config4", action="store_true", help="skip the extra BA-only measurement on the config-4 shape")
     ap.add_argument("--pose", choices=["lm", "ransac"], default="lm",
                     help="pose stage: north_star motion-only LM (default, BASELINE metric) or the reference's solvePnPRansac(100, 4.0, 0.99), batched on the device")
@@ -669,6 +698,9 @@ def main():
     pipe = ring.pipes[0]
     dev = pipe.dev
     chained = [None]
+    if args.ba_plain_schedule:
+        for p_ in ring.pipes:
+            p_.vo.set_tuning(ba_adaptive=0)
 
     def one_step(serial=False):
         """one pass of the hot path over one batch; step k runs on pipeline k mod P (serial: always on pipeline 0, i.e. one batch in flight)"""
@@ -715,6 +747,15 @@ def main():
     rep_s = [timed_region(one_step) for _ in range(max(args.repeats, 1))]
     one_step_serial = lambda: one_step(serial=True)
     serial_s = timed_region(one_step_serial) if n_flight > 1 else None   # the same steps with ONE batch in flight (the figure of the earlier rounds)
+    plain_s = None
+    if pipe.with_ba and not args.ba_plain_schedule:   # ... and with the plain BA schedule (every pass for every window: the schedule of the earlier rounds)
+        for p_ in ring.pipes:
+            p_.vo.set_tuning(ba_adaptive=0)
+        one_step(); one_step()
+        plain_s = timed_region(one_step)
+        for p_ in ring.pipes:
+            p_.vo.set_tuning(ba_adaptive=-1)
+        one_step(); one_step()    # (the state every later measurement sees is the default schedule's again)
     # ... and one extra, untimed-for-the-headline repeat of the same `steps` steps WITH it, one batch in flight: per-kernel durations from HIP events
     # on the launch stream (with two batches in flight the kernels of both share the CUs and an event bracket measures the mix)
     pipe.vo.profile_enable(True)
@@ -740,6 +781,7 @@ def main():
 
     if rank == 0:
         out = pipe.download()
+        pipe.ba_passes = pipe.vo.ba_schedule_passes(pipe.B) if pipe.with_ba else None
         flight_same = None
         if len(ring) > 1:   # the pipelines were handed the same images: whatever ran beside them, their results must be the same bits
             keys = ["kps", "desc", "lr", "f2f", "Tpnp", "inl"] + (["ba_T", "ba_inl"] if pipe.with_ba else [])
@@ -823,6 +865,12 @@ def main():
                                      "one_batch_in_flight": None if serial_s is None else {"ms_per_step": round(1e3 * serial_s / args.steps, 4),
                                                                                             "value": round(units_per_step(args, seq_mode, world, B) * args.steps / serial_s, 3)},
                                      "results_identical_across_pipelines": flight_same},
+                       "ba_schedule": None if not pipe.with_ba else dict(
+                           schedule_stats(pipe.ba_passes), mode="plain (--ba-plain-schedule)" if args.ba_plain_schedule else "adaptive (default)",
+                           plain_schedule=None if plain_s is None else {"ms_per_step": round(1e3 * plain_s / args.steps, 4),
+                                                                         "value": round(units_per_step(args, seq_mode, world, B) * args.steps / plain_s, 3),
+                                                                         "how": "the same steps, same batches in flight, with every optimize_map pass run for every window "
+                                                                                "(three launches; vslam_set_tuning ba_adaptive = 0)"}),
                        "stage_profiler": "off in the timed repeats; on in one extra repeat of the same %d steps with ONE batch in flight (%.4f ms/step) that feeds "
                                          "`roofline` and `kernels_ms_per_step`" % (args.steps, 1e3 * profiled_s / args.steps)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -830,7 +878,10 @@ def main():
                          "copy_ceiling_gbs": round(copy_gbs, 1), "copy_probe": copy_probe, "copy_ceiling_guide_gbs": 6290.0, "frac_of_copy_ceiling": round(achieved / copy_gbs, 6) if copy_gbs > 0 else None,
                          "algorithmic_bytes_per_launch_set": int(alg), "formula": formula,
                          "avg_ms_per_launch_set": round(1e3 * per_bracket_s, 4), "kernel_launches_per_set": dom_launches // max(dom_calls, 1),
-                         "launch_set": ("one BA schedule = 3 x lm_window_kernel (optimize_map, 5 + 5 + 10 iterations) + 1 x pose_only_wave_kernel (10 iterations)"
+                         "launch_set": (("one BA schedule = 3 x lm_window_kernel (optimize_map, 5 + 5 + 10 iterations) + 1 x pose_only_wave_kernel (10 iterations)"
+                                         if args.ba_plain_schedule else
+                                         "one BA schedule = 1 x lm_window_kernel (a window's optimize_map passes 5 + 5 + 10 back to back; a pass that flags nothing new is "
+                                         "continued as the last one) + 1 x pose_only_wave_kernel (10 iterations)")
                                         if dom == "lm_window_kernel" else "one stage bracket")},
             "kernels_ms_per_step": {k: round(v[0] / n_prof_steps, 4) for k, v in kern},
             "other_rooflines": other_rooflines(prof, pipe, args, n_prof_steps, copy_gbs),

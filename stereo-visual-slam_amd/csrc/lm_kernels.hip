@@ -2187,15 +2187,15 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     }
     int rc = carve(*scratch, ka, total_lm, total_edge, a.n_windows, true, stream);
     if (rc) return rc;
-    ProfScope prof__(stream, "lm_window_kernel", schedule ? 4 : 1); // (launch-set size as in every earlier round; the adaptive schedule issues 2 launches)
+    // Tuning::ba_adaptive (default on): ONE launch runs a window's passes back to back, and a pass that flags nothing new is continued to the last pass's
+    // 10 iterations instead of being repeated (see the kernel); 0: the three passes as three launches, every one of them for every window
+    const bool adaptive = !(scratch->tune && scratch->tune->ba_adaptive == 0);
+    ProfScope prof__(stream, "lm_window_kernel", schedule ? (adaptive ? 2 : 4) : 1);
     if (VSLAM_LM_LPT && a.n_windows > 1 && a.n_windows <= kOrderCap)
         hipLaunchKernelGGL(lm_order_kernel, dim3(1), dim3(1024), 0, stream, a.edge_off, a.n_windows, const_cast<int32_t*>(ka.order));
     else ka.order = nullptr;
     if (schedule) {
         // run_vslam.cpp:58-71: optimize_map(5) x2 without write-back, optimize_map(10) writing poses, optimize_pose_only(10)
-        // Tuning::ba_adaptive (default on): ONE launch runs a window's passes back to back, and a pass that flags nothing new is continued to the last pass's
-        // 10 iterations instead of being repeated (see the kernel); 0: the three passes as three launches, every one of them for every window
-        const bool adaptive = !(scratch->tune && scratch->tune->ba_adaptive == 0);
         if (adaptive) {
             hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0, 1);
         } else {

@@ -57,6 +57,10 @@ def test_bench_line_contract():
     assert fl["batches"] == 2 and r["config"]["batches_in_flight_per_gpu"] == 2 and fl["results_identical_across_pipelines"] is True
     assert fl["one_batch_in_flight"]["value"] > 0 and r["inputs_from_host"]["batches_in_flight"] == 2
     assert rp["batches_in_flight"] == 2 and rp["one_batch_in_flight"]["value"] > 0
+    # the BA schedule continues a pass that flags nothing new instead of repeating it: the line says what it did and carries the plain schedule's figure
+    bs = r["timing"]["ba_schedule"]
+    assert bs["mode"].startswith("adaptive") and sum(bs["windows_by_passes_executed"].values()) == 16 and 10 <= bs["lm_iterations_per_window_mean"] <= 20
+    assert bs["plain_schedule"]["value"] > 0 and c4["plain_schedule_ms_per_batch"] > 0 and sum(c4["schedule"]["windows_by_passes_executed"].values()) == 256
 
 
 def test_bench_synthetic_windows_and_ransac_pose():
