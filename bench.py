@@ -631,6 +631,7 @@ def main():
     ap.add_argument("--ba-plain-schedule", action="store_true",
                     help="run all three optimize_map passes for every window (three launches) instead of continuing a pass that flags nothing new "
                          "(vslam_set_tuning ba_adaptive = 0); the default run reports this figure beside the headline")
+    ap.add_argument("--no-plain-schedule", action="store_true", help="skip the extra timed region with the plain BA schedule (profiling runs: it would mix its launches into the counters)")
     ap.add_argument("--no-config4", action="store_true", help="skip the extra BA-only measurement on the config-4 shape")
     ap.add_argument("--pose", choices=["lm", "ransac"], default="lm",
                     help="pose stage: north_star motion-only LM (default, BASELINE metric) or the reference's solvePnPRansac(100, 4.0, 0.99), batched on the device")
@@ -748,7 +749,7 @@ def main():
     one_step_serial = lambda: one_step(serial=True)
     serial_s = timed_region(one_step_serial) if n_flight > 1 else None   # the same steps with ONE batch in flight (the figure of the earlier rounds)
     plain_s = None
-    if pipe.with_ba and not args.ba_plain_schedule:   # ... and with the plain BA schedule (every pass for every window: the schedule of the earlier rounds)
+    if pipe.with_ba and not args.ba_plain_schedule and not args.no_plain_schedule:   # ... and with the plain BA schedule (every pass for every window: the schedule of the earlier rounds)
         for p_ in ring.pipes:
             p_.vo.set_tuning(ba_adaptive=0)
         one_step(); one_step()

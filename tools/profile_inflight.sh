@@ -2,7 +2,7 @@
 # Kernel trace of the default step with one and with two batches in flight (bench.py --in-flight): how the kernels of the two streams overlap.
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-COMMON="--steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-config4 --no-reference-pipeline --render-workers 0 --unique-frames 64 --inputs resident"
+COMMON="--steps 6 --warmup 2 --repeats 1 --no-plain-schedule --no-cpu-baseline --no-config4 --no-reference-pipeline --render-workers 0 --unique-frames 64 --inputs resident"
 for P in 1 2; do
   OUT=gpurun_out/prof_r04_inflight$P; mkdir -p $OUT
   timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py $COMMON --in-flight $P > $OUT/bench.json 2> $OUT/trace.log
