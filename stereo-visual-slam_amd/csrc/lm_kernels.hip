@@ -135,7 +135,7 @@ struct LmKernelArgs {
     int dinv_lds;     // landmarks per window whose Dinv is kept in dynamic LDS (0 = none)
     int want_chi2;    // the caller passed a chi2 output array: scatter chi2 back to its edge order at the end
     const int32_t* order; // n_windows: workgroup i takes window order[i] (largest first, lm_order_kernel), or null: window i
-    int32_t* passes;      // n_windows: optimize_map passes of the current schedule that were EXECUTED for the window (0 while it is still open; see `sched`)
+    int32_t* passes;      // n_windows: optimize_map passes of the current schedule that were EXECUTED for the window (written by the SCHED instance; 3 everywhere for the plain schedule)
 };
 
 // slots of the landmark-wise slot table worth fetching for the 64-landmark row that starts at landmark `first` (wave-uniform)
@@ -424,9 +424,12 @@ __device__ inline double row_dot_sub(double v, const double* a, const double* b,
     return v - (s0 + s1);
 }
 
-template <bool IMPL>
+// SCHED: the in-kernel adaptive schedule (below).  A separate instance: the pass loop costs the single-pass code ~5 % in spilled registers, and the
+// single-pass instance is what the host tier's per-call latency and the plain three-launch schedule run.
+template <bool IMPL, bool SCHED = false>
 __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel(LmKernelArgs ka, int mode, int iters, int update_poses, int update_lms,
-                                                            int classify, int reuse_csr, int sched) {
+                                                            int classify, int reuse_csr) {
+    static_assert(!(IMPL && SCHED), "the schedule is a property of the window problems");
     const LmWindowArgs& a = ka.a;
     __shared__ LmShared sm;
     const int w = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     double* recW_alt = lin + (size_t)ne;
 #define PC(ptr, c, l) (ptr)[(size_t)(c) * nl + (l)]
 
-    // In-kernel ADAPTIVE schedule (sched == 1; run_vslam.cpp:58-71 = optimize_map(5), optimize_map(5), optimize_map(10), the first two without
+    // In-kernel ADAPTIVE schedule (SCHED; run_vslam.cpp:58-71 = optimize_map(5), optimize_map(5), optimize_map(10), the first two without
     // write-back).  Every pass starts from the SAME poses and landmarks; only the landmark flags carry over.  A pass whose classification flags
     // nothing new therefore leaves the next pass the inputs it had itself: the next 5-iteration pass would repeat it bit for bit (the kernel is
     // deterministic) and the 10-iteration pass would repeat its 5 iterations and then run 5 more.  Such a pass is simply CONTINUED to 10 iterations,
@@ -510,11 +513,11 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     // to the plain schedule's (tests/test_gpu_lm.py::test_adaptive_schedule_is_bit_identical).  The passes of a window run back to back in ONE
     // launch: a window that is done frees its CU for the next window at once (three launches would wait for the slowest window three times).
     const int iters_early = iters, reuse_csr0 = reuse_csr;
-    const int npass = (!IMPL && sched == 1) ? 3 : 1;
+    constexpr int npass = SCHED ? 3 : 1;
     bool done = false;       // (uniform) the schedule's last pass has been run, as a continued early pass
     int pass = 0;
     for (; pass < npass && !done; ++pass) {
-    if (!IMPL && sched == 1) {
+    if (SCHED) {
         iters = pass < 2 ? iters_early : kSchedFinalIters; update_poses = pass == 2; reuse_csr = reuse_csr0 || pass > 0;
         if (pass > 0) __syncthreads(); // (the classification of the previous pass wrote the flags this pass's setup reads)
     }
@@ -1556,7 +1559,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
         }
         if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
     }
-    if (!IMPL && sched == 1 && pass < 2) {
+    if (SCHED && pass < 2) {
         if (!done) { // (done: this was the continuation -- the last pass, whatever its own classification flagged)
             const bool repeatable = __syncthreads_or(newly_flagged) == 0; // (uniform) the next pass would see the inputs this one saw
             if (repeatable) {
@@ -1578,7 +1581,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             if (act[l]) { a.xyz[3 * ((size_t)lm0 + l)] = (float)PC(P, 0, l); a.xyz[3 * ((size_t)lm0 + l) + 1] = (float)PC(P, 1, l); a.xyz[3 * ((size_t)lm0 + l) + 2] = (float)PC(P, 2, l); }
     PH(12);
     } // passes
-    if (!IMPL && sched == 1 && tid == 0) ka.passes[w] = pass; // passes executed: 1 or 2 = an early pass was continued as the last one
+    if (SCHED && tid == 0) ka.passes[w] = pass; // passes executed: 1 or 2 = an early pass was continued as the last one
     if (tid == 0) ka.status[w] = VSLAM_OK;
 #undef PH
 #undef PC
@@ -2177,6 +2180,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     const size_t dyn_lds = (size_t)kDinvLds * 6 * sizeof(double);
     if (!scratch->lds_opt_in) { // more than 64 KB of dynamic LDS needs the opt-in (once per context, i.e. per device)
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_window_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_window_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
         scratch->lds_opt_in = true;
     }
     static long long* d_cyc = nullptr; static int cyc_n = 0;
@@ -2197,22 +2201,22 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     if (schedule) {
         // run_vslam.cpp:58-71: optimize_map(5) x2 without write-back, optimize_map(10) writing poses, optimize_pose_only(10)
         if (adaptive) {
-            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0, 1);
+            hipLaunchKernelGGL((lm_window_kernel<false, true>), dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0);
         } else {
             hipLaunchKernelGGL(lm_fill_kernel, dim3((a.n_windows + 255) / 256), dim3(256), 0, stream, ka.passes, a.n_windows, 3);
-            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0, 0);
-            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 1, 0); // (the landmark CSR of the first launch is still valid)
-            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, kSchedFinalIters, 1, 0, 1, 1, 0);
+            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 0);
+            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, 5, 0, 0, 1, 1); // (the landmark CSR of the first launch is still valid)
+            hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 0, kSchedFinalIters, 1, 0, 1, 1);
         }
         // the pose-only pass: one wave per keyframe (pose_only_wave_kernel); Tuning::pose_only_window = 1 (tuning aid / cross-check test) keeps the window kernel
         const bool po_window = scratch->tune && scratch->tune->pose_only_window > 0;
-        if (po_window) hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1, 0);
+        if (po_window) hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, 1, 10, 1, 0, 1, 1);
         else {
             if (ka.dbg_cycles && getenv("VSLAM_PO_PROFILE")) hipMemsetAsync(ka.dbg_cycles, 0, sizeof(long long) * kDbgSlots * a.n_windows, stream); // show only this pass
             hipLaunchKernelGGL(pose_only_wave_kernel, dim3(a.n_windows), dim3(kPoBlock), 0, stream, ka, 10, 1);
         }
     } else {
-        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, mode, iters, update_poses, update_lms, 1, 0, 0);
+        hipLaunchKernelGGL(lm_window_kernel<false>, dim3(a.n_windows), dim3(kLmBlock), dyn_lds, stream, ka, mode, iters, update_poses, update_lms, 1, 0);
     }
     VS_HIP(hipGetLastError());
     if (ka.dbg_cycles) {
@@ -2268,7 +2272,7 @@ int launch_pnp(const PnpArgs& p, LmScratch* scratch, hipStream_t stream) {
     if (rc) return rc;
     ka.order = nullptr; // (problem b runs on workgroup b)
     ProfScope prof__(stream, "lm_window_kernel<pnp>", 2);
-    hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0, 0, 0);
+    hipLaunchKernelGGL(lm_window_kernel<true>, dim3(p.B), dim3(kLmBlock), 0, stream, ka, 1, p.iters, 1, 0, 0, 0);
     hipLaunchKernelGGL(pnp_inlier_kernel, dim3(p.B), dim3(256), 0, stream, p.xyz, p.uv, p.n, p.capacity, p.T, p.K[0], p.K[1], p.K[2], p.K[3],
                        p.reproj_thr * p.reproj_thr, p.inlier, p.n_inliers);
     VS_HIP(hipGetLastError());

@@ -30,9 +30,10 @@ if os.path.exists(sq):
         if any(name.startswith(p) for p in prefixes):
             m = {k: float(v) for k, v in re.findall(r"(\w+)\s+([0-9][0-9.e+]*)%?", line)}
             rows[name] = line.strip()
-            if name.startswith("lm_window_kernel<false>"):
+            if name.startswith("lm_window_kernel<false"):
                 d = int(m.get("disp", 0)) or 1
-                out["valu_wave_insts_per_window_schedule"] = m["valu_insts"] / (d / 3.0) / batch  # three optimize_map launches per schedule
+                per_sched = 1.0 if "<false, true>" in line else 3.0   # <false, true>: the in-kernel adaptive schedule, one launch; <false, false>: three launches per schedule
+                out["valu_wave_insts_per_window_schedule"] = m["valu_insts"] / (d / per_sched) / batch
                 out["valu_active_pct_of_wave_cycles"] = m.get("active_valu")
     out["sq"] = rows
 json.dump(out, open(os.path.join(root, "profiles", out_name), "w"), indent=1)

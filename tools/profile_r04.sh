@@ -41,8 +41,8 @@ open(os.path.join(root, "sq_summary.txt"), "w").write("\n".join(lines) + "\n")
 PY
   TOTAL_STEPS=$((STEPS * 2 + 1))   # warmup + one timed repeat + the profiled repeat
   case $CFG in
-    tracks)  python tools/make_counter_json.py $OUT traffic_tracks.json $BATCH $TOTAL_STEPS "lm_window_kernel<false>,pose_only_wave_kernel" lm_kernels.hip lm_window_kernel > $OUT/traffic.log 2>&1;;
-    config4) python tools/make_counter_json.py $OUT traffic.json $BATCH $TOTAL_STEPS "lm_window_kernel<false>,pose_only_wave_kernel" lm_kernels.hip lm_window_kernel > $OUT/traffic.log 2>&1;;
+    tracks)  python tools/make_counter_json.py $OUT traffic_tracks.json $BATCH $TOTAL_STEPS "lm_window_kernel<false,pose_only_wave_kernel" lm_kernels.hip lm_window_kernel > $OUT/traffic.log 2>&1;;
+    config4) python tools/make_counter_json.py $OUT traffic.json $BATCH $TOTAL_STEPS "lm_window_kernel<false,pose_only_wave_kernel" lm_kernels.hip lm_window_kernel > $OUT/traffic.log 2>&1;;
     sgbm)    python tools/make_counter_json.py $OUT traffic_sgbm.json $BATCH $TOTAL_STEPS "sgbm_" sgbm_kernels.hip "sgbm_* (family)" > $OUT/traffic.log 2>&1;;
   esac
   cp profiles/traffic*.json $OUT/ 2>/dev/null
