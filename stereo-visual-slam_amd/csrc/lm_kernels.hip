@@ -432,8 +432,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     static_assert(!(IMPL && SCHED), "the schedule is a property of the window problems");
     const LmWindowArgs& a = ka.a;
     __shared__ LmShared sm;
-    const int w = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // tell the compiler it is wave-uniform: wave-indexed control flow goes scalar
+    const int w = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;
     int prio_cnt = 0; (void)prio_cnt;
     // keyframes of this window: a.n_kf slots (the pose stride), of which window w uses the first n_kf_w[w] (a growing map)
     const int nk = (!IMPL && a.n_kf_w) ? min(max(a.n_kf_w[w], 1), a.n_kf) : a.n_kf, np = 6 * nk;
@@ -490,8 +489,6 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const double delta = a.huber_delta;
     const bool with_lm = (mode == 0);
     const int npairs = nk * (nk + 1) / 2;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int slot27 = wave_slot<27>(lane), slot36 = wave_slot<36>(lane); // which butterfly sum this lane ends up holding
     long long* cyc = ka.dbg_cycles ? ka.dbg_cycles + kDbgSlots * (size_t)w : nullptr;
     long long t_ph = cyc ? clock64() : 0;
     // (a fire-and-forget atomic: `cyc[i] += ...` made thread 0 wait a global round trip per marker, which the NEXT phase was then charged with)
@@ -517,6 +514,15 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     bool done = false;       // (uniform) the schedule's last pass has been run, as a continued early pass
     int pass = 0;
     for (; pass < npass && !done; ++pass) {
+    // The thread's own index is (re)derived INSIDE the pass loop, behind an opaque move in the schedule instance: everything computed from it (dozens of
+    // per-thread addresses and lane constants of the LM loop) is then not loop-invariant, so the compiler cannot hoist it in front of the pass loop, keep it
+    // alive across the register-hungry list builders and spill it there (47 spill stores at the loop head without this).
+    int tid_l = threadIdx.x;
+    if (SCHED) asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // tell the compiler it is wave-uniform: wave-indexed control flow goes scalar
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int slot27 = wave_slot<27>(lane), slot36 = wave_slot<36>(lane); // which butterfly sum this lane ends up holding
     if (SCHED) {
         iters = pass < 2 ? iters_early : kSchedFinalIters; update_poses = pass == 2; reuse_csr = reuse_csr0 || pass > 0;
         if (pass > 0) __syncthreads(); // (the classification of the previous pass wrote the flags this pass's setup reads)
@@ -1581,8 +1587,8 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
             if (act[l]) { a.xyz[3 * ((size_t)lm0 + l)] = (float)PC(P, 0, l); a.xyz[3 * ((size_t)lm0 + l) + 1] = (float)PC(P, 1, l); a.xyz[3 * ((size_t)lm0 + l) + 2] = (float)PC(P, 2, l); }
     PH(12);
     } // passes
-    if (SCHED && tid == 0) ka.passes[w] = pass; // passes executed: 1 or 2 = an early pass was continued as the last one
-    if (tid == 0) ka.status[w] = VSLAM_OK;
+    if (SCHED && threadIdx.x == 0) ka.passes[w] = pass; // passes executed: 1 or 2 = an early pass was continued as the last one
+    if (threadIdx.x == 0) ka.status[w] = VSLAM_OK;
 #undef PH
 #undef PC
 }
