@@ -267,15 +267,18 @@ def test_adaptive_schedule_is_bit_identical(pkg, synth, kind):
         T0, inl0 = pipe.ba_T.clone(), pipe.ba_inl.clone()
         chi2 = torch.zeros(int(pipe.ba_batch.total_edge), dtype=torch.float64, device=pipe.dev)
         pipe.ba_batch.d_chi2 = chi2.data_ptr()
+        import ctypes as C
+        stats = torch.zeros(B * C.sizeof(pkg.LmStats), dtype=torch.uint8, device=pipe.dev)   # vslam_lm_stats per window: what the LAST optimize_map pass reports
+        pipe.ba_batch.d_stats = stats.data_ptr()
         got = {}
         for adaptive in (1, 0):
-            pipe.ba_T.copy_(T0); pipe.ba_inl.copy_(inl0); chi2.zero_()
+            pipe.ba_T.copy_(T0); pipe.ba_inl.copy_(inl0); chi2.zero_(); stats.zero_()
             torch.cuda.synchronize()
             pipe.vo.set_tuning(ba_adaptive=adaptive)
             pipe.vo.ba_batch_dev(pipe.ba_batch, schedule=1)
             passes = pipe.vo.ba_schedule_passes(B)
             assert (pipe.vo.ba_status(B) == 0).all()
-            got[adaptive] = (pipe.ba_T.cpu().numpy().copy(), pipe.ba_inl.cpu().numpy().copy(), chi2.cpu().numpy().copy(), passes)
+            got[adaptive] = (pipe.ba_T.cpu().numpy().copy(), pipe.ba_inl.cpu().numpy().copy(), chi2.cpu().numpy().copy(), passes, stats.cpu().numpy().copy())
         assert (got[0][3] == 3).all()                      # plain: every pass ran
         assert ((got[1][3] >= 1) & (got[1][3] <= 3)).all()
         print(kind, "passes executed per window:", np.bincount(got[1][3], minlength=4)[1:])
@@ -285,6 +288,7 @@ def test_adaptive_schedule_is_bit_identical(pkg, synth, kind):
             assert (got[1][3] > 1).any() and (got[1][1] == 0).any()
         for a, b in zip(got[1][:3], got[0][:3]):
             assert np.array_equal(a, b)
+        assert np.array_equal(got[1][4], got[0][4])        # iterations, trials, chi2 / lambda per iteration of the last pass: the same record
     finally:
         pipe.vo.set_tuning(ba_adaptive=-1)
         pipe.close()
