@@ -6,7 +6,7 @@ import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-KINDS = ["match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev"]
+KINDS = ["match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev", "ba_schedule"]
 
 
 class Mismatch(AssertionError):
@@ -68,6 +68,38 @@ def one_case(kind, rng, vo, pkg, O, synth):
         T, x, chi2, st = O.local_ba(win["T0"], win["xyz"], win["kf_idx"], win["lm_idx"], win["uv"], iters=it, update_poses=True, update_lms=True)
         if not (np.allclose(r["T"], T, rtol=1e-4, atol=1e-6) and np.allclose(r["xyz"], x, rtol=1e-4, atol=1e-4)):
             fail("local_ba", nk=nk, nl=nl, seed=seed, iters=it)
+    elif kind == "ba_schedule":
+        # the adaptive BA schedule (a pass that flags nothing new is continued instead of repeated) against the plain one -- every optimize_map pass for
+        # every window -- on random batches: bit-identical poses, flags and per-edge chi2 (round 4)
+        import torch
+        nw = int(rng.integers(1, 10)); nk = int(rng.integers(2, 11)); nl = int(rng.choice([40, 300, 900, 1500]))
+        frac = float(rng.choice([0.0, 0.0, 0.005, 0.02, 0.05]))   # gross observation errors: passes that do flag, windows that need two or three of them
+        wins = [synth.ba_window_fast(n_kf=nk, n_lm=nl, seed=seed + 17 * i, outlier_frac=frac, max_obs=min(5, nk), min_obs=min(2, nk)) for i in range(nw)]
+        lm_off = np.cumsum([0] + [len(wn["xyz"]) for wn in wins]).astype(np.int32); e_off = np.cumsum([0] + [len(wn["kf_idx"]) for wn in wins]).astype(np.int32)
+        d = "cuda"
+        T0 = torch.from_numpy(np.stack([wn["T0"] for wn in wins])).to(d)
+        xyz = torch.from_numpy(np.concatenate([wn["xyz"] for wn in wins])).to(d); kf = torch.from_numpy(np.concatenate([wn["kf_idx"] for wn in wins])).to(d)
+        lm = torch.from_numpy(np.concatenate([wn["lm_idx"] for wn in wins])).to(d); uv = torch.from_numpy(np.concatenate([wn["uv"] for wn in wins])).to(d)
+        t_lm, t_e = torch.from_numpy(lm_off).to(d), torch.from_numpy(e_off).to(d)
+        outs = []
+        try:
+            for adaptive in (1, 0):
+                T = T0.clone(); inl = torch.ones(int(lm_off[-1]), dtype=torch.uint8, device=d); chi = torch.zeros(int(e_off[-1]), dtype=torch.float64, device=d)
+                bb = pkg.BaBatch()
+                bb.n_windows = nw; bb.n_kf = nk
+                bb.d_lm_off = t_lm.data_ptr(); bb.d_edge_off = t_e.data_ptr(); bb.d_T_c_w = T.data_ptr(); bb.d_xyz = xyz.data_ptr()
+                bb.d_reliable = None; bb.d_lm_inlier = inl.data_ptr(); bb.d_kf_idx = kf.data_ptr(); bb.d_lm_idx = lm.data_ptr(); bb.d_uv = uv.data_ptr()
+                bb.d_chi2 = chi.data_ptr(); bb.d_stats = None; bb.total_lm = int(lm_off[-1]); bb.total_edge = int(e_off[-1])
+                torch.cuda.synchronize()
+                vo.set_tuning(ba_adaptive=adaptive)
+                vo.ba_batch_dev(bb, schedule=1)
+                passes = vo.ba_schedule_passes(nw)
+                outs.append((T.cpu().numpy(), inl.cpu().numpy(), chi.cpu().numpy(), passes, vo.ba_status(nw)))
+        finally:
+            vo.set_tuning(ba_adaptive=-1)
+        (Ta, ia, ca, pa, sa), (Tb, ib, cb, pb, sb) = outs
+        if not ((sa == sb).all() and (pb[sb == 0] == 3).all() and np.array_equal(Ta, Tb) and np.array_equal(ia, ib) and np.array_equal(ca, cb)):
+            fail("ba_schedule", nw=nw, nk=nk, nl=nl, frac=frac, seed=seed, passes=pa.tolist())
     elif kind == "pnp":
         M = int(rng.integers(4, 1500))
         p = synth.pnp_problem(M=M, seed=seed, outlier_frac=float(rng.choice([0.0, 0.15, 0.4])))
@@ -171,7 +203,7 @@ def run(seconds=120.0, seed=0, only="", vo=None, max_cases=None, schedule=None):
     i = 0
     try:
         while time.time() < t_end and (max_cases is None or i < max_cases):
-            kind = only or (schedule[i % len(schedule)] if schedule else rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev"]))
+            kind = only or (schedule[i % len(schedule)] if schedule else rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev", "ba_schedule"]))
             one_case(kind, rng, vo, pkg, O, synth)
             n[kind] += 1
             i += 1
