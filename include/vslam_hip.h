@@ -287,7 +287,8 @@ int vslam_ba_batch_dev(vslam_ctx* ctx, const vslam_ba_batch* batch, int schedule
  * All pointers are device pointers. */
 typedef struct vslam_tracks_in {
     int32_t n_frames;
-    int32_t kp_capacity, lr_capacity, match_capacity, pnp_capacity;
+    int32_t kp_capacity, lr_capacity, match_capacity, pnp_capacity; /* kp_capacity <= 65536 (the builder packs a keypoint index into 16 bits;
+                                      larger values are refused with VSLAM_ERR_ARG) */
     const vslam_keypoint* d_kps;   /* n_frames x kp_capacity: left keypoints */
     const vslam_dmatch* d_lr;      /* n_frames x lr_capacity: depth association of frame f, queryIdx = left keypoint (L/R matches; the identity
                                       list when the depth comes from the disparity map) */
@@ -295,7 +296,10 @@ typedef struct vslam_tracks_in {
     const float* d_xyz;            /* n_frames x lr_capacity x 3: point of association m in the CAMERA frame of frame f (T_c_w = identity) */
     const uint8_t* d_valid;        /* n_frames x lr_capacity: the depth gates of set_ref_3d_position passed (:199) */
     const uint8_t* d_reliable;     /* n_frames x lr_capacity: reliable_depth_ (:201) */
-    const vslam_dmatch* d_f2f;     /* (n_frames - 1) x match_capacity: item i = matches frame i (query) -> frame i + 1 (train) */
+    const vslam_dmatch* d_f2f;     /* (n_frames - 1) x match_capacity: item i = matches frame i (query) -> frame i + 1 (train).  PRECONDITION: one-to-one
+                                      inside an item (no two matches share a queryIdx or a trainIdx) -- what the cross-checked matcher of
+                                      vslam_feature_matching[_dev] (VO::feature_matching, visual_odometry.cpp:219-251) emits.  Matches that share a
+                                      trainIdx (knn / ratio-test output) would make two tracks claim one keypoint: not supported, result undefined */
     const int32_t* d_nf2f;         /* n_frames - 1 */
     const uint8_t* d_pose_inlier;  /* (n_frames - 1) x pnp_capacity: inlier flag of input j of item i's pose problem, inputs in the order
                                       vslam_build_pnp_inputs_dev emitted them */

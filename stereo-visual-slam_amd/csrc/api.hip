@@ -108,6 +108,7 @@ static const TuneKey kTuneKeys[] = {
     {"sgbm_fwd_min", "VSLAM_SGBM_FWD_MIN", &Tuning::sgbm_fwd_min, 0, 1 << 30},
     {"sgbm_fw_rows", "VSLAM_SGBM_FW_ROWS", &Tuning::sgbm_fw_rows, 32, 64},
     {"pose_only_window", "VSLAM_POSE_ONLY_WINDOW", &Tuning::pose_only_window, 0, 1},
+    {"ba_resident", "VSLAM_BA_RESIDENT", &Tuning::ba_resident, 0, 1},
     {"pnp_window", "VSLAM_PNP_WINDOW", &Tuning::pnp_window, 0, 1},
     {"ba_adaptive", "VSLAM_BA_ADAPTIVE", &Tuning::ba_adaptive, 0, 1},
 };
@@ -223,10 +224,8 @@ int vslam_create(const vslam_params* p, int device, void* stream, vslam_ctx** ou
     if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return VSLAM_ERR_ARG; }
     if (p->max_batch <= 0 || p->kp_capacity < 64 || p->kp_capacity > kMaxRows || p->orb_nfeatures <= 0) { set_error("bad params (max_batch>0, 64<=kp_capacity<=%d)", kMaxRows); return VSLAM_ERR_ARG; }
     VS_HIP(hipSetDevice(device));
-    Ctx* c = new Ctx();
-    memset(c, 0, sizeof(*c));
+    Ctx* c = new Ctx(); // (value-initialised: zeroes, then the members' default initialisers -- Tuning's -1, LmScratch's)
     c->p = *p; c->device = device;
-    c->tune = Tuning();
     c->lm.tune = &c->tune;
     { int rc_t = tune_from_env(c->tune); if (rc_t) { delete c; return rc_t; } }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
@@ -282,6 +281,7 @@ int vslam_sync(vslam_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return VSLAM_ERR_ARG;
     VS_ENTER(c);
+    if (c->sgbm_unchecked) { int32_t st = 0; return vslam_sgbm_status_dev(ctx, &st); } // (synchronises; a fired backstop voids the maps: VSLAM_ERR_HIP)
     VS_HIP(hipStreamSynchronize(c->stream));
     return VSLAM_OK;
 }
@@ -493,6 +493,7 @@ int vslam_disparity_map_dev(vslam_ctx* ctx, const uint8_t* d_left, const uint8_t
     if (!c || !d_left || !d_right || w <= 0 || h <= 0 || pitch < w || B < 0 || img_stride_bytes < (size_t)pitch * h ||
         (!d_disparity && !d_disp_i16 && !d_disp_raw_i16)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     VS_ENTER(c);
+    c->sgbm_unchecked = true; // (asynchronous: the forward sweep's error word is looked at by the next vslam_sync / vslam_sgbm_status_dev)
     return launch_sgbm(c->tune, d_left, d_right, img_stride_bytes, pitch, w, h, B, d_disparity, d_disp_i16, d_disp_raw_i16, &c->d_sgbm, &c->sgbm_bytes,
                        &c->dev_bytes, c->stream);
 }
@@ -535,6 +536,7 @@ int vslam_sgbm_status_dev(vslam_ctx* ctx, int32_t* h_status) {
     if (!c || !h_status) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     VS_ENTER(c);
     *h_status = 0;
+    c->sgbm_unchecked = false;
     if (!c->d_sgbm) { VS_HIP(hipStreamSynchronize(c->stream)); return VSLAM_OK; } // no SGBM launch yet
     // header of the SGBM scratch: int32 [0..7] ticket pools, [8] error word of the most recent launch (sgbm_kernels.hip, launch_sgbm)
     VS_HIP(hipMemcpyAsync(h_status, c->d_sgbm + 32, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -953,6 +955,7 @@ int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf,
         !out->d_lm_off || !out->d_edge_off || !out->d_T_c_w || !out->d_xyz || !out->d_reliable || !out->d_lm_inlier || !out->d_kf_idx || !out->d_lm_idx ||
         !out->d_uv || !out->d_n_kf) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if ((long long)in->n_frames * in->kp_capacity > 0x7FFFFFFFll) { set_error("n_frames x kp_capacity exceeds the 31-bit node keys"); return VSLAM_ERR_ARG; }
+    if (in->kp_capacity > 65536) { set_error("kp_capacity %d exceeds 65536 (the window builder packs a keypoint index into 16 bits)", in->kp_capacity); return VSLAM_ERR_ARG; }
     VS_ENTER(c);
     const size_t need = track_scratch_bytes(in->n_frames, in->kp_capacity, lm_capacity);
     if (c->track_bytes < need) {

@@ -200,6 +200,7 @@ struct Tuning {
     int sgbm_fw_rows = -1;    // VSLAM_SGBM_FW_ROWS: 32 or 64 image rows per slab of the forward sweep
     int pose_only_window = -1; // VSLAM_POSE_ONLY_WINDOW: 1 = the schedule's pose-only pass on lm_window_kernel instead of pose_only_wave_kernel
     int pnp_window = -1;      // VSLAM_PNP_WINDOW: 1 = single-pose problems on lm_window_kernel<pnp> instead of pnp_wave_kernel
+    int ba_resident = -1;     // VSLAM_BA_RESIDENT: 0 = optimize_map windows always on lm_window_kernel (default: ba_resident_kernel for the windows that fit its LDS budget)
     int ba_adaptive = -1;     // VSLAM_BA_ADAPTIVE: 0 = the BA schedule runs all three optimize_map passes for every window (default: a pass that flags nothing new is continued instead of repeated)
 };
 int launch_sgbm(const Tuning& tune, const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
@@ -213,7 +214,20 @@ struct LmScratch {
     int32_t* passes = nullptr; // optimize_map passes executed per window by the most recent schedule (lm_fetch_passes)
     const Tuning* tune = nullptr; // the owning context's overrides
     bool lds_opt_in = false; // the > 64 KB dynamic-LDS attribute of lm_window_kernel has been set on this context's device
+    bool rs_opt_in = false;  // ... of ba_resident_kernel
+    int rs_dyn_bytes = -1;   // dynamic LDS a ba_resident_kernel workgroup may use on this context's device (-1: not queried yet)
+    int32_t* defer = nullptr; // per window of the most recent launch: 1 = left to lm_window_kernel by ba_resident_kernel
 };
+// ba_resident.hip: optimize_map / the BA schedule on windows whose landmark state fits the LDS of one CU (the rest is marked in `defer`)
+struct RsLaunch {
+    LmWindowArgs a;
+    void* uv_s; int32_t* epos; double* tab; double* xin; double* Pbak; double* Dc; double* blc; // scratch slices (see RsArgs)
+    int32_t* status; int32_t* passes; int32_t* defer; const int32_t* order; long long* dbg;
+    int dyn_bytes, schedule, adaptive, iters, update_poses, update_lms;
+    bool opt_in_done;
+};
+int rs_dyn_lds_bytes(int device);
+int launch_ba_resident(const RsLaunch& L, hipStream_t stream);
 int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, int update_poses, int update_lms, LmScratch* scratch,
                       hipStream_t stream);
 size_t lm_hits_per_edge();
@@ -258,6 +272,7 @@ struct Ctx {
     uint8_t* h_pinned; size_t pinned_bytes;
     // SGBM working set (cost volumes; grown on demand by vslam_disparity_map*)
     uint8_t* d_sgbm; size_t sgbm_bytes;
+    bool sgbm_unchecked;  // an asynchronous SGBM launch whose error word nobody has read yet (vslam_sync / vslam_sgbm_status_dev do)
     uint8_t* d_ransac; size_t ransac_bytes; // hypothesis tables of vslam_pnp_ransac_dev (grown on demand)
     uint8_t* d_track; size_t track_bytes; // chain tables of vslam_build_windows_dev (grown on demand)
     LmScratch lm;
