@@ -322,6 +322,14 @@ int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status);
  * poses and landmarks; only the flags carry over) and it was continued to the last pass's 10 iterations instead -- same result, 10 or 15 LM
  * iterations instead of 20.  vslam_set_tuning(ctx, "ba_adaptive", 0) runs every pass.  Synchronises the context stream. */
 int vslam_ba_schedule_passes_dev(vslam_ctx* ctx, int n_windows, int32_t* h_passes);
+
+/* Diagnostic (rows A10 / A11): the residual and the Jacobians of EdgeProjection (optimization.cpp:41-73) and PoseOnlyEdgeProjection
+ * (:75-101) as THE DEVICE CODE OF THE LM KERNELS evaluates them -- the same device functions (normalised-coordinate factors At, Bt,
+ * en, Huber weight), scaled back to pixels: err = z - K (T p) / Z (2), J_pose = d err / d xi for the left perturbation T <- exp(xi) T,
+ * xi = [translation; rotation] (2 x 6, row-major), J_point = d err / d p_w (2 x 3), chi2 = |err|^2, w = Huber weight (delta =
+ * params.huber_delta).  n observations of n world points through ONE pose; host buffers, synchronous; any output may be NULL. */
+int vslam_edge_jacobians(vslam_ctx* ctx, int n, const float* xyz_w, const float* uv, const double T_c_w[7], const double* K4,
+                         double* err, double* J_pose, double* J_point, double* chi2, double* huber_w);
 /* Kernel-choice overrides of a context (tuning aid, and how the tests force every kernel path): name in {"orb_fuse_min", "sgbm_fuse_min",
  * "sgbm_fwd_min" (items per call from which the fused kernel is used), "sgbm_fw_rows" (32 | 64), "pose_only_window", "pnp_window", "ba_adaptive" (0 | 1)};
  * value -1 = the library's batch-size rule.  vslam_create seeds them once from the environment variables VSLAM_<NAME> (an unparsable
@@ -356,6 +364,14 @@ typedef struct vslam_kernel_time {
 } vslam_kernel_time;
 int vslam_profile_enable(vslam_ctx* ctx, int on);
 int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_out);
+/* The same brackets as INTERVALS on one time axis for the whole process (milliseconds since the first vslam_profile_enable(.., 1) of any context
+ * on the device): with several contexts / streams in flight together this is what tells how much their kernel families overlap.  Synchronises
+ * the stream, returns up to `cap` brackets recorded since the last read of either kind (in launch order) and resets, like vslam_profile_read. */
+typedef struct vslam_stage_interval {
+    char name[48];
+    double t0_ms, t1_ms;
+} vslam_stage_interval;
+int vslam_profile_intervals(vslam_ctx* ctx, vslam_stage_interval* out, int cap, int* n_out);
 
 /* Measurement aid: a float4 streaming copy of `bytes` (read + write), `reps` launches timed with hipEvents on the context
  * stream; *gbs_out = moved GB/s.  The achievable-bandwidth figure reported next to the 8 TB/s HBM spec. */

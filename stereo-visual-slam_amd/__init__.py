@@ -72,15 +72,19 @@ ABI_SYMBOLS = [
     "vslam_orb_compute", "vslam_feature_detection_dev", "vslam_feature_matching", "vslam_feature_matching_dev",
     "vslam_find_3d_disparity", "vslam_triangulate", "vslam_triangulate_dev", "vslam_gather_matched_uv_dev",
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
-    "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_ba_schedule_passes_dev", "vslam_orb_status_dev", "vslam_dev_alloc",
+    "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_ba_schedule_passes_dev", "vslam_edge_jacobians", "vslam_orb_status_dev", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
-    "vslam_profile_enable", "vslam_profile_read", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
+    "vslam_profile_enable", "vslam_profile_read", "vslam_profile_intervals", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
     "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant", "vslam_sgbm_status_dev", "vslam_set_tuning", "vslam_build_windows_dev", "vslam_pnp_ransac_dev",
 ]
 
 
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("total_ms", C.c_double), ("launches", C.c_int32), ("calls", C.c_int32)]
+
+
+class StageInterval(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("t0_ms", C.c_double), ("t1_ms", C.c_double)]
 
 
 class VslamError(RuntimeError):
@@ -424,6 +428,12 @@ class VO:
         self._chk(self.lib.vslam_profile_read(self.h, buf, 32, C.byref(n)), "vslam_profile_read")
         return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches, buf[i].calls) for i in range(n.value)}
 
+    def profile_intervals(self, cap=4096):
+        """[(kernel family, t0_ms, t1_ms)] of the brackets recorded since the last read, on the process-wide time axis (comparable across contexts)"""
+        buf = (StageInterval * cap)(); n = C.c_int()
+        self._chk(self.lib.vslam_profile_intervals(self.h, buf, cap, C.byref(n)), "vslam_profile_intervals")
+        return [(buf[i].name.decode(), buf[i].t0_ms, buf[i].t1_ms) for i in range(n.value)]
+
     def hbm_copy_probe(self, nbytes=1 << 30, reps=5):
         """GB/s (read + write) of a float4 streaming copy on this GPU, timed on the context stream"""
         g = C.c_double()
@@ -444,6 +454,17 @@ class VO:
         st = np.zeros(n_windows, np.int32)
         self._chk(self.lib.vslam_ba_status_dev(self.h, int(n_windows), _p(st)), "vslam_ba_status_dev")
         return st
+
+    def edge_jacobians(self, xyz_w, uv, T_c_w, K=None):
+        """residual / Jacobians of EdgeProjection and PoseOnlyEdgeProjection (optimization.cpp:41-101) as the LM kernels' device functions evaluate
+        them: {err (n, 2), J_pose (n, 2, 6), J_point (n, 2, 3), chi2 (n), huber_w (n)} for n world points seen through one pose"""
+        xyz = np.ascontiguousarray(xyz_w, np.float32); z = np.ascontiguousarray(uv, np.float32); T = np.ascontiguousarray(T_c_w, np.float64)
+        n = len(xyz)
+        out = dict(err=np.zeros((n, 2)), J_pose=np.zeros((n, 2, 6)), J_point=np.zeros((n, 2, 3)), chi2=np.zeros(n), huber_w=np.zeros(n))
+        K4 = None if K is None else np.ascontiguousarray(K, np.float64)
+        self._chk(self.lib.vslam_edge_jacobians(self.h, n, _p(xyz), _p(z), _p(T), _p(K4) if K4 is not None else None, _p(out["err"]), _p(out["J_pose"]),
+                                                _p(out["J_point"]), _p(out["chi2"]), _p(out["huber_w"])), "vslam_edge_jacobians")
+        return out
 
     def ba_schedule_passes(self, n_windows):
         """optimize_map passes the last schedule executed per window (3, or 1 / 2 when a pass flagged nothing new and was continued instead of repeated)"""

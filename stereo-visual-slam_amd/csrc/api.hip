@@ -38,6 +38,7 @@ struct Prof {
     }
 };
 static thread_local Prof* g_prof = nullptr;
+static hipEvent_t g_prof_origin = nullptr; // time origin shared by every context's brackets (vslam_profile_intervals)
 Prof* prof_current() { return g_prof; }
 void prof_set_current(Prof* p) { g_prof = p; }
 void prof_begin(hipStream_t s, const char* name, int launches) {
@@ -971,6 +972,38 @@ int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf,
                                 const_cast<int32_t*>(out->d_kf_idx), const_cast<int32_t*>(out->d_lm_idx), const_cast<float*>(out->d_uv), d_status, c->stream);
 }
 
+int vslam_edge_jacobians(vslam_ctx* ctx, int n, const float* xyz_w, const float* uv, const double T_c_w[7], const double* K4, double* err, double* J_pose,
+                         double* J_point, double* chi2, double* huber_w) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || n <= 0 || !xyz_w || !uv || !T_c_w) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
+    int rc;
+    if ((rc = arena_reserve(c, al256(12 * (size_t)n) + al256(8 * (size_t)n) + 256 + al256(16 * (size_t)n) + al256(96 * (size_t)n) + al256(48 * (size_t)n) + 2 * al256(8 * (size_t)n) + 4096))) return rc;
+    Arena ar(c);
+    float* d_xyz = arena_take<float>(ar, 3 * (size_t)n);
+    float* d_uv = arena_take<float>(ar, 2 * (size_t)n);
+    double* d_T = arena_take<double>(ar, 7);
+    double* d_err = arena_take<double>(ar, 2 * (size_t)n);
+    double* d_Jp = arena_take<double>(ar, 12 * (size_t)n);
+    double* d_Jl = arena_take<double>(ar, 6 * (size_t)n);
+    double* d_chi = arena_take<double>(ar, n);
+    double* d_hw = arena_take<double>(ar, n);
+    VS_HIP(hipMemcpyAsync(d_xyz, xyz_w, 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_uv, uv, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    VS_HIP(hipMemcpyAsync(d_T, T_c_w, 56, hipMemcpyHostToDevice, c->stream));
+    double K[4];
+    fill_K(c, K);
+    if (K4) memcpy(K, K4, sizeof(K));
+    if ((rc = launch_edge_jacobians(n, d_xyz, d_uv, d_T, K, c->p.huber_delta, d_err, d_Jp, d_Jl, d_chi, d_hw, c->stream))) return rc;
+    if (err) VS_HIP(hipMemcpyAsync(err, d_err, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (J_pose) VS_HIP(hipMemcpyAsync(J_pose, d_Jp, 96 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (J_point) VS_HIP(hipMemcpyAsync(J_point, d_Jl, 48 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (chi2) VS_HIP(hipMemcpyAsync(chi2, d_chi, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (huber_w) VS_HIP(hipMemcpyAsync(huber_w, d_hw, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    return VSLAM_OK;
+}
+
 int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !h_status || n_windows <= 0) return VSLAM_ERR_ARG;
@@ -990,6 +1023,12 @@ int vslam_profile_enable(vslam_ctx* ctx, int on) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return VSLAM_ERR_ARG;
     if (!c->prof) c->prof = new Prof();
+    if (on && !g_prof_origin) { // the common time origin of vslam_profile_intervals: recorded once per process, on the first context that profiles
+        VS_HIP(hipSetDevice(c->device));
+        VS_HIP(hipEventCreate(&g_prof_origin));
+        VS_HIP(hipEventRecord(g_prof_origin, c->stream));
+        VS_HIP(hipEventSynchronize(g_prof_origin));
+    }
     c->prof->on = on != 0;
     prof_set_current(on ? c->prof : nullptr);
     return VSLAM_OK;
@@ -1016,6 +1055,32 @@ int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_o
             ++n;
         }
         out[k].total_ms += ms; out[k].launches += r.launches; out[k].calls += 1;
+        p->pool.push_back(r.e0); p->pool.push_back(r.e1);
+    }
+    p->recs.clear();
+    *n_out = n;
+    return VSLAM_OK;
+}
+
+int vslam_profile_intervals(vslam_ctx* ctx, vslam_stage_interval* out, int cap, int* n_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !out || !n_out || cap <= 0) return VSLAM_ERR_ARG;
+    *n_out = 0;
+    Prof* p = c->prof;
+    if (!p || !g_prof_origin) return VSLAM_OK;
+    VS_ENTER(c);
+    VS_HIP(hipStreamSynchronize(c->stream));
+    int n = 0;
+    for (const Prof::Rec& r : p->recs) {
+        if (n < cap) {
+            float a0 = 0.f, a1 = 0.f;
+            if (hipEventElapsedTime(&a0, g_prof_origin, r.e0) == hipSuccess && hipEventElapsedTime(&a1, g_prof_origin, r.e1) == hipSuccess) {
+                memset(&out[n], 0, sizeof(out[n]));
+                strncpy(out[n].name, r.name, sizeof(out[n].name) - 1);
+                out[n].t0_ms = a0; out[n].t1_ms = a1;
+                ++n;
+            }
+        }
         p->pool.push_back(r.e0); p->pool.push_back(r.e1);
     }
     p->recs.clear();

@@ -50,7 +50,7 @@ struct alignas(16) RsShared {
     long long bpq[kRsNp], bsq[kRsNp], hdq[kRsNp]; // fixed-point accumulators: pose gradient, reduced right-hand side, diag(H_pp)
     double red[kRsWaves * 2];
     int redi[kRsWaves * 8];
-    int slotoff[kRsKf + 2];                       // first entry of observation slot q in the slot-major tables
+    int slotoff[kRsKf + 2];                       // observation slot q of sorted landmark s sits at entry slotoff[q] + s of the slot-major tables (may be negative: slot q starts at landmark nl - n_q)
     int nq[kRsKf + 2];
     int flag[16];
     unsigned short rowU[kRsMaxRows];              // union of the keyframe sets of a row's live landmarks
@@ -78,6 +78,7 @@ struct RsArgs {
     long long* dbg;
     int dyn_bytes;
     int want_chi2;
+    int dense_to_general;  // 1: windows with more than 2.2 observations per landmark are left to lm_window_kernel (Tuning::ba_resident = 1 forces them here)
 };
 
 __device__ inline long long to_fixed(double v, double scale) { return __double2ll_rn(v * scale); }
@@ -101,7 +102,10 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
     while (n2 < nl) n2 <<= 1;
     {   // does the window fit?  (uniform)
         const size_t need_run = (size_t)nblk * 288 + (size_t)nlp * 26, need_setup = (size_t)nlp * 6 + (size_t)n2 * 4;
-        if (nl <= 0 || ne <= 0 || nrows > kRsMaxRows || n2 > kRsSortCap || need_run > (size_t)ra.dyn_bytes || need_setup > (size_t)ra.dyn_bytes) {
+        // (dense graphs -- more than ~2.2 observations per landmark, e.g. the synthetic config-4 windows at 3.5 -- stay on lm_window_kernel: their
+        // Schur work is hits, not landmarks, and its stored hit lists / weights win there: 3.78 vs 4.3 ms per 256 such windows)
+        const bool dense = ra.dense_to_general && 5 * (long long)ne > 11 * (long long)nl;
+        if (dense || nl <= 0 || ne <= 0 || nrows > kRsMaxRows || n2 > kRsSortCap || need_run > (size_t)ra.dyn_bytes || need_setup > (size_t)ra.dyn_bytes) {
             if (tid == 0) ra.defer[w] = 1;
             return;
         }
@@ -196,16 +200,17 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
             if (tid == 0) { ra.status[w] = VSLAM_ERR_ARG; if (SCHED) ra.passes[w] = 0; }
             return;
         }
-        // sort keys: (12 - count) | keyframe set | landmark id: most observations first, equal sets adjacent, stable
+        // sort keys: count | keyframe set | landmark id: fewest observations first (the order vslam_build_windows_dev emits: its windows arrive sorted
+        // and skip the sort below), equal sets adjacent, stable
         int sorted_ok = 1;
         for (int l = tid; l < n2; l += kRsBlock) {
             unsigned key = 0xFFFFFFFFu;
             if (l < nl) {
                 const unsigned m = t_mask[l] & 0xFFFu;
-                key = ((unsigned)(12 - __popc(m)) << 25) | (m << 13) | (unsigned)l;
+                key = ((unsigned)__popc(m) << 25) | (m << 13) | (unsigned)l;
                 if (l + 1 < nl) {
                     const unsigned m1 = t_mask[l + 1] & 0xFFFu;
-                    const unsigned k1 = ((unsigned)(12 - __popc(m1)) << 12) | m1;
+                    const unsigned k1 = ((unsigned)__popc(m1) << 12) | m1;
                     if ((key >> 13) > k1) sorted_ok = 0;
                 }
             }
@@ -225,14 +230,14 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
                 }
             __syncthreads();
         }
-        // sorted tables; n_q = landmarks with more than q observations (a prefix of the sorted order)
+        // sorted tables; the landmarks with more than q observations are the SUFFIX [first_q, nl) of the sorted order (sm.nq[q] = nl - first_q of them)
         for (int s = tid; s < nl; s += kRsBlock) {
             const int l = (int)(keys[s] & 0x1FFFu);
             const unsigned m = t_mask[l];
             const unsigned m12 = m & 0xFFFu, lastk = (m >> 16) & 0xFu;
             const int c_here = __popc(m12);
-            const int c_next = s + 1 < nl ? __popc(t_mask[keys[s + 1] & 0x1FFFu] & 0xFFFu) : 0;
-            for (int q = c_next; q < c_here; ++q) sm.nq[q] = s + 1;
+            const int c_prev = s > 0 ? __popc(t_mask[keys[s - 1] & 0x1FFFu] & 0xFFFu) : 0;
+            for (int q = c_prev; q < c_here; ++q) sm.nq[q] = nl - s;
             perm[s] = (unsigned short)l;
             mstat[s] = (unsigned short)(m12 | ((unsigned)__popc(m12 & ((1u << lastk) - 1u)) << 12));
             inv[l] = (unsigned short)s;
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
         __syncthreads();
         if (tid == 0) {
             int acc = 0;
-            for (int q = 0; q <= kRsKf; ++q) { sm.slotoff[q] = acc; acc += q < kRsKf ? sm.nq[q] : 0; }
+            // slot q of sorted landmark s sits at [slotoff[q] + s]: slot q's entries start where the earlier slots end, its first landmark is nl - n_q
+            for (int q = 0; q <= kRsKf; ++q) { const int nqq = q < kRsKf ? sm.nq[q] : 0; sm.slotoff[q] = acc - (nl - nqq); acc += nqq; }
             if (acc != ne) sm.flag[7] = 3; // (cannot happen once duplicates are excluded; kept as a guard for the tables' bounds)
         }
         __syncthreads();
@@ -284,16 +290,16 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
     // LDS, its first kRsSlotsReg observations from the slot-major table (one independent, coalesced load each).  The observation loads of
     // the NEXT row a wave will visit are issued before the current row is worked on (uv_issue / row_open): two waves per SIMD do not cover a
     // trip to L2 / HBM per row on their own (2.9 k cycles per row measured before the prefetch).
-    // Rows [rs0, nrows) are SINGLES rows: every live landmark in them has exactly one observation (the sorted order puts them last).
+    // Rows [0, rm0) are SINGLES rows: every live landmark in them has exactly one observation (the sorted order puts them first).
     struct Row { int s; unsigned m; int lastq; double px, py, pz; float2 z[kRsSlotsReg]; unsigned U; int rc; };
     auto uv_issue = [&](int r, float2 (&z)[kRsSlotsReg]) {
         if (r >= nrows) return;
         const int s = 64 * r + lane;
         const int rc = __builtin_amdgcn_readfirstlane((int)sm.rowC[r]);
-        z[0] = uvs[min(sm.slotoff[0] + s, ne - 1)];
+        z[0] = uvs[max(min(sm.slotoff[0] + s, ne - 1), 0)];
 #pragma unroll
         for (int q = 1; q < kRsSlotsReg; ++q)
-            if (q < rc) z[q] = uvs[min(sm.slotoff[q] + s, ne - 1)]; // (uniform branch)
+            if (q < rc) z[q] = uvs[max(min(sm.slotoff[q] + s, ne - 1), 0)]; // (uniform branch)
     };
     auto row_open = [&](int r, const float2 (&z)[kRsSlotsReg], Row& R) {
         R.s = 64 * r + lane;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
         float2 z = R.z[0];
 #pragma unroll
         for (int i = 1; i < kRsSlotsReg; ++i) if (q == i) z = R.z[i];
-        if (q >= kRsSlotsReg) z = uvs[min(sm.slotoff[min(q, kRsKf - 1)] + R.s, ne - 1)];
+        if (q >= kRsSlotsReg) z = uvs[max(min(sm.slotoff[min(q, kRsKf - 1)] + R.s, ne - 1), 0)];
         return z;
     };
     // |entry| bound of one observation's contributions to the normal equations (see the header): (fx^2 + fy^2) g^2 + w chi
@@ -357,15 +363,15 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
     };
 
     // ---- one landmark-wise pass builds the whole reduced system at (sm.Rt, positions in LDS) for the given lambda.  Work items, drawn from an
-    // LDS counter (costliest first): the rows in front of rs0 one by one (multi-observation landmarks: generic path below), then the singles
+    // LDS counter (costliest first): the rows from the last down to rm0 one by one (multi-observation landmarks: generic path below), then the singles
     // rows in chunks of kRsChunk.  diag_only: only diag(H_pp) (fixed point, sm.hdq) and the largest |H_ll| diagonal entry (returned per
     // thread) -- computeLambdaInit; every row takes the generic path then.
     auto linearise = [&](double lambda, double scale, bool diag_only) -> double {
         double maxdiag = 0;
         const bool hitmode = !diag_only && sm.flag[9] != 0;
-        const int rs0 = diag_only ? nrows : sm.flag[8];
-        const int nitems = rs0 + (nrows - rs0 + kRsChunk - 1) / kRsChunk;
-        auto item_row = [&](int it) -> int { return it < rs0 ? it : rs0 + (it - rs0) * kRsChunk; };
+        const int rm0 = diag_only ? 0 : sm.flag[8], nmulti = nrows - rm0;
+        const int nitems = nmulti + (rm0 + kRsChunk - 1) / kRsChunk;
+        auto item_row = [&](int it) -> int { return it < nmulti ? nrows - 1 - it : (it - nmulti) * kRsChunk; };
         auto draw = [&]() -> int {
             int it = 0;
             if (lane == 0) it = atomicAdd(&sm.flag[6], 1);
@@ -378,9 +384,9 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
             const int next = draw();
             long long t_sub = cyc ? clock64() : 0;
 #define RSUB(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); atomicAdd(reinterpret_cast<unsigned long long*>(cyc) + (i), (unsigned long long)(t1__ - t_sub)); t_sub = t1__; } } while (0)
-            if (item >= rs0) {
+            if (item >= nmulti) {
                 // ---- singles chunk: contributions of consecutive rows accumulate in registers; folded when the keyframe changes
-                const int r0 = item_row(item), r1 = min(r0 + kRsChunk, nrows);
+                const int r0 = item_row(item), r1 = min(r0 + kRsChunk, rm0);
                 double acc[33];
 #pragma unroll
                 for (int i = 0; i < 33; ++i) acc[i] = 0;
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
                 continue;
             }
             // ---- generic row (landmarks with several observations)
-            const int r = item;
+            const int r = item_row(item);
             Row R; row_open(r, zn, R);
             if (next < nitems) uv_issue(item_row(next), zn);
             item = next;
@@ -629,8 +635,8 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
                     const int s = hit[min(j + lane, jend - 1)];
                     const unsigned m = live[s] & 0xFFFu;
                     const int q1 = __popc(m & ((1u << k1) - 1u)), q2 = __popc(m & ((1u << k2) - 1u));
-                    const float2 z1 = uvs[min(sm.slotoff[min(q1, kRsKf - 1)] + s, ne - 1)];
-                    const float2 z2 = uvs[min(sm.slotoff[min(q2, kRsKf - 1)] + s, ne - 1)];
+                    const float2 z1 = uvs[max(min(sm.slotoff[min(q1, kRsKf - 1)] + s, ne - 1), 0)];
+                    const float2 z2 = uvs[max(min(sm.slotoff[min(q2, kRsKf - 1)] + s, ne - 1), 0)];
                     const double2* dq = reinterpret_cast<const double2*>(Dc + 6 * (size_t)s);
                     const double2 Da = dq[0], Db = dq[1], Dcc = dq[2];
                     const double px = P[s], py = P[nlp + s], pz = P[2 * nlp + s];
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
     // position moved IN PLACE, the robust cost and the bound at the trial state (sm.RtT).  Static rows.
     auto backsub_pass = [&](double lambda, bool backup, double& scale_out, double& bound_out) -> double {
         double part = 0, bpart = 0, spart = 0;
-        const int rs0 = sm.flag[8];
+        const int rm0 = sm.flag[8];
         float2 zn[kRsSlotsReg];
         uv_issue(wave, zn);
         for (int r = wave; r < nrows; r += kRsWaves) {
@@ -724,7 +730,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
             if (R.U == 0) continue;
             const bool on = R.m != 0;
             if (backup && R.s < nl) { Pbak[R.s] = R.px; Pbak[nl + R.s] = R.py; Pbak[2 * (size_t)nl + R.s] = R.pz; }
-            if (r >= rs0) { // singles row
+            if (r < rm0) { // singles row
                 if (on) {
                     const int k = __builtin_ctz(R.m);
                     double x, y, rho, enx, eny, c, rob, wg, A[12], B[6], n00, n01, n11;
@@ -873,23 +879,23 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
         }
         for (int i = tid; i < nk * 7; i += kRsBlock) sm.T[i] = a.T[Tbase + i];
         __syncthreads();
-        if (tid == kRsBlock - 1) { // singles rows: the trailing run of rows whose live landmarks all have exactly one observation
-            int r = nrows;
-            while (r > 0 && sm.rowC[r - 1] <= 1) --r;
+        if (tid == kRsBlock - 1) { // singles rows: the leading run of rows whose live landmarks all have exactly one observation
+            int r = 0;
+            while (r < nrows && sm.rowC[r] <= 1) ++r;
             sm.flag[8] = r;
         }
         if (tid < nk) expand_pose(&sm.T[7 * tid], &sm.Rt[12 * tid]);
         __syncthreads();
-        {   // ---- hit lists of the multi-observation rows [0, rs0): per keyframe pair (k1 <= k2) the sorted landmarks that are live and see both,
+        {   // ---- hit lists of the multi-observation rows [rm0, nrows): per keyframe pair (k1 <= k2) the sorted landmarks that are live and see both,
             // in sorted order (count, prefix, write: a wave takes the pairs p = wave, wave + 8, ...).  Too many hits for the LDS the window leaves
             // free (or no such rows): flag[9] = 0, the rows then form their pairs themselves (row-wise path of the linearisation).
-            const int rs0 = sm.flag[8];
+            const int rm0 = sm.flag[8];
             for (int pass2 = 0; pass2 < 2; ++pass2) {
                 if (pass2 == 1 && !sm.flag[9]) break; // (uniform)
                 for (int p = wave; p < npairs; p += kRsWaves) {
                     const int k1 = sm.pk1[p], k2 = sm.pk2[p];
                     int run = pass2 ? sm.pairoff[p] : 0;
-                    for (int r = 0; r < rs0; ++r) {
+                    for (int r = rm0; r < nrows; ++r) {
                         const unsigned U = sm.rowU[r];
                         if (!((U >> k1) & 1u) || !((U >> k2) & 1u)) continue; // (uniform)
                         const unsigned m = live[64 * r + lane] & 0xFFFu;
@@ -914,7 +920,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
                             sm.itemoff[p + 1] = items;
                         }
                         sm.pairoff[npairs] = acc;
-                        sm.flag[9] = (rs0 > 0 && acc > 0 && acc <= hit_cap && items <= kRsHitItems) ? 1 : 0;
+                        sm.flag[9] = (rm0 < nrows && acc > 0 && acc <= hit_cap && items <= kRsHitItems) ? 1 : 0;
                     }
                     __syncthreads();
                 }
@@ -1182,6 +1188,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
                 }
                 if (j < 10) lastbits_lo |= (unsigned long long)bits << (6 * j); else lastbits_hi |= (unsigned long long)bits << (6 * (j - 10));
             }
+            if (cyc && tid == 0) { const long long t1__ = clock64(); atomicAdd(reinterpret_cast<unsigned long long*>(cyc) + 15, (unsigned long long)(t1__ - t_ph)); }
             double th = delta;
             if (classify) {
                 int v[6] = {cnt_out[0], cnt_out[1], cnt_out[2], cnt_out[3], cnt_out[4], cnt_all};
@@ -1252,7 +1259,7 @@ int launch_ba_resident(const RsLaunch& L, hipStream_t stream) {
     ra.a = L.a;
     ra.uv_s = reinterpret_cast<float2*>(L.uv_s); ra.epos = L.epos; ra.tab = L.tab; ra.xin = L.xin; ra.Pbak = L.Pbak; ra.Dc = L.Dc; ra.blc = L.blc;
     ra.status = L.status; ra.passes = L.passes; ra.defer = L.defer; ra.order = L.order; ra.dbg = L.dbg;
-    ra.dyn_bytes = L.dyn_bytes; ra.want_chi2 = L.a.chi2 != nullptr;
+    ra.dyn_bytes = L.dyn_bytes; ra.want_chi2 = L.a.chi2 != nullptr; ra.dense_to_general = L.dense_to_general;
     if (!L.opt_in_done) { // more than 64 KB of dynamic LDS needs the opt-in (once per context, i.e. per device)
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, L.dyn_bytes));
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, L.dyn_bytes));

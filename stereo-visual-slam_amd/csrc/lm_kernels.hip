@@ -1978,6 +1978,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         L.status = ka.status; L.passes = ka.passes; L.defer = scratch->defer; L.order = ka.order; L.dbg = getenv("VSLAM_RS_PROFILE") ? ka.dbg_cycles : nullptr;
         L.dyn_bytes = scratch->rs_dyn_bytes; L.schedule = schedule; L.adaptive = adaptive ? 1 : 0; L.iters = iters; L.update_poses = update_poses; L.update_lms = update_lms;
         L.opt_in_done = scratch->rs_opt_in;
+        L.dense_to_general = !(scratch->tune && scratch->tune->ba_resident == 1);
         if (schedule && !adaptive) hipLaunchKernelGGL(lm_fill_kernel, dim3((a.n_windows + 255) / 256), dim3(256), 0, stream, ka.passes, a.n_windows, 3);
         rc = launch_ba_resident(L, stream);
         if (rc) return rc;
@@ -1988,7 +1989,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
             std::vector<long long> h(kDbgSlots * (size_t)a.n_windows);
             hipMemcpy(h.data(), ka.dbg_cycles, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
             static const char* rs_names[16] = {"setup", "pass init", "boot evaluation", "lambda-init pass", "linearise", "convert+cholesky+solve", "pose update+backsub+trial eval",
-                                               "(loop tail)", "classification", "write-back", "lin: row fetch wait", "lin: landmark blocks", "lin: diag pair", "lin: off-diag pairs", "-", "-"};
+                                               "(loop tail)", "classification", "write-back", "lin: row open", "lin: landmark blocks", "lin: diag pair (row-wise)", "lin: off-diag pairs (row-wise)", "lin: singles chunks", "(classification: row loop)"};
             double tot = 0;
             for (int i = 0; i < 16; ++i) { double sum = 0; for (int w = 0; w < a.n_windows; ++w) sum += (double)h[16 * (size_t)w + i]; sum /= a.n_windows; if (i < 10) tot += sum; fprintf(stderr, "  [rs profile] %-32s %10.0f ticks/window\n", rs_names[i], sum); }
             fprintf(stderr, "  [rs profile] total %.0f (clock64 ticks)\n", tot);
@@ -2043,6 +2044,42 @@ int lm_fetch_status(const LmScratch* scratch, int n_windows, int32_t* h_status, 
     // the status words of the most recent launch live at a fixed offset that carve() recorded
     VS_HIP(hipMemcpyAsync(h_status, g_lm.status, sizeof(int32_t) * n_windows, hipMemcpyDeviceToHost, stream));
     VS_HIP(hipStreamSynchronize(stream));
+    return VSLAM_OK;
+}
+
+// diagnostic of rows A10 / A11: one lane per observation runs the device functions every LM kernel linearises with (cam_norm, eval_obs,
+// jac_norm, jac_point_norm) and scales the normalised-coordinate factors back to pixels: A = diag(fx, fy) At, B = diag(fx, fy) Bt, e = diag(fx, fy) en
+__global__ __launch_bounds__(256) void edge_jacobian_kernel(int n, const float* __restrict__ xyz, const float* __restrict__ uv, const double* __restrict__ T, double K0, double K1,
+                                                           double K2, double K3, double delta, double* __restrict__ err, double* __restrict__ Jp, double* __restrict__ Jl,
+                                                           double* __restrict__ chi2, double* __restrict__ hw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double K[4] = {K0, K1, K2, K3};
+    const CamK ck = make_camk(K);
+    double Tl[7], Rt[12];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) Tl[c] = T[c];
+    expand_pose(Tl, Rt);
+    double x, y, rho, enx, eny, c, rob, wg, A[12], B[6];
+    cam_norm(Rt, (double)xyz[3 * i], (double)xyz[3 * i + 1], (double)xyz[3 * i + 2], x, y, rho);
+    eval_obs(ck, x, y, reinterpret_cast<const float2*>(uv)[i], delta, enx, eny, c, rob, wg);
+    jac_norm(x, y, rho, A);
+    jac_point_norm(x, y, rho, Rt, B);
+    if (err) { err[2 * i] = ck.fx * enx; err[2 * i + 1] = ck.fy * eny; }
+    if (Jp)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { Jp[12 * i + a] = ck.fx * A[a]; Jp[12 * i + 6 + a] = ck.fy * A[6 + a]; }
+    if (Jl)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { Jl[6 * i + a] = ck.fx * B[a]; Jl[6 * i + 3 + a] = ck.fy * B[3 + a]; }
+    if (chi2) chi2[i] = c;
+    if (hw) hw[i] = wg;
+}
+int launch_edge_jacobians(int n, const float* d_xyz, const float* d_uv, const double* d_T, const double K[4], double delta, double* d_err, double* d_Jp, double* d_Jl,
+                          double* d_chi2, double* d_hw, hipStream_t stream) {
+    if (n <= 0) return VSLAM_OK;
+    hipLaunchKernelGGL(edge_jacobian_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_xyz, d_uv, d_T, K[0], K[1], K[2], K[3], delta, d_err, d_Jp, d_Jl, d_chi2, d_hw);
+    VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
 

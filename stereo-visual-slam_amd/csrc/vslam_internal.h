@@ -200,7 +200,8 @@ struct Tuning {
     int sgbm_fw_rows = -1;    // VSLAM_SGBM_FW_ROWS: 32 or 64 image rows per slab of the forward sweep
     int pose_only_window = -1; // VSLAM_POSE_ONLY_WINDOW: 1 = the schedule's pose-only pass on lm_window_kernel instead of pose_only_wave_kernel
     int pnp_window = -1;      // VSLAM_PNP_WINDOW: 1 = single-pose problems on lm_window_kernel<pnp> instead of pnp_wave_kernel
-    int ba_resident = -1;     // VSLAM_BA_RESIDENT: 0 = optimize_map windows always on lm_window_kernel (default: ba_resident_kernel for the windows that fit its LDS budget)
+    int ba_resident = -1;     // VSLAM_BA_RESIDENT: 0 = optimize_map windows always on lm_window_kernel; 1 = on ba_resident_kernel whenever they fit its LDS budget;
+                              // default: ba_resident_kernel for the windows that fit and have at most 2.2 observations per landmark (the windows of a real sequence)
     int ba_adaptive = -1;     // VSLAM_BA_ADAPTIVE: 0 = the BA schedule runs all three optimize_map passes for every window (default: a pass that flags nothing new is continued instead of repeated)
 };
 int launch_sgbm(const Tuning& tune, const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
@@ -223,7 +224,7 @@ struct RsLaunch {
     LmWindowArgs a;
     void* uv_s; int32_t* epos; double* tab; double* xin; double* Pbak; double* Dc; double* blc; // scratch slices (see RsArgs)
     int32_t* status; int32_t* passes; int32_t* defer; const int32_t* order; long long* dbg;
-    int dyn_bytes, schedule, adaptive, iters, update_poses, update_lms;
+    int dyn_bytes, schedule, adaptive, iters, update_poses, update_lms, dense_to_general;
     bool opt_in_done;
 };
 int rs_dyn_lds_bytes(int device);
@@ -241,6 +242,8 @@ struct PnpArgs {
     int n_hint; // points per problem when the host knows it (0 = unknown): picks the kernel in launch_pnp
 };
 int launch_pnp(const PnpArgs& a, LmScratch* scratch, hipStream_t stream);
+int launch_edge_jacobians(int n, const float* d_xyz, const float* d_uv, const double* d_T, const double K[4], double delta, double* d_err, double* d_Jp, double* d_Jl,
+                          double* d_chi2, double* d_hw, hipStream_t stream);
 // pnp_kernels.hip: EPnP of H 5-point subsets (one wave each) -> R|t (H x 12), pose (H x 7), ok flag; f32 inlier scoring of hypotheses
 size_t pnp_epnp_ws_bytes(int H);
 int launch_pnp_epnp(const float* d_hx, const float* d_hu, int H, const double K[4], double* d_Rt, double* d_T, int32_t* d_ok, uint8_t* ws, hipStream_t stream);
