@@ -421,6 +421,105 @@ def ba_config4_measure(args, local, torch):
         pipe.close()
 
 
+def inflight_overlap(ring, args, timed_region, one_step):
+    """`steps` steps with every pipeline in flight and every pipeline's stage profiler on: the hipEvent brackets of all of them on one time axis.
+    overlap_share = part of the busy span with >= 2 kernel families running; sum_kernel_ms_over_span_ms = their durations added up over the span
+    (1.0 = nothing overlaps); per family: its share of the added-up durations."""
+    for p_ in ring.pipes:
+        p_.vo.profile_enable(True); p_.vo.profile_read()
+    el = timed_region(one_step)
+    iv = []
+    for i, p_ in enumerate(ring.pipes):
+        iv += [(n, a, b, i) for n, a, b in p_.vo.profile_intervals() if b > a]
+        p_.vo.profile_enable(False)
+    if not iv:
+        return None
+    t0 = min(a for _, a, _, _ in iv); t1 = max(b for _, _, b, _ in iv)
+    ev = sorted([(a, 1) for _, a, _, _ in iv] + [(b, -1) for _, _, b, _ in iv])
+    busy = over = 0.0; depth = 0; last = t0
+    for t, d in ev:
+        if depth >= 1: busy += t - last
+        if depth >= 2: over += t - last
+        depth += d; last = t
+    total = sum(b - a for _, a, b, _ in iv)
+    fam = {}
+    for n, a, b, _ in iv:
+        fam[n] = fam.get(n, 0.0) + (b - a)
+    return {"steps": args.steps, "pipelines": len(ring.pipes), "span_ms": round(t1 - t0, 3), "busy_ms": round(busy, 3), "ms_per_step_with_brackets": round(1e3 * el / args.steps, 4),
+            "overlap_share": round(over / busy, 4) if busy > 0 else None, "sum_kernel_ms_over_span_ms": round(total / (t1 - t0), 4) if t1 > t0 else None,
+            "family_ms_per_step_in_flight": {k_: round(v / args.steps, 4) for k_, v in sorted(fam.items(), key=lambda kv: -kv[1])},
+            "how": "vslam_profile_intervals of every pipeline (hipEvent brackets around each kernel family on its stream, one time origin per process); a bracket "
+                   "covers a family's launches back to back, so gaps inside a family count as busy"}
+
+
+def config4_step_measure(args, local, torch, seqs):
+    """the SAME step (front end on the rendered frames, pose stage) with the BA schedule on canned windows of the BASELINE config-4 shape (10 keyframes x
+    3000 landmarks, ~10.5 k edges) instead of the windows the step's own tracks give (3.5 k landmarks, 4.6 k edges): keyframes/s at the config-4 BA shape"""
+    from stereo_visual_slam_amd.pipeline import PipelineRing
+    n_flight = max(1, args.in_flight)
+    ring = PipelineRing(n_flight, args.batch, sequences=seqs[:n_flight], device=local, anms_num=args.anms, n_lm=3000, unique_frames=len(seqs[0]), ba_windows="synthetic",
+                        unique_windows=min(args.batch, 256))
+    pipe = ring.pipes[0]
+    try:
+        for _ in range(2 * n_flight):
+            ring.step()
+        torch.cuda.synchronize(pipe.dev)
+        n = max(args.steps // 2, 4)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ring.step()
+        torch.cuda.synchronize(pipe.dev)
+        el = time.perf_counter() - t0
+        bad = sum(int((p_.vo.orb_status(2 * p_.B) != 0).sum()) + int((p_.vo.ba_status(p_.B) != 0).sum()) for p_ in ring.pipes)
+        if bad:
+            return {"error": "status words non-zero (%d)" % bad}
+        return {"value": round(args.batch * n / el, 2), "unit": "keyframes/s", "ms_per_step": round(1e3 * el / n, 4), "steps": n, "batch": args.batch, "batches_in_flight": n_flight,
+                "workload": "the default step with its BA schedule run on canned synthetic windows of the config-4 shape (10 KF x 3000 landmarks x %.0f edges, %d unique windows) "
+                            "instead of the windows built from the step's tracks" % (pipe.edges_per_window, pipe.unique_windows)}
+    finally:
+        ring.close()
+
+
+def live_dropin_measure(n_frames=50, anms=500, with_cpu=True, cpu_frames=12):
+    """The drop-in itself: the C++ host mirror of the reference's node loop (host/run_vslam: VO::pipeline per frame, the BA schedule per keyframe, run_vslam.cpp:40-82) on 50
+    rendered stereo pairs read from PNG files, reference-faithful configuration (ANMS 500, SGBM depth, solvePnPRansac pose, Q1 quirk on) -- one frame at a time through the
+    host-buffer tier of the C-ABI, i.e. live-SLAM latency, not batch throughput.  Beside it (part of the cpu_baseline leg) the same host code on the CPU oracle
+    (oracle/run_vslam_cpu) over the first `cpu_frames` pairs."""
+    import subprocess
+    import tempfile
+    from stereo_visual_slam_amd import synth
+    gpu_exe = os.path.join(ROOT, "stereo-visual-slam_amd", "host", "run_vslam"); cpu_exe = os.path.join(ROOT, "oracle", "run_vslam_cpu")
+    if not os.path.exists(gpu_exe):
+        return {"error": "host/run_vslam not built (python -c 'import __graft_entry__ as g; g.build()')"}
+
+    def run(exe, d, n):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, d + "/", str(n), "0", str(anms), os.path.join(d, "traj.txt"), "1", "1", "1"], capture_output=True, text=True, timeout=1500)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stdout[-200:] + r.stderr[-200:]).strip()}
+        line = [l for l in r.stdout.splitlines() if l.startswith("timing ")]
+        summ = [l for l in r.stdout.splitlines() if l.startswith("frames ")]
+        out = {"process_wall_s": round(wall, 2), "summary": summ[-1] if summ else None}
+        if line:
+            t = line[-1].split()
+            kv = {t[i]: float(t[i + 1]) for i in range(1, len(t) - 1, 2)}
+            out.update(loop_s=kv.get("loop_s"), frames=int(kv.get("frames", 0)), frames_per_s=kv.get("frames_per_s"), keyframes_per_s=kv.get("keyframes_per_s"),
+                       s_per_keyframe=kv.get("s_per_keyframe"))
+        return out
+
+    with tempfile.TemporaryDirectory() as d:
+        synth.write_pgm_sequence(d + "/", n_frames, seed=5, fmt="png")
+        res = {"frames": n_frames, "config": "ANMS %d, SGBM depth + find_3d, solvePnPRansac(100, 4.0, 0.99), BA schedule 5+5+10+10 per keyframe on the 10-keyframe map, "
+                                             "Q1 quirk on; PNG pairs read from disk per frame; the frame loop only (context creation excluded)" % anms,
+               "reference_figure": "the reference's README.md:90 quotes 0.18 s per keyframe on its authors' CPU (not reproducible here: OpenCV / g2o absent)",
+               "gpu": run(gpu_exe, d, n_frames)}
+        if with_cpu and os.path.exists(cpu_exe):
+            res["cpu"] = run(cpu_exe, d, min(cpu_frames, n_frames))
+            res["cpu"]["note"] = "oracle/run_vslam_cpu: the same host code over the CPU oracle behind the same C-ABI, first %d pairs, one thread" % min(cpu_frames, n_frames)
+        return res
+
+
 def reference_pipeline_measure(args, local, torch, seq, B=256):
     """The REFERENCE's own stages in throughput mode, measured in the default run so that the driver records it: depth from StereoSGBM +
     Frame::find_3d on the left keypoints (visual_odometry.cpp:159-217) instead of L/R match + DLT, pose from cv::solvePnPRansac(..., 100, 4.0,
@@ -616,7 +715,10 @@ def main():
                          "always come from a repeat with ONE batch in flight (kernels of two batches sharing the chip have no duration of their own)")
     ap.add_argument("--anms", type=int, default=1500, help="keypoints per image after ANMS (BASELINE config 2: ~1500; reference: 500)")
     ap.add_argument("--landmarks", type=int, default=3000)
-    ap.add_argument("--unique-frames", type=int, default=256, help="rendered stereo keyframes (one sequence, laid over the batch as a ping-pong)")
+    ap.add_argument("--unique-frames", type=int, default=0, help="rendered stereo keyframes per pipeline (one sequence, laid over the batch as a ping-pong); 0 = the batch size: "
+                                                                  "every keyframe of a batch is a different rendered frame, and every pipeline in flight renders its own sequence")
+    ap.add_argument("--no-config4-step", action="store_true", help="skip the extra timed steps with canned config-4-shaped BA windows (`value_config4_windows`)")
+    ap.add_argument("--no-live-dropin", action="store_true", help="skip the C++ host driver run (host/run_vslam on 50 rendered pairs: the drop-in's own frames/s)")
     ap.add_argument("--inputs", choices=["resident", "host"], default="host",
                     help="host: additionally time the same steps with the images arriving from pinned host memory (ring of 2 batches, "
                          "hipMemcpyAsync on a copy stream overlapped with the previous step) and report it under `inputs_from_host`; "
@@ -681,6 +783,8 @@ def main():
     from stereo_visual_slam_amd import sharding
     B = args.batch
     seq_mode = args.sequence > 0
+    if args.unique_frames <= 0:
+        args.unique_frames = args.sequence if seq_mode else B
     n_flight = 1 if seq_mode else max(1, args.in_flight)   # (sequence mode: a step is one pass over THE sequence; kept at one pass in flight)
     ba_windows = args.ba_windows  # (sequence mode: a chunk's map starts at its halo frame, like the map of a sequence starts at frame 0; the BA
                                   # results are not fed back into the gathered trajectory in either mode)
@@ -693,7 +797,7 @@ def main():
                             with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence),
                             render_workers=render_workers, ba_windows=ba_windows, pose=args.pose)
     else:
-        ring = PipelineRing(n_flight, B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
+        ring = PipelineRing(n_flight, B, distinct=True, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=1000 * rank, verbose=args.verbose and rank == 0,
                             with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, render_workers=render_workers,
                             ba_windows=ba_windows, pose=args.pose)
     pipe = ring.pipes[0]
@@ -765,6 +869,31 @@ def main():
     prof = pipe.vo.profile_read()
     pipe.vo.profile_enable(False)
     n_prof_steps = args.steps
+    # ... and the attribution of the HEADLINE configuration: the same steps with all pipelines in flight and every pipeline's brackets on ONE time
+    # axis (vslam_profile_intervals): how much of the busy span has two or more kernel families running, and the sum of their durations over the span
+    overlap = None
+    if n_flight > 1 and world == 1:
+        try:
+            overlap = inflight_overlap(ring, args, timed_region, one_step)
+        except Exception as e:
+            overlap = {"error": repr(e)}
+    # the pipelines in flight are handed DIFFERENT frames; that sharing the chip changes nobody's bits is checked by stepping each pipeline once more
+    # alone and comparing with what it produced in flight
+    flight_same = None
+    if n_flight > 1 and world == 1 and not seq_mode:
+        keys = ["kps", "desc", "lr", "f2f", "Tpnp", "inl"] + (["ba_T", "ba_inl"] if pipe.with_ba else [])
+        one_step(); one_step()
+        torch.cuda.synchronize(dev)
+        inflight_out = [p_.download() for p_ in ring.pipes]
+        flight_same = True
+        for p_, o1 in zip(ring.pipes, inflight_out):
+            p_.step(); torch.cuda.synchronize(dev)
+            o2 = p_.download()
+            flight_same = flight_same and all(np.array_equal(o1[k_], o2[k_]) for k_ in keys)
+            del o2
+        del inflight_out
+        if not flight_same:
+            raise SystemExit("bench invalid: a pipeline produced different results in flight beside another one than alone, on the same inputs")
     host_inputs = None
     if args.inputs == "host" and not seq_mode and world == 1:
         try:
@@ -783,16 +912,7 @@ def main():
     if rank == 0:
         out = pipe.download()
         pipe.ba_passes = pipe.vo.ba_schedule_passes(pipe.B) if pipe.with_ba else None
-        flight_same = None
-        if len(ring) > 1:   # the pipelines were handed the same images: whatever ran beside them, their results must be the same bits
-            keys = ["kps", "desc", "lr", "f2f", "Tpnp", "inl"] + (["ba_T", "ba_inl"] if pipe.with_ba else [])
-            flight_same = True
-            for p_ in ring.pipes[1:]:
-                o2 = p_.download()
-                flight_same = flight_same and all(np.array_equal(out[k_], o2[k_]) for k_ in keys)
-                del o2
-            if not flight_same:
-                raise SystemExit("bench invalid: pipelines in flight together produced different results on the same inputs")
+        other_seqs = [p_.h_seq for p_ in ring.pipes[1:]]
         for p_ in ring.pipes[1:]:
             p_.close()
         pipe.ba_shape = None
@@ -859,8 +979,9 @@ def main():
                        "batch_keyframes_per_gpu": B, "image": "1241x376 u8",
                        "batches_in_flight_per_gpu": len(ring),
                        "ba_windows": pipe.ba_windows if pipe.with_ba else None,
-                       "unique_inputs": "%d rendered stereo keyframes of one sequence (ping-pong over the batch), %d BA windows (%s)" % (
-                           pipe.unique_frames, pipe.unique_windows if pipe.with_ba else 0, "built from the step's tracks" if pipe.ba_windows == "tracks" else "canned"),
+                       "unique_inputs": "%d rendered stereo keyframes per pipeline (one sequence each, ping-pong over the batch when shorter than it; %s), %d BA windows (%s)" % (
+                           pipe.unique_frames, "every pipeline in flight its own sequence" if getattr(ring, "distinct", False) else "the pipelines share the frames",
+                           pipe.unique_windows if pipe.with_ba else 0, "built from the step's tracks" if pipe.ba_windows == "tracks" else "canned"),
                        "parallelism": ("one %d-frame sequence in %d contiguous chunks with a 1-frame halo, relative poses gathered and chained on rank 0" % (args.sequence, world))
                                       if seq_mode else "%d independent replicas, sharded keyframes" % world},
             "timing": {"repeats": len(rep_s), "ms_per_step_each": [round(1e3 * x / args.steps, 4) for x in rep_s], "reported": "median",
@@ -870,7 +991,8 @@ def main():
                                             "the whole hot path over one batch of %d keyframes; the timed region ends with a device-wide synchronize" % (len(ring), B),
                                      "one_batch_in_flight": None if serial_s is None else {"ms_per_step": round(1e3 * serial_s / args.steps, 4),
                                                                                             "value": round(units_per_step(args, seq_mode, world, B) * args.steps / serial_s, 3)},
-                                     "results_identical_across_pipelines": flight_same},
+                                     "results_identical_in_flight_and_alone": flight_same,
+                                     "overlap": overlap},
                        "ba_schedule": None if not pipe.with_ba else dict(
                            schedule_stats(pipe.ba_passes), mode="plain (--ba-plain-schedule)" if args.ba_plain_schedule else "adaptive (default)",
                            plain_schedule=None if plain_s is None else {"ms_per_step": round(1e3 * plain_s / args.steps, 4),
@@ -920,6 +1042,16 @@ def main():
                     res["ba_config4"] = ba_config4_measure(args, local, torch)
                 except Exception as e:
                     res["ba_config4"] = {"error": repr(e)}
+            if not args.no_config4_step:
+                try:
+                    res["value_config4_windows"] = config4_step_measure(args, local, torch, [pipe.h_seq] + other_seqs)
+                except Exception as e:
+                    res["value_config4_windows"] = {"error": repr(e)}
+            if not args.no_live_dropin:
+                try:
+                    res["live_dropin"] = live_dropin_measure(with_cpu=not args.no_cpu_baseline)
+                except Exception as e:
+                    res["live_dropin"] = {"error": repr(e)}
         if extras_ok and not args.no_cpu_baseline:
             res["cpu_baseline"], res["pose_rmse_vs_oracle"] = (cpu_baseline_tracks if pipe.ba_windows == "tracks" else cpu_baseline)(pipe, out, args.anms)
             info, have_cv2 = host_info()
@@ -940,6 +1072,27 @@ def main():
             else:
                 res["cpu_baseline"]["reference_libs_timing"] = "unavailable on this host (no cv2 / OpenCV / g2o found at run time)"
                 res["cpu_baseline"]["host"]["reference_libs_pin"] = "skipped: no cv2 on this host (tests/test_reference_libs_pin.py)"
+        # scalars of the extra measurements, repeated inside `config` (a record that keeps only the contract's keys still carries them)
+        def _g(d, *ks):
+            for k_ in ks:
+                d = d.get(k_) if isinstance(d, dict) else None
+            return d
+        res["config"]["extras"] = {
+            "one_batch_in_flight_keyframes_per_s": _g(res, "timing", "in_flight", "one_batch_in_flight", "value"),
+            "plain_ba_schedule_keyframes_per_s": _g(res, "timing", "ba_schedule", "plain_schedule", "value"),
+            "overlap_share_two_or_more_kernels": _g(res, "timing", "in_flight", "overlap", "overlap_share"),
+            "sum_kernel_ms_over_span_ms": _g(res, "timing", "in_flight", "overlap", "sum_kernel_ms_over_span_ms"),
+            "inputs_from_host_keyframes_per_s": _g(res, "inputs_from_host", "value"),
+            "value_config4_windows_keyframes_per_s": _g(res, "value_config4_windows", "value"),
+            "reference_pipeline_keyframes_per_s": _g(res, "reference_pipeline", "value"),
+            "reference_pipeline_sgbm_ms_per_pair": _g(res, "reference_pipeline", "roofline", "ms_per_pair"),
+            "ba_config4_ms_per_schedule_batch_256": _g(res, "ba_config4", "ms_per_schedule_batch"),
+            "ba_built_windows_ms_per_schedule_batch": _g(res, "roofline", "avg_ms_per_launch_set"),
+            "live_dropin_frames_per_s": _g(res, "live_dropin", "gpu", "frames_per_s"),
+            "live_dropin_keyframes_per_s": _g(res, "live_dropin", "gpu", "keyframes_per_s"),
+            "live_dropin_cpu_path_frames_per_s": _g(res, "live_dropin", "cpu", "frames_per_s"),
+            "pose_rmse_vs_oracle_m": _g(res, "pose_rmse_vs_oracle", "ba_translation_rmse_m"),
+        }
         print(json.dumps(res), flush=True)
     ring.close()
     if world > 1:

@@ -11,6 +11,7 @@
 // reference's solvePnPRansac control flow, 0 = motion-only Huber LM.  The defaults are the reference's algorithm.
 // trace_path: one line per frame / per BA run with the integer decisions and the f64 poses (%.17g), for the
 // CPU-path vs GPU-path parity test (tests/test_gpu_host_driver.py).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -54,6 +55,7 @@ int main(int argc, char** argv) {
     // run_vslam.cpp:34-38: K and the baseline are constants of the node (the same numbers Frame carries, types_def.hpp:53-54)
     const vslam::Mat33 K = {p.cam[0], 0, p.cam[2], 0, p.cam[1], p.cam[3], 0, 0, 1};
     int n_keyframes = 0, n_ok = 0, n_ba = 0;
+    const auto loop_t0 = std::chrono::steady_clock::now(); // (the frame loop: image read + pipeline + BA schedule, what README.md:90 of the reference times per keyframe)
     for (int ite = 0; ite < n_frames; ite++) { // run_vslam.cpp:40
         bool if_insert_keyframe = false;
         const bool not_lost = my_VO.pipeline(if_insert_keyframe);
@@ -89,12 +91,15 @@ int main(int argc, char** argv) {
         }
         if (!not_lost) break;
     }
+    const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count();
     if (if_write_pose) my_map.write_remaining_pose(); // :84-87
     if (trace) std::fclose(trace);
     std::printf("frames %d keyframes_inserted %d ba_runs %d map_keyframes %zu landmarks %zu last_inliers %d\n", my_VO.seq_, n_keyframes, n_ba,
                 my_map.keyframes_.size(), my_map.landmarks_.size(), my_VO.num_inliers_);
     const auto t = my_VO.T_c_w_.inverse().translation();
     std::printf("final_position %.6f %.6f %.6f\n", t[0], t[1], t[2]);
+    std::printf("timing loop_s %.6f frames %d frames_per_s %.3f keyframes_per_s %.3f s_per_keyframe %.6f\n", loop_s, my_VO.seq_, my_VO.seq_ / loop_s,
+                n_keyframes / loop_s, n_keyframes > 0 ? loop_s / n_keyframes : 0.0);
     vslam::clear_optimizer_backend(ctx); // (my_VO outlives this statement: unbind before the context goes)
     vslam_destroy(ctx);
     return 0;

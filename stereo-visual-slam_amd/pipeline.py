@@ -284,15 +284,28 @@ class PipelineRing:
     stepping alone (tests/test_gpu_pipeline.py).  A third pipeline adds nothing (41.8 k at 3 x 256).
     step() hands the next batch to pipeline k mod P and returns without synchronising; sync() waits for all of them."""
 
-    def __init__(self, P, B, **kw):
+    def __init__(self, P, B, distinct=False, sequences=None, **kw):
+        """distinct: every pipeline renders (or is handed, `sequences[i]`) ITS OWN sequence of frames -- seed + 7919 i -- so that the batches in flight
+        together are different data; otherwise all pipelines show the first one's frames (tests compare their results bit for bit)"""
         assert P >= 1
-        first = KeyframePipeline(B, **kw)
-        kw2 = dict(kw)
-        kw2["sequence"] = first.h_seq          # the other pipelines show the same rendered frames: no second rendering
-        kw2["unique_frames"] = first.unique_frames
-        kw2["render_workers"] = 0
-        kw2["verbose"] = False
-        self.pipes = [first] + [KeyframePipeline(B, **kw2) for _ in range(P - 1)]
+        kw0 = dict(kw)
+        if sequences is not None:
+            kw0["sequence"] = sequences[0]
+        first = KeyframePipeline(B, **kw0)
+        self.pipes = [first]
+        for i in range(1, P):
+            kw2 = dict(kw)
+            kw2["unique_frames"] = first.unique_frames
+            kw2["verbose"] = False
+            if sequences is not None and i < len(sequences):
+                kw2["sequence"] = sequences[i]; kw2["render_workers"] = 0
+            elif distinct:
+                kw2["seed"] = kw.get("seed", 0) + 7919 * i
+            else:
+                kw2["sequence"] = first.h_seq          # the other pipelines show the same rendered frames: no second rendering
+                kw2["render_workers"] = 0
+            self.pipes.append(KeyframePipeline(B, **kw2))
+        self.distinct = distinct or (sequences is not None and len(sequences) > 1)
         self.k = 0
 
     def __len__(self):

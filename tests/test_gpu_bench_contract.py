@@ -54,7 +54,20 @@ def test_bench_line_contract():
     # two batches in flight by default (pipeline.PipelineRing): the line says so, carries the one-batch figure beside it, and the run itself
     # checked that the pipelines produced the same bits
     fl = r["timing"]["in_flight"]
-    assert fl["batches"] == 2 and r["config"]["batches_in_flight_per_gpu"] == 2 and fl["results_identical_across_pipelines"] is True
+    assert fl["batches"] == 2 and r["config"]["batches_in_flight_per_gpu"] == 2 and fl["results_identical_in_flight_and_alone"] is True
+    # round 5: the pipelines in flight show different frames; the headline configuration has its own attribution (brackets of both pipelines on one time axis)
+    assert "its own sequence" in r["config"]["unique_inputs"]
+    ov = fl["overlap"]
+    assert ov["pipelines"] == 2 and 0.0 <= ov["overlap_share"] <= 1.0 and ov["sum_kernel_ms_over_span_ms"] > 0.5 and "lm_window_kernel" in ov["family_ms_per_step_in_flight"]
+    # ... the same step at the config-4 BA shape, the drop-in's own frames/s, and the scalars of every extra measurement inside `config`
+    v4 = r["value_config4_windows"]
+    assert v4["value"] > 0 and v4["unit"] == "keyframes/s" and v4["batch"] == 16
+    ld = r["live_dropin"]
+    assert ld["gpu"]["frames"] == 50 and ld["gpu"]["frames_per_s"] > 1 and ld["gpu"]["keyframes_per_s"] > 0 and ld["cpu"]["frames_per_s"] > 0
+    ex = r["config"]["extras"]
+    assert ex["value_config4_windows_keyframes_per_s"] == v4["value"] and ex["reference_pipeline_keyframes_per_s"] == rp["value"]
+    assert ex["ba_config4_ms_per_schedule_batch_256"] == c4["ms_per_schedule_batch"] and ex["one_batch_in_flight_keyframes_per_s"] == fl["one_batch_in_flight"]["value"]
+    assert ex["live_dropin_frames_per_s"] == ld["gpu"]["frames_per_s"] and ex["overlap_share_two_or_more_kernels"] == ov["overlap_share"]
     assert fl["one_batch_in_flight"]["value"] > 0 and r["inputs_from_host"]["batches_in_flight"] == 2
     assert rp["batches_in_flight"] == 2 and rp["one_batch_in_flight"]["value"] > 0
     # the BA schedule continues a pass that flags nothing new instead of repeating it: the line says what it did and carries the plain schedule's figure
