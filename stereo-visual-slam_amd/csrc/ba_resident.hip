@@ -1216,8 +1216,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
                     if (lv & 0xFFFu) {
                         const unsigned b6 = j < 10 ? (unsigned)(lastbits_lo >> (6 * j)) : (unsigned)(lastbits_hi >> (6 * (j - 10)));
                         const bool keep = ((b6 >> ti) & 1u) == 0;
-                        a.lm_inlier[lm0 + perm[s]] = keep;
-                        if (!keep) { live[s] = 0; newly_flagged = 1; }
+                        if (!keep) { a.lm_inlier[lm0 + perm[s]] = 0; live[s] = 0; newly_flagged = 1; } // (a live landmark's flag is 1: only a change is written)
                     }
                 }
                 if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;

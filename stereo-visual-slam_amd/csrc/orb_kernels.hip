@@ -954,6 +954,15 @@ constexpr int kAnmsBrute = 160; // at most this many stronger keypoints: scannin
 // K3b orb_orient_kernel: intensity-centroid orientation of the keypoints that survived the ANMS, and the (cos, sin) of the rBRIEF
 // rotation.  A 16-lane group per keypoint (four per wave); a fixed set of groups per image walks the list.  The level
 // coordinates are recovered as cvRound(pt / scale), the same identity the descriptor stage uses (orb.cpp computeDescriptors).
+// XCD-aware numbering of the (image, block) grids of the two patch-gathering kernels below: the hardware deals workgroups to the eight XCDs
+// round-robin by their linear id, and every XCD has its own L2.  With a (blocks, images) grid the nb blocks of ONE image land on all eight
+// XCDs, and every L2 fetches most of that image's pyramid for itself (rocprofv3, round 4: 5.0 MB fetched per image for a 1.9 MB blurred
+// pyramid).  Here the linear id is cut so that all blocks of image b have id = b (mod 8): one L2 serves an image's patches.
+__device__ inline bool xcd_image_block(int nb, int B, int& b, int& bx) {
+    const int id = blockIdx.x, per = 8 * nb, g = id / per, r = id - g * per;
+    b = 8 * g + (r & 7); bx = r >> 3;
+    return b < B;
+}
 #ifndef VSLAM_ORIENT_BLOCKS
 #define VSLAM_ORIENT_BLOCKS 48
 #endif
@@ -961,11 +970,12 @@ constexpr int kOrientBlocks = VSLAM_ORIENT_BLOCKS, kOrientThreads = 256;
 __global__ __launch_bounds__(kOrientThreads) void orb_orient_kernel(LevelTable T, const uint8_t* __restrict__ d_imgs, size_t img_bytes, int pitch0,
                                                                   const uint8_t* __restrict__ d_pyr, size_t pyr_bytes,
                                                                   vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, const int32_t* __restrict__ d_order,
-                                                                  int kp_capacity, const int32_t* __restrict__ d_count) {
-    const int b = blockIdx.y;
+                                                                  int kp_capacity, const int32_t* __restrict__ d_count, int nb, int B) {
+    int b, bx;
+    if (!xcd_image_block(nb, B, b, bx)) return; // (uniform)
     const int n = min(d_count[b], kp_capacity);
-    const int ngrp = gridDim.x * (kOrientThreads >> 4);
-    const int grp = blockIdx.x * (kOrientThreads >> 4) + (threadIdx.x >> 4);
+    const int ngrp = nb * (kOrientThreads >> 4);
+    const int grp = bx * (kOrientThreads >> 4) + (threadIdx.x >> 4);
     vslam_keypoint* kps = d_kps + (size_t)b * kp_capacity;
     const IcRowWeights icw = ic_row_weights();
     // the f64 cos / sin of the rotation is evaluated AFTER the walk, one lane per keypoint of this workgroup (inside the walk it would
@@ -1013,8 +1023,8 @@ int launch_orb_orient(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
     fill_level_table(plan, &T);
     if (kp_capacity > 16 * kOrientBlocks * (kOrientThreads >> 4)) { set_error("kp_capacity %d exceeds the orientation walk (%d)", kp_capacity, 16 * kOrientBlocks * (kOrientThreads >> 4)); return VSLAM_ERR_ARG; }
     ProfScope prof__(stream, "orb_orient_kernel");
-    hipLaunchKernelGGL(orb_orient_kernel, dim3(kOrientBlocks, B), dim3(kOrientThreads), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
-                       (size_t)plan.pyr_bytes, d_kps, d_cs, d_order, kp_capacity, d_count);
+    hipLaunchKernelGGL(orb_orient_kernel, dim3(kOrientBlocks * ((B + 7) / 8 * 8)), dim3(kOrientThreads), 0, stream, T, d_imgs, img_bytes, pitch, d_pyr,
+                       (size_t)plan.pyr_bytes, d_kps, d_cs, d_order, kp_capacity, d_count, kOrientBlocks, B);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
@@ -1606,14 +1616,15 @@ __global__ __launch_bounds__(kDescWaves * 64) void orb_describe_kernel(BlurTable
                                                                       size_t pyr_bytes, const uint8_t* __restrict__ d_blur, size_t blur_bytes,
                                                                       const vslam_keypoint* __restrict__ d_kps, const float2* __restrict__ d_cs,
                                                                       const int32_t* __restrict__ d_order, int kp_capacity,
-                                                                      const int32_t* __restrict__ d_count, uint8_t* __restrict__ d_desc) {
-    const int b = blockIdx.y;
+                                                                      const int32_t* __restrict__ d_count, uint8_t* __restrict__ d_desc, int nb, int B) {
+    int b, bx;
+    if (!xcd_image_block(nb, B, b, bx)) return; // (uniform; no block-level barrier below)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nwaves = gridDim.x * kDescWaves;
+    const int nwaves = nb * kDescWaves;
     const int n = min(d_count[b], kp_capacity);
     // the wave visits walk positions i = wave id + k * #waves; lane k preloads the output slot of the k-th visit (d_order: the slots in
     // (octave, raster) order, so that waves running side by side fetch neighbouring patches)
-    const int i0 = blockIdx.x * kDescWaves + wave; // wave-uniform
+    const int i0 = bx * kDescWaves + wave; // wave-uniform
     if (i0 >= n) return; // no block-level barrier below
     int slots;
     {
@@ -1740,8 +1751,8 @@ int launch_orb_describe(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_b
     const int max_kp = min(kp_capacity, kMaxRows);
     const int blocks = min(kDescBlocksPerImage, (max_kp + kDescWaves - 1) / kDescWaves);
     ProfScope prof__(stream, "orb_describe_kernel");
-    hipLaunchKernelGGL(orb_describe_kernel, dim3(blocks, B), dim3(kDescWaves * 64), 0, stream, T, LT, d_imgs,
-                       img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_blur, (size_t)plan.blur_bytes, d_kps, d_cs, d_order, kp_capacity, d_count, d_desc);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3(blocks * ((B + 7) / 8 * 8)), dim3(kDescWaves * 64), 0, stream, T, LT, d_imgs,
+                       img_bytes, pitch, d_pyr, (size_t)plan.pyr_bytes, d_blur, (size_t)plan.blur_bytes, d_kps, d_cs, d_order, kp_capacity, d_count, d_desc, blocks, B);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }

@@ -30,11 +30,14 @@ if os.path.exists(sq):
         if any(name.startswith(p) for p in prefixes):
             m = {k: float(v) for k, v in re.findall(r"(\w+)\s+([0-9][0-9.e+]*)%?", line)}
             rows[name] = line.strip()
-            if name.startswith("lm_window_kernel<false"):
+            if name.startswith("lm_window_kernel<false") or name.startswith("ba_resident_kernel"):
                 d = int(m.get("disp", 0)) or 1
-                per_sched = 1.0 if "<false, true>" in line else 3.0   # <false, true>: the in-kernel adaptive schedule, one launch; <false, false>: three launches per schedule
-                out["valu_wave_insts_per_window_schedule"] = m["valu_insts"] / (d / per_sched) / batch
-                out["valu_active_pct_of_wave_cycles"] = m.get("active_valu")
+                # one launch per schedule: lm_window_kernel<false, true> (in-kernel adaptive schedule) and ba_resident_kernel<true>; lm_window_kernel<false, false>: three
+                per_sched = 1.0 if ("<false, true>" in line or name.startswith("ba_resident_kernel")) else 3.0
+                # (with ba_resident_kernel in the set, lm_window_kernel only takes the deferred windows -- usually none: its launches return at once)
+                key = "resident_" if name.startswith("ba_resident_kernel") else ""
+                out[key + "valu_wave_insts_per_window_schedule"] = m["valu_insts"] / (d / per_sched) / batch
+                out[key + "valu_active_pct_of_wave_cycles"] = m.get("active_valu")
     out["sq"] = rows
 json.dump(out, open(os.path.join(root, "profiles", out_name), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k not in ("per_kernel", "sq")}, indent=1))
