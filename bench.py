@@ -786,12 +786,14 @@ def main():
     if args.unique_frames <= 0:
         args.unique_frames = args.sequence if seq_mode else B
     n_flight = 1 if seq_mode else max(1, args.in_flight)   # (sequence mode: a step is one pass over THE sequence; kept at one pass in flight)
-    ba_windows = args.ba_windows  # (sequence mode: a chunk's map starts at its halo frame, like the map of a sequence starts at frame 0; the BA
-                                  # results are not fed back into the gathered trajectory in either mode)
-    if seq_mode:  # config 5: this rank's contiguous chunk of ONE sequence, plus the frame before it (halo)
+    ba_windows = args.ba_windows  # (the BA results are not fed back into the gathered trajectory in either mode)
+    if seq_mode:  # config 5: this rank's contiguous chunk of ONE sequence, plus its halo: the frame before it for the pose stage, nine frames when the BA
+                  # windows are built from the tracks (window b = keyframes [b - 9, b]: with them, and the tracks carried across the chunk boundary, a
+                  # rank's windows are the unsharded run's windows bit for bit -- sharding.sequence_windows_and_ba)
         assert args.sequence >= 2 * world, "--sequence needs at least two frames per rank"
         lo, hi = sharding.shard_range(args.sequence, rank, world)
-        h_lo = sharding.halo_start(lo)
+        seq_exact_ba = (not args.no_ba) and ba_windows == "tracks"
+        h_lo = sharding.halo_start(lo, sharding.WINDOW_HALO if seq_exact_ba else 1)
         B = hi - h_lo
         ring = PipelineRing(1, B, device=local, anms_num=args.anms, n_lm=args.landmarks, seed=0, verbose=args.verbose and rank == 0,
                             with_ba=not args.no_ba, depth=args.depth, unique_frames=args.unique_frames, frame_range=(h_lo, hi, args.sequence),
@@ -810,14 +812,25 @@ def main():
     def one_step(serial=False):
         """one pass of the hot path over one batch; step k runs on pipeline k mod P (serial: always on pipeline 0, i.e. one batch in flight)"""
         pipe = ring.pipes[0] if serial else ring.next_pipe()
+        if seq_mode:
+            # front end + pose stage on the chunk; ragged gather of the OWNED relative poses (56 B each, every rank gets all of them); the trajectory is their
+            # chain; then the windows of the owned frames -- poses in the sequence's world, tracks continued across the chunk start -- and their BA schedule
+            pipe.stage_orb(); pipe.stage_stereo_match(); pipe.stage_track()
+            with torch.cuda.stream(pipe.stream):
+                p_lo, p_hi = sharding.owned_pose_range(args.sequence, rank, world)
+                rel = pipe.d_Tpnp[p_lo - h_lo - 1: p_hi - h_lo - 1]   # item i of d_Tpnp = T_{h_lo+i+1, h_lo+i}
+                rel_all = sharding.gather_relative_poses(rel, args.sequence, dist, world)
+                if rank == 0:
+                    chained[0] = sharding.chain_poses(rel_all)
+            if seq_exact_ba:
+                sharding.sequence_windows_and_ba(pipe, args.sequence, rank, world, dist, rel_all)
+            else:
+                pipe.stage_ba()
+            return
         pipe.step()
         if not serial:
             ring.k += 1
-        if seq_mode:   # ragged gather of the per-frame relative poses (56 B each), chained into one trajectory on rank 0
-            with torch.cuda.stream(pipe.stream):
-                rel = pipe.d_Tpnp[:max(B - 1, 0)]  # item i = T_{h_lo+i+1, h_lo+i}: exactly the poses this rank owns (sharding.owned_pose_range)
-                chained[0] = sharding.gather_and_chain(rel, args.sequence, dist, world, rank)
-        elif world > 1:  # throughput-mode pose gather (RCCL over xGMI), 56 B per keyframe; ordered after the step on its stream
+        if world > 1:  # throughput-mode pose gather (RCCL over xGMI), 56 B per keyframe; ordered after the step on its stream
             with torch.cuda.stream(pipe.stream):
                 sharding.gather_poses(pipe.d_Tpnp, dist)
 
@@ -904,14 +917,15 @@ def main():
     # a step that overflowed an ORB capacity or whose BA windows were rejected must not count as processed keyframes
     n_img = pipe.B if args.depth == "sgbm" else 2 * pipe.B
     orb_bad = sum(int((p_.vo.orb_status(n_img) != 0).sum()) for p_ in ring.pipes)
-    ba_bad = sum(int((p_.vo.ba_status(p_.B) != 0).sum()) for p_ in ring.pipes) if pipe.with_ba else 0
+    n_ba_windows = (hi - lo) if (seq_mode and seq_exact_ba) else pipe.B     # (sequence mode: the BA ran on the windows of the owned frames)
+    ba_bad = sum(int((p_.vo.ba_status(n_ba_windows) != 0).sum()) for p_ in ring.pipes) if pipe.with_ba else 0
     build_bad = sum(int(p_.ba_build_status.item()) for p_ in ring.pipes) if (pipe.with_ba and pipe.ba_windows == "tracks") else 0
     if orb_bad or ba_bad or build_bad:
         raise SystemExit("bench invalid: %d images overflowed an ORB capacity, %d BA windows were rejected, window builder status %d" % (orb_bad, ba_bad, build_bad))
 
     if rank == 0:
         out = pipe.download()
-        pipe.ba_passes = pipe.vo.ba_schedule_passes(pipe.B) if pipe.with_ba else None
+        pipe.ba_passes = pipe.vo.ba_schedule_passes(n_ba_windows) if pipe.with_ba else None
         other_seqs = [p_.h_seq for p_ in ring.pipes[1:]]
         for p_ in ring.pipes[1:]:
             p_.close()
@@ -919,7 +933,7 @@ def main():
         win_stats = None
         if pipe.with_ba and pipe.ba_windows == "tracks":
             nl_w, ne_w = np.diff(out["ba_lm_off"]), np.diff(out["ba_e_off"])
-            pipe.ba_shape = (ne_w, nl_w, out["ba_nkf"])
+            pipe.ba_shape = (ne_w[pipe.B - n_ba_windows:], nl_w[pipe.B - n_ba_windows:], out["ba_nkf"][pipe.B - n_ba_windows:])
             n_l = int(out["ba_lm_off"][-1])
             win_stats = {"landmarks_per_window_mean": float(nl_w.mean()), "landmarks_per_window_max": int(nl_w.max()), "edges_per_window_mean": float(ne_w.mean()),
                          "edges_per_window_max": int(ne_w.max()), "reliable_fraction": float(out["ba_rel"][:n_l].mean()) if n_l else 0.0,
@@ -982,7 +996,9 @@ def main():
                        "unique_inputs": "%d rendered stereo keyframes per pipeline (one sequence each, ping-pong over the batch when shorter than it; %s), %d BA windows (%s)" % (
                            pipe.unique_frames, "every pipeline in flight its own sequence" if getattr(ring, "distinct", False) else "the pipelines share the frames",
                            pipe.unique_windows if pipe.with_ba else 0, "built from the step's tracks" if pipe.ba_windows == "tracks" else "canned"),
-                       "parallelism": ("one %d-frame sequence in %d contiguous chunks with a 1-frame halo, relative poses gathered and chained on rank 0" % (args.sequence, world))
+                       "parallelism": ("one %d-frame sequence in %d contiguous chunks with a %d-frame halo, relative poses gathered and chained, track state carried across the "
+                                       "chunk boundaries rank by rank, BA on the windows of the owned frames (the unsharded run's windows bit for bit)" % (
+                                           args.sequence, world, sharding.WINDOW_HALO if seq_exact_ba else 1))
                                       if seq_mode else "%d independent replicas, sharded keyframes" % world},
             "timing": {"repeats": len(rep_s), "ms_per_step_each": [round(1e3 * x / args.steps, 4) for x in rep_s], "reported": "median",
                        "spread_pct": round(100.0 * (max(rep_s) - min(rep_s)) / elapsed, 2),

@@ -40,7 +40,7 @@ extern "C" {
  * of vslam_feature_matching_dev; revision 4 appended d_n_kf to vslam_ba_batch and added vslam_build_windows_dev, vslam_pnp_ransac_dev,
  * vslam_set_tuning, vslam_sgbm_status_dev).  vslam_create refuses a vslam_params whose struct_size / abi_version do not match the library's,
  * so a caller compiled against an older header fails with VSLAM_ERR_ARG instead of having its arguments reinterpreted. */
-#define VSLAM_ABI_VERSION 4
+#define VSLAM_ABI_VERSION 5
 
 #define VSLAM_ORB_NLEVELS 8
 #define VSLAM_MAX_KF 12          /* keyframes per optimisation window (reference: Map::num_keyframes_ = 10, map.hpp:22) */
@@ -306,6 +306,16 @@ typedef struct vslam_tracks_in {
     const double* d_T_rel;         /* (n_frames - 1) x 7: T_{i+1,i}, the pose stage's estimate with frame i as the world */
     const int32_t* d_nkps;         /* n_frames: keypoints of frame f (no match refers to a keypoint index beyond it), or NULL: every slot up to
                                       kp_capacity is examined (slower, same result) */
+    /* ---- ABI rev 5: a batch that is a CHUNK of a longer sequence (sequence mode, BASELINE config 5).  All four may be NULL / 0. */
+    const double* d_T_abs;         /* n_frames x 7: T_{f,0} of every frame of the batch in the SEQUENCE's world (the gathered, chained relative poses);
+                                      used instead of chaining d_T_rel from the batch's first frame */
+    const float* d_carry_in;       /* kp_capacity x 4 floats, for the batch's FIRST frame: {x, y, z, flags} per keypoint slot -- flags (as float) 0: no
+                                      track reaches this keypoint from before the batch; 1: one does, and (x, y, z) is its landmark's position so far
+                                      (its creation point, no reliable depth seen yet); 3: likewise, position from a reliable depth.  What the rank that
+                                      owns the frames before this chunk exports (d_carry_out): tracks and their landmark positions then continue across
+                                      the chunk boundary exactly as in one unsharded batch */
+    float* d_carry_out;            /* kp_capacity x 4 floats: the same record for frame `carry_out_frame` of THIS batch (the first frame of the next chunk) */
+    int32_t carry_out_frame;       /* 1 .. n_frames - 1 (0: no carry-out) */
 } vslam_tracks_in;
 /* Fills the device arrays of `out` (caller-allocated: d_lm_off / d_edge_off n_frames + 1, d_T_c_w n_frames x n_kf x 7, d_xyz /
  * d_reliable / d_lm_inlier for lm_capacity landmarks, d_kf_idx / d_lm_idx / d_uv for edge_capacity edges, d_n_kf n_frames; the

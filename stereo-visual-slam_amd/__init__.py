@@ -35,7 +35,7 @@ class Params(C.Structure):
                 ("struct_size", C.c_int32), ("abi_version", C.c_int32)]
 
 
-ABI_VERSION = 4  # VSLAM_ABI_VERSION of include/vslam_hip.h this binding was written against
+ABI_VERSION = 5  # VSLAM_ABI_VERSION of include/vslam_hip.h this binding was written against
 
 
 class LmStats(C.Structure):
@@ -62,7 +62,9 @@ class TracksIn(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("kp_capacity", C.c_int32), ("lr_capacity", C.c_int32), ("match_capacity", C.c_int32),
                 ("pnp_capacity", C.c_int32), ("d_kps", C.c_void_p), ("d_lr", C.c_void_p), ("d_nlr", C.c_void_p), ("d_xyz", C.c_void_p),
                 ("d_valid", C.c_void_p), ("d_reliable", C.c_void_p), ("d_f2f", C.c_void_p), ("d_nf2f", C.c_void_p),
-                ("d_pose_inlier", C.c_void_p), ("d_T_rel", C.c_void_p), ("d_nkps", C.c_void_p)]
+                ("d_pose_inlier", C.c_void_p), ("d_T_rel", C.c_void_p), ("d_nkps", C.c_void_p),
+                # ABI rev 5: a chunk of a longer sequence -- absolute poses, carry across the chunk boundaries (all optional)
+                ("d_T_abs", C.c_void_p), ("d_carry_in", C.c_void_p), ("d_carry_out", C.c_void_p), ("carry_out_frame", C.c_int32)]
 
 
 # every symbol include/vslam_hip.h declares (checked by tests/test_abi.py)

@@ -956,6 +956,9 @@ int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf,
         !out->d_lm_off || !out->d_edge_off || !out->d_T_c_w || !out->d_xyz || !out->d_reliable || !out->d_lm_inlier || !out->d_kf_idx || !out->d_lm_idx ||
         !out->d_uv || !out->d_n_kf) { set_error("bad argument"); return VSLAM_ERR_ARG; }
     if ((long long)in->n_frames * in->kp_capacity > 0x7FFFFFFFll) { set_error("n_frames x kp_capacity exceeds the 31-bit node keys"); return VSLAM_ERR_ARG; }
+    if ((in->d_carry_out != nullptr) != (in->carry_out_frame > 0) || in->carry_out_frame < 0 || in->carry_out_frame >= in->n_frames + (in->n_frames == 1 ? 1 : 0)) {
+        if (in->d_carry_out || in->carry_out_frame != 0) { set_error("carry_out_frame %d needs d_carry_out and 1 <= carry_out_frame < n_frames (%d)", in->carry_out_frame, in->n_frames); return VSLAM_ERR_ARG; }
+    }
     if (in->kp_capacity > 65536) { set_error("kp_capacity %d exceeds 65536 (the window builder packs a keypoint index into 16 bits)", in->kp_capacity); return VSLAM_ERR_ARG; }
     VS_ENTER(c);
     const size_t need = track_scratch_bytes(in->n_frames, in->kp_capacity, lm_capacity);

@@ -122,14 +122,21 @@ __global__ __launch_bounds__(256) void track_link_kernel(TrackDims d, const vsla
 // ---- per keypoint slot: is it a node (a Feature of its keyframe: tracked, or owner of a valid depth), the root of its chain (where the
 // landmark was created) and the FIRST node of the chain, up to this one, with a reliable depth (-1: none yet): the landmark's position
 // at the time of this node is that node's point if there is one, the root's otherwise (visual_odometry.cpp:391-401).
+// A chunk of a longer sequence (carry: vslam_tracks_in::d_carry_in): a track may reach a keypoint of the batch's first frame from BEFORE the batch.
+// Such a slot is a node whatever its own depth, and the chain's root -- and its first reliable node, if the carry says one was seen -- lie upstream:
+// both tables then hold the code  kCarryCode - slot  (< -1), which the emit pass resolves to the carried position.
+constexpr int kCarryCode = -2;
+__device__ inline int carry_flags(const float* carry, int slot) { return carry ? (int)carry[4 * slot + 3] : 0; }
 __global__ __launch_bounds__(256) void track_chain_kernel(TrackDims d, const uint8_t* __restrict__ d_valid, const uint8_t* __restrict__ d_rel,
                                                          const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ pred,
-                                                         const int32_t* __restrict__ succ, int32_t* __restrict__ root, int32_t* __restrict__ relsrc,
-                                                         int32_t* __restrict__ info) {
+                                                         const int32_t* __restrict__ succ, const float* __restrict__ carry, int32_t* __restrict__ root,
+                                                         int32_t* __restrict__ relsrc, int32_t* __restrict__ info) {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d.kp_cap) return;
     const size_t at = (size_t)f * d.kp_cap + i;
-    const int m = kp2lr[at], p = pred[at];
+    const int m = kp2lr[at];
+    int p = pred[at];
+    if (f == 0 && (carry_flags(carry, i) & 1)) p = 0; // (tracked from before the batch: a node with a predecessor; the index itself is never followed)
     const bool own3d = m >= 0 && d_valid[(size_t)f * d.lr_cap + m] != 0;
     int r = -1, first = -1;
     if (own3d || p >= 0) {
@@ -143,11 +150,16 @@ __global__ __launch_bounds__(256) void track_chain_kernel(TrackDims d, const uin
             --cf; ci = pp;
         }
         r = cf * d.kp_cap + ci;
+        if (cf == 0) { // the chain reaches the batch's first frame: does it go on upstream?
+            const int cfl = carry_flags(carry, ci);
+            if (cfl & 1) { r = kCarryCode - ci; if (cfl & 2) first = kCarryCode - ci; } // (an upstream reliable node is earlier than any local one)
+        }
     }
     root[at] = r; relsrc[at] = first;
     // what a window needs to know about this slot without walking: node?, has a predecessor?, successors left in its chain
     int rem = 0;
-    if (r >= 0) {
+    const bool node = r >= 0 || r <= kCarryCode;
+    if (node) {
         int cf = f, ci = i;
         while (cf + 1 < d.B && rem < VSLAM_MAX_KF) {
             const int nx = succ[(size_t)cf * d.kp_cap + ci];
@@ -155,7 +167,40 @@ __global__ __launch_bounds__(256) void track_chain_kernel(TrackDims d, const uin
             ++cf; ci = nx; ++rem;
         }
     }
-    info[at] = (r >= 0 ? 1 : 0) | (p >= 0 ? 2 : 0) | (rem << 8);
+    info[at] = (node ? 1 : 0) | (p >= 0 ? 2 : 0) | (rem << 8);
+}
+
+// the landmark position a chain node stands for: the point of node `src` (= first reliable node of the chain, else its root) in the world of G,
+// or the carried position when the chain's source lies before the batch
+__device__ inline void landmark_position(const TrackDims& d, int src, const int32_t* __restrict__ kp2lr, const float* __restrict__ d_xyz, const double* __restrict__ G,
+                                         const float* __restrict__ carry, float out[3]) {
+    if (src <= kCarryCode) { const int slot = kCarryCode - src; out[0] = carry[4 * slot]; out[1] = carry[4 * slot + 1]; out[2] = carry[4 * slot + 2]; return; }
+    const int sf = src / d.kp_cap, si = src - sf * d.kp_cap;
+    const int mm = kp2lr[(size_t)sf * d.kp_cap + si];
+    const float* pc = d_xyz + 3 * ((size_t)sf * d.lr_cap + mm);
+    double Gi[7], pw[3];
+    const double p[3] = {(double)pc[0], (double)pc[1], (double)pc[2]};
+    se3::inverse(G + (size_t)sf * 7, Gi);
+    se3::act(Gi, p, pw);
+    out[0] = (float)pw[0]; out[1] = (float)pw[1]; out[2] = (float)pw[2];
+}
+
+// ---- carry-out for the chunk that starts at frame c of this batch: per keypoint slot of frame c, does a track reach it from frame c - 1, and
+// what is that track's landmark position / reliable flag AS OF ITS NODE IN FRAME c - 1 (the state the next chunk's chain walk would have found upstream)
+__global__ __launch_bounds__(256) void track_carry_out_kernel(TrackDims d, int c, const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ pred,
+                                                             const int32_t* __restrict__ root, const int32_t* __restrict__ relsrc, const float* __restrict__ d_xyz,
+                                                             const double* __restrict__ G, const float* __restrict__ carry_in, float* __restrict__ carry_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.kp_cap) return;
+    float rec[4] = {0.f, 0.f, 0.f, 0.f};
+    const int p = pred[(size_t)c * d.kp_cap + i];
+    if (p >= 0) {
+        const size_t pn = (size_t)(c - 1) * d.kp_cap + p;
+        const int rs = relsrc[pn], src = (rs >= 0 || rs <= kCarryCode) ? rs : root[pn];
+        landmark_position(d, src, kp2lr, d_xyz, G, carry_in, rec);
+        rec[3] = (rs >= 0 || rs <= kCarryCode) ? 3.f : 1.f;
+    }
+    reinterpret_cast<float4*>(carry_out)[i] = make_float4(rec[0], rec[1], rec[2], rec[3]);
 }
 
 // A chain HEAD of window [s, b]: a node in frame s, or a node without predecessor (a landmark created inside the window).  Every
@@ -300,7 +345,7 @@ __global__ __launch_bounds__(kRankBlock) void window_rank_kernel(TrackDims d, co
 __global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vslam_keypoint* __restrict__ d_kps, const float* __restrict__ d_xyz,
                                                          const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ root,
                                                          const int32_t* __restrict__ relsrc, const int32_t* __restrict__ succ,
-                                                         const double* __restrict__ G, const int32_t* __restrict__ hist,
+                                                         const double* __restrict__ G, const float* __restrict__ carry, const int32_t* __restrict__ hist,
                                                          const uint32_t* __restrict__ head_rec, const int32_t* __restrict__ lm_off,
                                                          const int32_t* __restrict__ edge_off, float* __restrict__ xyz_out,
                                                          uint8_t* __restrict__ rel_out, uint8_t* __restrict__ inl_out, int32_t* __restrict__ kf_out,
@@ -325,17 +370,12 @@ __global__ __launch_bounds__(256) void window_emit_kernel(TrackDims d, const vsl
     }
     const size_t last = (size_t)cf * d.kp_cap + ci;
     const int rs = relsrc[last];
-    const int src = rs >= 0 ? rs : root[last];
-    const int sf = src / d.kp_cap, si = src - sf * d.kp_cap;
-    const int mm = kp2lr[(size_t)sf * d.kp_cap + si];
-    const float* pc = d_xyz + 3 * ((size_t)sf * d.lr_cap + mm);
-    double Gi[7], pw[3];
-    const double p[3] = {(double)pc[0], (double)pc[1], (double)pc[2]};
-    se3::inverse(G + (size_t)sf * 7, Gi);
-    se3::act(Gi, p, pw);
+    const bool has_rel = rs >= 0 || rs <= kCarryCode;
+    float pos[3];
+    landmark_position(d, has_rel ? rs : root[last], kp2lr, d_xyz, G, carry, pos);
     float* o = xyz_out + 3 * (size_t)g;
-    o[0] = (float)pw[0]; o[1] = (float)pw[1]; o[2] = (float)pw[2];
-    rel_out[g] = rs >= 0; inl_out[g] = 1;
+    o[0] = pos[0]; o[1] = pos[1]; o[2] = pos[2];
+    rel_out[g] = has_rel; inl_out[g] = 1;
 }
 
 size_t track_scratch_bytes(int B, int kp_cap, int lm_capacity) {
@@ -357,13 +397,17 @@ int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, i
     uint32_t* head_rec = (uint32_t*)((uint8_t*)hist + al((size_t)d.B * (VSLAM_MAX_KF + 1) * 4));
     ProfScope prof__(stream, "build_windows_kernels", 8);
     hipLaunchKernelGGL(track_init_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_lr, in.d_nlr, kp2lr, pred, succ);
-    hipLaunchKernelGGL(track_pose_chain_kernel, dim3(1), dim3(256), 0, stream, d.B, in.d_T_rel, G);
+    if (in.d_T_abs) VS_HIP(hipMemcpyAsync(G, in.d_T_abs, sizeof(double) * 7 * (size_t)d.B, hipMemcpyDeviceToDevice, stream)); // (a chunk: poses in the sequence's world)
+    else hipLaunchKernelGGL(track_pose_chain_kernel, dim3(1), dim3(256), 0, stream, d.B, in.d_T_rel, G);
     if (d.B > 1) hipLaunchKernelGGL(track_link_kernel, dim3(d.B - 1), dim3(256), 0, stream, d, in.d_f2f, in.d_nf2f, in.d_valid, in.d_pose_inlier, kp2lr, pred, succ);
-    hipLaunchKernelGGL(track_chain_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, in.d_valid, in.d_reliable, kp2lr, pred, succ, root, relsrc, info);
+    hipLaunchKernelGGL(track_chain_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, in.d_valid, in.d_reliable, kp2lr, pred, succ, in.d_carry_in, root, relsrc, info);
+    if (in.d_carry_out && in.carry_out_frame > 0 && in.carry_out_frame < d.B)
+        hipLaunchKernelGGL(track_carry_out_kernel, dim3((d.kp_cap + 255) / 256), dim3(256), 0, stream, d, in.carry_out_frame, kp2lr, pred, root, relsrc, in.d_xyz, G,
+                           in.d_carry_in, in.d_carry_out);
     hipLaunchKernelGGL(window_count_kernel, dim3(d.B), dim3(256), 0, stream, d, info, in.d_nkps, counts, hist);
     hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(256), 0, stream, d, counts, lm_capacity, edge_capacity, d_lm_off, d_edge_off, d_n_kf, d_status);
     hipLaunchKernelGGL(window_rank_kernel, dim3(d.B), dim3(kRankBlock), 0, stream, d, G, counts, hist, info, in.d_nkps, d_lm_off, d_edge_off, d_T, head_rec);
-    hipLaunchKernelGGL(window_emit_kernel, dim3((lm_capacity + 255) / 256), dim3(256), 0, stream, d, in.d_kps, in.d_xyz, kp2lr, root, relsrc, succ, G, hist, head_rec,
+    hipLaunchKernelGGL(window_emit_kernel, dim3((lm_capacity + 255) / 256), dim3(256), 0, stream, d, in.d_kps, in.d_xyz, kp2lr, root, relsrc, succ, G, in.d_carry_in, hist, head_rec,
                        d_lm_off, d_edge_off, d_xyz_out, d_rel_out, d_inl_out, d_kf_out, d_lm_out, d_uv_out);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;

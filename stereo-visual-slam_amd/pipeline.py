@@ -231,6 +231,40 @@ class KeyframePipeline:
         """optimize_map's graph build (optimization.cpp:127-214) + insert_key_frame's bookkeeping (visual_odometry.cpp:363-424) on the device"""
         self.vo.build_windows_dev(self.tracks, self.n_kf, self.lm_capacity, self.edge_capacity, self.ba_batch, self.ba_build_status.data_ptr())
 
+    def stage_build_windows_chunk(self, T_abs, carry_in=None, carry_out_frame=0):
+        """sequence mode: this batch is the chunk [first, last] of a longer sequence.  T_abs (B, 7): the poses of its frames in the SEQUENCE's world (gathered
+        relative poses, chained); carry_in (kp_capacity, 4) f32 or None: the tracks that reach the chunk's first frame from before it (the previous rank's
+        carry-out); carry_out_frame > 0: also export that record for this local frame (returned tensor) -- the first frame of the next rank's chunk."""
+        d = self.dev
+        if not hasattr(self, "d_T_abs"):
+            self.d_T_abs = torch.zeros((self.B, 7), dtype=torch.float64, device=d)
+            self.d_carry_in = torch.zeros((self.cap, 4), dtype=torch.float32, device=d)
+            self.d_carry_out = torch.zeros((self.cap, 4), dtype=torch.float32, device=d)
+        with torch.cuda.stream(self.stream):
+            self.d_T_abs.copy_(T_abs.to(d))
+            if carry_in is not None:
+                self.d_carry_in.copy_(carry_in.to(d))
+        tr = self.tracks
+        tr.d_T_abs = self.d_T_abs.data_ptr()
+        tr.d_carry_in = self.d_carry_in.data_ptr() if carry_in is not None else None
+        tr.d_carry_out = self.d_carry_out.data_ptr() if carry_out_frame > 0 else None
+        tr.carry_out_frame = int(carry_out_frame)
+        self.stage_build_windows()
+        tr.d_T_abs = None; tr.d_carry_in = None; tr.d_carry_out = None; tr.carry_out_frame = 0
+        return self.d_carry_out if carry_out_frame > 0 else None
+
+    def ba_schedule_from(self, first):
+        """the BA schedule on the built windows [first, B) only (sequence mode: the windows of the frames this rank OWNS; the ones before belong to its halo)"""
+        from . import BaBatch
+        b = BaBatch()
+        for f_, _ in BaBatch._fields_:
+            setattr(b, f_, getattr(self.ba_batch, f_))
+        b.n_windows = self.B - first
+        b.d_lm_off = self.ba_lm_off[first:].data_ptr(); b.d_edge_off = self.ba_e_off[first:].data_ptr()
+        b.d_T_c_w = self.ba_T[first:].data_ptr(); b.d_n_kf = self.ba_nkf[first:].data_ptr()
+        self._ba_view = b   # (kept alive until the next call)
+        self.vo.ba_batch_dev(b, schedule=1)
+
     def stage_ba(self):
         if not self.with_ba:
             return

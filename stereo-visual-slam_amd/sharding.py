@@ -21,9 +21,13 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def halo_start(lo):
-    """first frame a rank has to PROCESS to own frames from `lo` on: its predecessor, except at the start of the sequence"""
-    return max(lo - 1, 0)
+WINDOW_HALO = 9   # Map::num_keyframes_ - 1 (map.hpp:22): window b holds keyframes [b - 9, b]
+
+
+def halo_start(lo, halo=1):
+    """first frame a rank has to PROCESS to own frames from `lo` on: `halo` frames before them (1: the pose stage needs the predecessor of its first
+    frame; WINDOW_HALO: the local-BA window of its first frame reaches nine keyframes back), clipped at the start of the sequence"""
+    return max(lo - halo, 0)
 
 
 def owned_pose_range(total, rank, world):
@@ -95,6 +99,62 @@ def gather_and_chain(local_rel, total, dist, world, rank):
     else:
         rel = local_rel
     return chain_poses(rel) if rank == 0 else None
+
+
+def gather_relative_poses(local_rel, total, dist, world):
+    """every rank's owned relative poses (owned_pose_range rows each) -> the (total - 1, 7) list in frame order, on EVERY rank (an all-gather)"""
+    if world <= 1:
+        return local_rel
+    sizes = [hi - lo for lo, hi in (owned_pose_range(total, r, world) for r in range(world))]
+    return _gather_ragged(local_rel, sizes, dist)
+
+
+def carry_out_frame(total, rank, world, halo=WINDOW_HALO):
+    """local index (inside rank `rank`'s chunk, which starts at halo_start(lo, halo)) of the frame where the NEXT rank's chunk starts, or 0: no carry needed
+    (last rank, or the next chunk starts at frame 0 of the sequence)"""
+    if rank + 1 >= world:
+        return 0
+    lo, _ = shard_range(total, rank, world)
+    lo_n, _ = shard_range(total, rank + 1, world)
+    return max(halo_start(lo_n, halo) - halo_start(lo, halo), 0)
+
+
+def chain_carry(dist, rank, world, build, carry_buf, needs_in, sends_out):
+    """The one SERIAL step of sequence mode: the track state at a chunk boundary depends on every frame before it, so rank r can build its windows only
+    after rank r - 1 has (a 64 KB record, two kernels: microseconds against the chunk's front end and BA).  rank r receives the carry of rank r - 1
+    (if needs_in), calls build(carry or None) -> its own carry-out tensor (or None), sends it on (if sends_out)."""
+    if rank > 0 and needs_in:
+        dist.recv(carry_buf, src=rank - 1)
+    out = build(carry_buf if (rank > 0 and needs_in) else None)
+    if rank + 1 < world and sends_out:
+        dist.send(out.contiguous(), dst=rank + 1)
+    return out
+
+
+def sequence_windows_and_ba(pipe, total, rank, world, dist, rel_all):
+    """sequence mode, after the front end and the pose stage ran on the chunk [halo_start(lo, WINDOW_HALO), hi): the chunk's frames get their poses in the
+    SEQUENCE's world (rel_all = every frame's relative pose, gathered; chained identically on every rank), the window builder continues the tracks
+    that cross the chunk's start (carry from the previous rank), and the BA schedule runs on the windows of the frames this rank owns -- the same
+    windows, bit for bit, as one unsharded pass over the sequence builds (tests/test_gpu_sequence.py).  Returns the local index of the first owned window."""
+    lo, hi = shard_range(total, rank, world)
+    h_lo = halo_start(lo, WINDOW_HALO)
+    G = chain_poses(rel_all)                       # (total, 7): the same bits on every rank
+    T_abs = G[h_lo:hi]
+    c_out = carry_out_frame(total, rank, world)
+    needs_in = h_lo > 0
+    buf = torch.zeros((pipe.cap, 4), dtype=torch.float32, device=rel_all.device)
+
+    def build(carry):
+        return pipe.stage_build_windows_chunk(T_abs, carry, c_out)
+
+    with torch.cuda.stream(pipe.stream):
+        if world > 1:
+            chain_carry(dist, rank, world, build, buf, needs_in, c_out > 0)
+        else:
+            build(None)
+    first = lo - h_lo
+    pipe.ba_schedule_from(first)
+    return first
 
 
 def camera_centre(T):

@@ -1,4 +1,4 @@
-"""BASELINE config 5 on ONE GPU: the loop of run_vslam.cpp:40 cut into contiguous chunks with a 1-frame halo (sharding.py), each chunk
+"""BASELINE config 5 on ONE GPU: the loop of run_vslam.cpp:40 cut into contiguous chunks with a halo (sharding.py), each chunk
 run through the device pipeline exactly as a rank would run it, the per-chunk relative poses put through the ragged gather and the
 chaining scan -- and the result required to equal the unsharded run of the same 50 frames bit for bit, and the CPU oracle to 1e-4.
 (The collective itself is covered with gloo on CPU in tests/test_sharding_gloo.py; here a stand-in `dist` object plays the wire so
@@ -107,3 +107,94 @@ def test_sequence_relative_poses_match_oracle(rendered, oracle):
             q = T[:4] if np.dot(T[:4], rel[f - 1][:4]) >= 0 else -T[:4]
             assert np.allclose(rel[f - 1][:4], q, rtol=1e-4, atol=1e-7) and np.allclose(rel[f - 1][4:], T[4:], rtol=1e-4, atol=1e-6), f
         prev = (kL, dL, m, xyz, valid)
+
+
+# ---------------------------------------------------------------- round 5: the BA windows of a sharded sequence ARE the unsharded run's windows
+class WireP2P(WireStandIn):
+    """... plus send / recv between ranks that run one after the other in ascending order (the carry chain is serial by nature)"""
+
+    def __init__(self, world):
+        super().__init__(world)
+        self.mail = {}
+
+    def send(self, t, dst):
+        self.mail[dst] = t.clone()
+
+    def recv(self, t, src):
+        t.copy_(self.mail.pop(self.rank))
+
+
+def _front_and_pose(rendered, h_lo, hi):
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    pipe = KeyframePipeline(hi - h_lo, device=0, anms_num=ANMS, with_ba=True, ba_windows="tracks", unique_frames=F, frame_range=(h_lo, hi, F), sequence=rendered)
+    pipe.stage_orb(); pipe.stage_stereo_match(); pipe.stage_track()
+    pipe.vo.sync()
+    import torch
+    torch.cuda.synchronize()   # (the test reads the poses from torch's default stream; the product orders its gather on the pipeline's stream)
+    return pipe
+
+
+def _owned_results(pipe, first):
+    import torch
+    pipe.vo.sync(); torch.cuda.synchronize()
+    n = pipe.B - first
+    assert (pipe.vo.ba_status(n) == 0).all() and int(pipe.ba_build_status.item()) == 0
+    lm_off = pipe.ba_lm_off.cpu().numpy(); e_off = pipe.ba_e_off.cpu().numpy()
+    T = pipe.ba_T.cpu().numpy(); inl = pipe.ba_inl.cpu().numpy(); xyz = pipe.ba_xyz.cpu().numpy(); uv = pipe.ba_uv.cpu().numpy()
+    kf = pipe.ba_kf.cpu().numpy(); lm = pipe.ba_lm.cpu().numpy(); nkf = pipe.ba_nkf.cpu().numpy()
+    out = []
+    for b in range(first, pipe.B):
+        out.append(dict(T=T[b, :nkf[b]].copy(), inl=inl[lm_off[b]:lm_off[b + 1]].copy(), xyz=xyz[lm_off[b]:lm_off[b + 1]].copy(), n_kf=int(nkf[b]),
+                        uv=uv[e_off[b]:e_off[b + 1]].copy(), kf=kf[e_off[b]:e_off[b + 1]].copy(), lm=lm[e_off[b]:e_off[b + 1]].copy()))
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_sequence_ba_windows_equal_unsharded(rendered, world):
+    """Sequence mode with local BA: every rank processes its chunk plus a 9-frame halo, the relative poses are gathered and chained, the track state at a chunk's
+    first frame arrives from the rank before it (a 64 KB carry), and the BA schedule runs on the windows of the OWNED frames.  Every such window -- its
+    keyframe poses, landmark positions, reliable flags, edges -- and its result (poses after the 5+5+10+10 schedule, landmark flags) must equal the unsharded
+    pass over the 50 frames bit for bit, for 2 and for 8 ranks (chunks of 6-7 frames: shorter than the halo)."""
+    import torch
+    from stereo_visual_slam_amd import sharding
+    # unsharded: one chunk, world 1, the same product code
+    pipe = _front_and_pose(rendered, 0, F)
+    try:
+        rel_full = pipe.d_Tpnp[:F - 1].clone()
+        first = sharding.sequence_windows_and_ba(pipe, F, 0, 1, None, rel_full)
+        assert first == 0
+        ref = _owned_results(pipe, 0)
+    finally:
+        pipe.close()
+    assert len(ref) == F and max(r["n_kf"] for r in ref) == 10 and sum(len(r["inl"]) for r in ref) > 10000
+    # sharded: phase 1 on every rank (front end, pose stage, deposit of the owned relative poses), then the gathered list, then the serial carry chain
+    wire = WireP2P(world)
+    pipes, rel_all = {}, None
+    try:
+        for rank in range(world):
+            lo, hi = sharding.shard_range(F, rank, world)
+            h_lo = sharding.halo_start(lo, sharding.WINDOW_HALO)
+            pipes[rank] = _front_and_pose(rendered, h_lo, hi)
+            p_lo, p_hi = sharding.owned_pose_range(F, rank, world)
+            rel = pipes[rank].d_Tpnp[p_lo - h_lo - 1: p_hi - h_lo - 1]
+            assert np.array_equal(rel.cpu().numpy(), rel_full[p_lo - 1:p_hi - 1].cpu().numpy()), rank
+            wire.rank = rank
+            rel_all = sharding.gather_relative_poses(rel, F, wire, world)     # (complete on the last caller: what the all-gather hands every rank)
+        assert np.array_equal(rel_all.cpu().numpy(), rel_full.cpu().numpy())
+        n_checked = 0
+        for rank in range(world):                                              # ascending: rank r needs the carry of rank r - 1
+            lo, hi = sharding.shard_range(F, rank, world)
+            wire.rank = rank
+            first = sharding.sequence_windows_and_ba(pipes[rank], F, rank, world, wire, rel_all)
+            assert first == lo - sharding.halo_start(lo, sharding.WINDOW_HALO)
+            got = _owned_results(pipes[rank], first)
+            assert len(got) == hi - lo
+            for j, g in enumerate(got):
+                r = ref[lo + j]
+                for k in ("n_kf", "kf", "lm", "uv", "xyz", "inl", "T"):
+                    assert np.array_equal(g[k], r[k]), (rank, lo + j, k)
+                n_checked += 1
+        assert n_checked == F
+    finally:
+        for p_ in pipes.values():
+            p_.close()

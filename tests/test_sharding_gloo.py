@@ -146,3 +146,82 @@ def test_sequence_sharding_two_and_three_ranks_match_single_rank():
         res = _run_seq(world, F)
         assert all(res[r] is None for r in range(1, world))
         assert res[0].shape == (F, 7) and np.allclose(res[0], want, rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------- round 5: the carry chain of sequence mode with local BA
+def _carry_worker(rank, world, port, total, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stereo_visual_slam_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(total, rank, world)
+        h_lo = sharding.halo_start(lo, sharding.WINDOW_HALO)
+        c_out = sharding.carry_out_frame(total, rank, world)
+        buf = torch.zeros((8, 4), dtype=torch.float32)
+        seen = {}
+
+        def build(carry):
+            # injected "window builder": what it was handed, and a carry-out that names the frame it describes and everything upstream of it
+            seen["in"] = None if carry is None else carry.clone()
+            up = 0.0 if carry is None else float(carry[0, 0])
+            out = torch.zeros((8, 4), dtype=torch.float32)
+            out[:, 0] = up + 1.0                    # chain depth: rank r's carry-out has passed through r + 1 builders
+            out[:, 1] = float(h_lo + c_out)         # the global frame the record is for
+            return out
+
+        sharding.chain_carry(dist, rank, world, build, buf, h_lo > 0, c_out > 0)
+        q.put((rank, lo, hi, h_lo, c_out, None if seen["in"] is None else seen["in"][0].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+import pytest
+
+
+@pytest.mark.parametrize("world,total", [(2, 50), (3, 50), (3, 20)])
+def test_carry_chain_reaches_every_rank_in_order(world, total):
+    """sequence mode's one serial step over gloo: rank r gets exactly the record rank r - 1 built for the first frame of r's chunk (halo included), built
+    after r - 1 received its own; ranks whose chunk starts at frame 0 get none"""
+    import pytest  # noqa: F401
+    from stereo_visual_slam_amd import sharding
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = [ctx.Process(target=_carry_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p_ in procs:
+        p_.join(60)
+    depth = 0
+    for rank, lo, hi, h_lo, c_out, got in res:
+        assert h_lo == max(lo - sharding.WINDOW_HALO, 0)
+        if h_lo == 0:
+            assert got is None                      # nothing upstream of frame 0
+        else:
+            assert got is not None and got[1] == float(h_lo)          # the record describes THIS chunk's first frame ...
+            assert got[0] == float(depth)                              # ... and was built by the rank before, after its own carry arrived
+        if c_out > 0:
+            depth += 1
+        else:
+            assert rank == world - 1 or sharding.halo_start(sharding.shard_range(total, rank + 1, world)[0], sharding.WINDOW_HALO) == 0
+
+
+def test_owned_windows_cover_every_frame_once():
+    from stereo_visual_slam_amd import sharding
+    for total in (20, 50, 4541):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = sharding.shard_range(total, r, world)
+                h = sharding.halo_start(lo, sharding.WINDOW_HALO)
+                assert lo - h == min(lo, sharding.WINDOW_HALO)
+                seen += list(range(lo, hi))
+                c = sharding.carry_out_frame(total, r, world)
+                if r + 1 < world:
+                    lo_n = sharding.shard_range(total, r + 1, world)[0]
+                    assert h + c == sharding.halo_start(lo_n, sharding.WINDOW_HALO) or (c == 0 and sharding.halo_start(lo_n, sharding.WINDOW_HALO) <= h)
+                    assert c < hi - h
+            assert seen == list(range(total))
