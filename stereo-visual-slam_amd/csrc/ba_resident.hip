@@ -834,16 +834,9 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
         __syncthreads();
     };
 
-    // ------------------------------------------------------------------ passes of the schedule (run_vslam.cpp:61-66) / the single call
-    const int iters_early = iters;
-    constexpr int npass = SCHED ? 3 : 1;
-    bool done = false;
-    int pass = 0;
-    vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
-    for (; pass < npass && !done; ++pass) {
-        if (SCHED) { iters = pass < 2 ? iters_early : kRsSchedFinalIters; update_poses = pass == 2; }
-        // ---- pass init: live words (pass 0: inlier / reliable filter, optimization.cpp:160; later passes: what the classification left),
-        // positions from the sorted input copy, row unions, poses
+    // ---- pass init.  mode 0: first optimize_map pass (live = inlier && reliable_depth_, optimization.cpp:160); 1: a later pass (what the classification
+    // left).  Positions from the sorted input copy, row unions, singles rows, hit lists, poses.
+    auto pass_init = [&](int mode) {
         __syncthreads();
         for (int s0 = tid; s0 < nlp; s0 += 4 * kRsBlock) {
             unsigned lvv[4]; float v[4][3];
@@ -856,7 +849,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
                 if (s < nl) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) v[u][c] = xs[3 * (size_t)s + c];
-                    if (pass == 0) {
+                    if (mode != 1) {
                         const unsigned ms = mstat[s];
                         const int l = perm[s];
                         const uint8_t inl = a.lm_inlier[lm0 + l];
@@ -926,6 +919,92 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
                 }
             }
         }
+    };
+
+    // ---- chi2 of every active edge at (Rsel, LDS positions), the adaptive threshold and the landmark flags (optimization.cpp:224-266, :395-424): the
+    // landmark's last edge decides.  Returns whether this thread cleared a flag.
+    auto classify_pass = [&](const double* Rsel) -> int {
+        int newly_flagged = 0;
+            // per row slot of this wave (row = wave + 8 j): six bits "chi2 of the landmark's last edge > delta 2^i", i = 0..5
+            unsigned long long lastbits_lo = 0, lastbits_hi = 0;
+            int cnt_out[5] = {0, 0, 0, 0, 0}, cnt_all = 0;
+            double thv[6];
+            thv[0] = delta;
+#pragma unroll
+            for (int i = 1; i < 6; ++i) thv[i] = thv[i - 1] * 2;
+            double* chi2 = (ra.want_chi2 && a.chi2) ? a.chi2 + e0 : nullptr;
+            if (chi2) { for (int e = tid; e < ne; e += kRsBlock) chi2[e] = 0.0; __syncthreads(); }
+            float2 zn[kRsSlotsReg];
+            uv_issue(wave, zn);
+            for (int j = 0; wave + kRsWaves * j < nrows; ++j) {
+                const int r = wave + kRsWaves * j;
+                Row R; row_open(r, zn, R);
+                uv_issue(r + kRsWaves, zn);
+                unsigned mm = R.m, bits = 0;
+                for (int q = 0; q < R.rc; ++q) {
+                    if (mm) {
+                        const int k = __builtin_ctz(mm); mm &= mm - 1;
+                        const float2 z = obs_uv(R, q);
+                        double X, Y, Z, ex, ey;
+                        project_err(&Rsel[12 * k], K, R.px, R.py, R.pz, z.x, z.y, X, Y, Z, ex, ey);
+                        const double c = ex * ex + ey * ey;
+                        ++cnt_all;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) cnt_out[i] += c > thv[i];
+                        if (q == R.lastq) {
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) bits |= (c > thv[i]) ? (1u << i) : 0u;
+                        }
+                        if (chi2) chi2[epos[sm.slotoff[min(q, kRsKf - 1)] + R.s]] = c;
+                    }
+                }
+                if (j < 10) lastbits_lo |= (unsigned long long)bits << (6 * j); else lastbits_hi |= (unsigned long long)bits << (6 * (j - 10));
+            }
+            if (cyc && tid == 0) { const long long t1__ = clock64(); atomicAdd(reinterpret_cast<unsigned long long*>(cyc) + 15, (unsigned long long)(t1__ - t_ph)); }
+            double th = delta;
+            if (classify) {
+                int v[6] = {cnt_out[0], cnt_out[1], cnt_out[2], cnt_out[3], cnt_out[4], cnt_all};
+#pragma unroll
+                for (int i = 0; i < 6; ++i) for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+                __syncthreads();
+                if (lane == 0)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) sm.redi[8 * wave + i] = v[i];
+                __syncthreads();
+                int tot[6] = {0, 0, 0, 0, 0, 0};
+                for (int ww = 0; ww < kRsWaves; ++ww)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) tot[i] += sm.redi[8 * ww + i];
+                int ti = 0;
+                for (int iteration = 0; iteration < 5; ++iteration) {
+                    const double out = (double)tot[iteration], in = (double)(tot[5] - tot[iteration]);
+                    const double ratio = in / (in + out);
+                    if (ratio > 0.5) break;
+                    th *= 2; ++ti;
+                }
+                for (int j = 0; wave + kRsWaves * j < nrows; ++j) {
+                    const int s = 64 * (wave + kRsWaves * j) + lane;
+                    const unsigned lv = live[s];
+                    if (lv & 0xFFFu) {
+                        const unsigned b6 = j < 10 ? (unsigned)(lastbits_lo >> (6 * j)) : (unsigned)(lastbits_hi >> (6 * (j - 10)));
+                        const bool keep = ((b6 >> ti) & 1u) == 0;
+                        if (!keep) { a.lm_inlier[lm0 + perm[s]] = 0; live[s] = 0; newly_flagged = 1; } // (a live landmark's flag is 1: only a change is written)
+                    }
+                }
+                if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
+            }
+        return newly_flagged;
+    };
+
+    // ------------------------------------------------------------------ passes of the schedule (run_vslam.cpp:61-66) / the single call
+    const int iters_early = iters;
+    constexpr int npass = SCHED ? 3 : 1;
+    bool done = false;
+    int pass = 0;
+    vslam_lm_stats* st = a.stats ? a.stats + w : nullptr;
+    for (; pass < npass && !done; ++pass) {
+        if (SCHED) { iters = pass < 2 ? iters_early : kRsSchedFinalIters; update_poses = pass == 2; }
+        pass_init(pass == 0 ? 0 : 1);
         RPH(1);
 
         double lambda = 0, ni = 2, currentChi = 0, Bcur = 0;
@@ -1150,78 +1229,7 @@ __global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int it
         }
         // ---- chi2 of every active edge at the LAST EVALUATED state (g2o leaves the errors of the last trial behind, accepted or not), the
         // adaptive threshold and the landmark flags (optimization.cpp:224-266): the landmark's last edge decides
-        int newly_flagged = 0;
-        {
-            const double* Rsel = last_trial_is_current ? sm.Rt : sm.RtT;
-            // per row slot of this wave (row = wave + 8 j): six bits "chi2 of the landmark's last edge > delta 2^i", i = 0..5
-            unsigned long long lastbits_lo = 0, lastbits_hi = 0;
-            int cnt_out[5] = {0, 0, 0, 0, 0}, cnt_all = 0;
-            double thv[6];
-            thv[0] = delta;
-#pragma unroll
-            for (int i = 1; i < 6; ++i) thv[i] = thv[i - 1] * 2;
-            double* chi2 = (ra.want_chi2 && a.chi2) ? a.chi2 + e0 : nullptr;
-            if (chi2) { for (int e = tid; e < ne; e += kRsBlock) chi2[e] = 0.0; __syncthreads(); }
-            float2 zn[kRsSlotsReg];
-            uv_issue(wave, zn);
-            for (int j = 0; wave + kRsWaves * j < nrows; ++j) {
-                const int r = wave + kRsWaves * j;
-                Row R; row_open(r, zn, R);
-                uv_issue(r + kRsWaves, zn);
-                unsigned mm = R.m, bits = 0;
-                for (int q = 0; q < R.rc; ++q) {
-                    if (mm) {
-                        const int k = __builtin_ctz(mm); mm &= mm - 1;
-                        const float2 z = obs_uv(R, q);
-                        double X, Y, Z, ex, ey;
-                        project_err(&Rsel[12 * k], K, R.px, R.py, R.pz, z.x, z.y, X, Y, Z, ex, ey);
-                        const double c = ex * ex + ey * ey;
-                        ++cnt_all;
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) cnt_out[i] += c > thv[i];
-                        if (q == R.lastq) {
-#pragma unroll
-                            for (int i = 0; i < 6; ++i) bits |= (c > thv[i]) ? (1u << i) : 0u;
-                        }
-                        if (chi2) chi2[epos[sm.slotoff[min(q, kRsKf - 1)] + R.s]] = c;
-                    }
-                }
-                if (j < 10) lastbits_lo |= (unsigned long long)bits << (6 * j); else lastbits_hi |= (unsigned long long)bits << (6 * (j - 10));
-            }
-            if (cyc && tid == 0) { const long long t1__ = clock64(); atomicAdd(reinterpret_cast<unsigned long long*>(cyc) + 15, (unsigned long long)(t1__ - t_ph)); }
-            double th = delta;
-            if (classify) {
-                int v[6] = {cnt_out[0], cnt_out[1], cnt_out[2], cnt_out[3], cnt_out[4], cnt_all};
-#pragma unroll
-                for (int i = 0; i < 6; ++i) for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
-                __syncthreads();
-                if (lane == 0)
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) sm.redi[8 * wave + i] = v[i];
-                __syncthreads();
-                int tot[6] = {0, 0, 0, 0, 0, 0};
-                for (int ww = 0; ww < kRsWaves; ++ww)
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) tot[i] += sm.redi[8 * ww + i];
-                int ti = 0;
-                for (int iteration = 0; iteration < 5; ++iteration) {
-                    const double out = (double)tot[iteration], in = (double)(tot[5] - tot[iteration]);
-                    const double ratio = in / (in + out);
-                    if (ratio > 0.5) break;
-                    th *= 2; ++ti;
-                }
-                for (int j = 0; wave + kRsWaves * j < nrows; ++j) {
-                    const int s = 64 * (wave + kRsWaves * j) + lane;
-                    const unsigned lv = live[s];
-                    if (lv & 0xFFFu) {
-                        const unsigned b6 = j < 10 ? (unsigned)(lastbits_lo >> (6 * j)) : (unsigned)(lastbits_hi >> (6 * (j - 10)));
-                        const bool keep = ((b6 >> ti) & 1u) == 0;
-                        if (!keep) { a.lm_inlier[lm0 + perm[s]] = 0; live[s] = 0; newly_flagged = 1; } // (a live landmark's flag is 1: only a change is written)
-                    }
-                }
-                if (tid == 0 && a.chi2_thr) a.chi2_thr[w] = th;
-            }
-        }
+        const int newly_flagged = classify_pass(last_trial_is_current ? sm.Rt : sm.RtT);
         RPH(8);
         if (SCHED && pass < 2 && adaptive) {
             if (!done) { // (done: this was the continuation -- the last pass, whatever its own classification flagged)

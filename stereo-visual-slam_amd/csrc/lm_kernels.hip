@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kLmBlock, VSLAM_LM_MIN_WAVES) void lm_window_kernel
     const LmWindowArgs& a = ka.a;
     __shared__ LmShared sm;
     const int w = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;
-    if (ka.defer && !ka.defer[w]) return; // (uniform) ba_resident_kernel has done this window
+    if (ka.defer && !(ka.defer[w] & 1)) return; // (uniform) ba_resident_kernel has done this window
     int prio_cnt = 0; (void)prio_cnt;
     // keyframes of this window: a.n_kf slots (the pose stride), of which window w uses the first n_kf_w[w] (a growing map)
     const int nk = (!IMPL && a.n_kf_w) ? min(max(a.n_kf_w[w], 1), a.n_kf) : a.n_kf, np = 6 * nk;

@@ -155,3 +155,4 @@ def test_resident_defers_windows_that_do_not_fit(pkg, synth):
     assert np.allclose(res[1][0], res[0][0], rtol=1e-6, atol=1e-8)
     assert np.array_equal(res[1][0][1], res[0][0][1])        # the deferred window ran on the same kernel both times: same bits
     assert (res[1][1] != res[0][1]).mean() < 2e-3
+
