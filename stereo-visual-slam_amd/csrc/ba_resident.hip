@@ -27,6 +27,9 @@
 
 namespace vslam {
 
+#ifndef VSLAM_RS_MIN_WAVES
+#define VSLAM_RS_MIN_WAVES 2 // waves per SIMD the register allocation must leave room for (2: 256 VGPRs)
+#endif
 constexpr int kRsBlock = 512;
 constexpr int kRsWaves = kRsBlock / 64;
 constexpr int kRsKf = VSLAM_MAX_KF;
@@ -87,7 +90,7 @@ __device__ inline long long to_fixed(double v, double scale) { return __double2l
 __device__ inline int rs_blk(int I, int K) { return (I * (I + 1) / 2 + K) * 36; }
 
 template <bool SCHED>
-__global__ __launch_bounds__(kRsBlock) void ba_resident_kernel(RsArgs ra, int iters, int update_poses, int update_lms, int classify, int adaptive) {
+__global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kernel(RsArgs ra, int iters, int update_poses, int update_lms, int classify, int adaptive) {
     const LmWindowArgs& a = ra.a;
     extern __shared__ __align__(16) unsigned char dyn[];
     __shared__ RsShared sm;

@@ -6,7 +6,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 STEPS=3
-COMMON="--steps $STEPS --warmup 1 --repeats 1 --in-flight 1 --no-plain-schedule --no-cpu-baseline --no-config4 --no-reference-pipeline --no-config4-step --no-live-dropin --render-workers 0 --unique-frames 64 --inputs resident"
+COMMON="--steps $STEPS --warmup 1 --repeats 1 --in-flight 1 --no-plain-schedule --no-cpu-baseline --no-config4 --no-reference-pipeline --no-config4-step --no-live-dropin --render-workers 0 --unique-frames 128 --inputs resident"
 for CFG in ${@:-tracks config4 sgbm}; do
   case $CFG in
     tracks)  ARGS="$COMMON";                                   BATCH=512;;
