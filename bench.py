@@ -1029,8 +1029,9 @@ def main():
                          "avg_ms_per_launch_set": round(1e3 * per_bracket_s, 4), "kernel_launches_per_set": dom_launches // max(dom_calls, 1),
                          "launch_set": (("one BA schedule = 3 x lm_window_kernel (optimize_map, 5 + 5 + 10 iterations) + 1 x pose_only_wave_kernel (10 iterations)"
                                          if args.ba_plain_schedule else
-                                         "one BA schedule = 1 x lm_window_kernel (a window's optimize_map passes 5 + 5 + 10 back to back; a pass that flags nothing new is "
-                                         "continued as the last one) + 1 x pose_only_wave_kernel (10 iterations)")
+                                         "one BA schedule (stage-profiler family `lm_window_kernel`) = 1 x ba_resident_kernel (optimize_map passes 5 + 5 + 10 back to back for every "
+                                         "window that fits its LDS budget: all of them here; a pass that flags nothing new is continued as the last one) + 1 x lm_window_kernel (the "
+                                         "windows ba_resident_kernel deferred: none here, its workgroups return at once) + 1 x pose_only_wave_kernel (10 iterations)")
                                         if dom == "lm_window_kernel" else "one stage bracket")},
             "kernels_ms_per_step": {k: round(v[0] / n_prof_steps, 4) for k, v in kern},
             "other_rooflines": other_rooflines(prof, pipe, args, n_prof_steps, copy_gbs),

@@ -1963,7 +1963,8 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     // Tuning::ba_adaptive (default on): ONE launch runs a window's passes back to back, and a pass that flags nothing new is continued to the last pass's
     // 10 iterations instead of being repeated (see the kernel); 0: the three passes as three launches, every one of them for every window
     const bool adaptive = !(scratch->tune && scratch->tune->ba_adaptive == 0);
-    ProfScope prof__(stream, "lm_window_kernel", schedule ? (adaptive ? 2 : 4) : 1);
+    const bool resident_on = (schedule || mode == 0) && !(scratch->tune && scratch->tune->ba_resident == 0);
+    ProfScope prof__(stream, "lm_window_kernel", (schedule ? (adaptive ? 2 : 4) : 1) + (resident_on ? 1 : 0)); // (family name kept from rounds 1-4; the BA schedule's launches)
     if (VSLAM_LM_LPT && a.n_windows > 1 && a.n_windows <= kOrderCap)
         hipLaunchKernelGGL(lm_order_kernel, dim3(1), dim3(1024), 0, stream, a.edge_off, a.n_windows, const_cast<int32_t*>(ka.order));
     else ka.order = nullptr;
