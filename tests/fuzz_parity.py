@@ -6,7 +6,7 @@ import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-KINDS = ["match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev", "ba_schedule"]
+KINDS = ["match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev", "ba_schedule", "ba_resident"]
 
 
 class Mismatch(AssertionError):
@@ -68,6 +68,24 @@ def one_case(kind, rng, vo, pkg, O, synth):
         T, x, chi2, st = O.local_ba(win["T0"], win["xyz"], win["kf_idx"], win["lm_idx"], win["uv"], iters=it, update_poses=True, update_lms=True)
         if not (np.allclose(r["T"], T, rtol=1e-4, atol=1e-6) and np.allclose(r["xyz"], x, rtol=1e-4, atol=1e-4)):
             fail("local_ba", nk=nk, nl=nl, seed=seed, iters=it)
+    elif kind == "ba_resident":
+        # optimize_map on the LDS-resident kernel (forced: ba_resident = 1) vs the oracle, random window shapes incl. single-observation landmarks
+        # (the Woodbury path), tracks through the whole window, 1..12 keyframes; and the same call twice: the same bits (round 5)
+        nk = int(rng.integers(1, 13)); nl = int(rng.choice([40, 300, 1500, 2600, 4000]))
+        lo_obs = int(rng.integers(1, 3)); hi_obs = int(rng.integers(lo_obs, 11))
+        win = synth.ba_window(n_kf=nk, n_lm=nl, seed=seed, max_obs=min(hi_obs, nk), min_obs=min(lo_obs, nk))
+        it = int(rng.integers(1, 11))
+        try:
+            vo.set_tuning(ba_resident=1)
+            r = vo.optimize_map(win["T0"], win["xyz"], win["kf_idx"], win["lm_idx"], win["uv"], True, True, it)
+            r2 = vo.optimize_map(win["T0"], win["xyz"], win["kf_idx"], win["lm_idx"], win["uv"], True, True, it)
+        finally:
+            vo.set_tuning(ba_resident=-1)
+        T, x, chi2, st = O.local_ba(win["T0"], win["xyz"], win["kf_idx"], win["lm_idx"], win["uv"], iters=it, update_poses=True, update_lms=True)
+        if not (np.allclose(r["T"], T, rtol=1e-4, atol=1e-6) and np.allclose(r["xyz"], x, rtol=1e-4, atol=1e-4) and np.allclose(r["chi2"], chi2, rtol=1e-4, atol=1e-6)):
+            fail("ba_resident", nk=nk, nl=nl, seed=seed, iters=it, obs=(lo_obs, hi_obs))
+        if not (np.array_equal(r["T"], r2["T"]) and np.array_equal(r["xyz"], r2["xyz"]) and np.array_equal(r["chi2"], r2["chi2"])):
+            fail("ba_resident twice", nk=nk, nl=nl, seed=seed, iters=it, obs=(lo_obs, hi_obs))
     elif kind == "ba_schedule":
         # the adaptive BA schedule (a pass that flags nothing new is continued instead of repeated) against the plain one -- every optimize_map pass for
         # every window -- on random batches: bit-identical poses, flags and per-edge chi2 (round 4)
@@ -203,7 +221,7 @@ def run(seconds=120.0, seed=0, only="", vo=None, max_cases=None, schedule=None):
     i = 0
     try:
         while time.time() < t_end and (max_cases is None or i < max_cases):
-            kind = only or (schedule[i % len(schedule)] if schedule else rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev", "ba_schedule"]))
+            kind = only or (schedule[i % len(schedule)] if schedule else rng.choice(["match", "match", "sgbm", "orb", "ba", "pnp", "ransac", "windows", "ransac_dev", "ba_schedule", "ba_resident"]))
             one_case(kind, rng, vo, pkg, O, synth)
             n[kind] += 1
             i += 1

@@ -16,7 +16,7 @@ def test_fuzz_slice_all_stages(pkg):
     try:
         # round-robin over the six stages so that each gets its share of the budget (ORB cases build a context per image size and
         # run the CPU oracle on up to 1400 x 700 pixels: they dominate the wall clock)
-        n = fuzz_parity.run(seconds=55.0, seed=20260929, vo=ctx, schedule=["match", "sgbm", "ba", "pnp", "ransac", "windows", "ransac_dev", "ba_schedule", "match", "orb"])
+        n = fuzz_parity.run(seconds=55.0, seed=20260929, vo=ctx, schedule=["match", "sgbm", "ba", "pnp", "ransac", "windows", "ransac_dev", "ba_schedule", "ba_resident", "match", "orb"])
     finally:
         ctx.close()
     print("fuzz slice (seed 20260929):", n, "total", sum(n.values()))
