@@ -351,6 +351,12 @@ int vslam_set_tuning(vslam_ctx* ctx, const char* name, int value);
 int vslam_sgbm_status_dev(vslam_ctx* ctx, int32_t* h_status);
 /* per-image ORB capacity flags of the most recent ORB launch (0 = ok) */
 int vslam_orb_status_dev(vslam_ctx* ctx, int B, int32_t* h_status);
+/* Diagnostic (rows A1 / A3): one level of the scale pyramid (blurred = 0: cv::resize INTER_LINEAR of the level above, what cv::ORB::detect runs
+ * FAST / Harris / the IC angle on; level 0 is the caller's image and is not kept) or of the GaussianBlur 7x7 sigma 2 pyramid (blurred = 1: what
+ * cv::ORB::compute samples) of image `item` of the most recent ORB launch of this context (vslam_feature_detection[_dev], vslam_orb_compute:
+ * the calls that describe fill both; detect-only calls fill the unblurred pyramid), copied to host memory: *w x *h bytes, row stride out_stride.
+ * Synchronises the stream.  visual_odometry.cpp:80,85 (inside cv::ORB). */
+int vslam_orb_level(vslam_ctx* ctx, int item, int level, int blurred, uint8_t* out, int out_stride, int out_rows, int* w, int* h);
 
 /* Device glue between the frame-to-frame matcher and the motion-only stage (the gather of
  * VO::motion_estimation, visual_odometry.cpp:260-270): for every frame-to-frame match (query = previous frame,

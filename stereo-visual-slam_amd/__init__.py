@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "vslam_orb_compute", "vslam_feature_detection_dev", "vslam_feature_matching", "vslam_feature_matching_dev",
     "vslam_find_3d_disparity", "vslam_triangulate", "vslam_triangulate_dev", "vslam_gather_matched_uv_dev",
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
-    "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_ba_schedule_passes_dev", "vslam_edge_jacobians", "vslam_orb_status_dev", "vslam_dev_alloc",
+    "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_ba_schedule_passes_dev", "vslam_edge_jacobians", "vslam_orb_status_dev", "vslam_orb_level", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
     "vslam_profile_enable", "vslam_profile_read", "vslam_profile_intervals", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
     "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant", "vslam_sgbm_status_dev", "vslam_set_tuning", "vslam_build_windows_dev", "vslam_pnp_ransac_dev",
@@ -253,6 +253,14 @@ class VO:
     def feature_detection_dev(self, d_imgs, img_bytes, pitch, B, d_kps, d_desc, d_count):
         self._chk(self.lib.vslam_feature_detection_dev(self.h, _p(d_imgs), C.c_size_t(img_bytes), int(pitch), int(B), _p(d_kps),
                                                        _p(d_desc), _p(d_count)), "vslam_feature_detection_dev")
+
+    def orb_level(self, item, level, blurred):
+        """one level of the (blurred) pyramid of image `item` of the most recent ORB launch (diagnostic)"""
+        w, h = C.c_int(0), C.c_int(0)
+        buf = np.zeros((self.params.img_h, (self.params.img_w + 63) & ~63), np.uint8)
+        self._chk(self.lib.vslam_orb_level(self.h, int(item), int(level), int(bool(blurred)), _p(buf), int(buf.strides[0]), int(buf.shape[0]),
+                                           C.byref(w), C.byref(h)), "vslam_orb_level")
+        return buf[:h.value, :w.value].copy()
 
     def orb_status(self, B):
         st = np.zeros(B, np.int32)

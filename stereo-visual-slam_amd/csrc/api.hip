@@ -438,6 +438,20 @@ int vslam_orb_status_dev(vslam_ctx* ctx, int B, int32_t* h_status) {
     return VSLAM_OK;
 }
 
+int vslam_orb_level(vslam_ctx* ctx, int item, int level, int blurred, uint8_t* out, int out_stride, int out_rows, int* w, int* h) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !out || !w || !h || item < 0 || item >= c->p.max_batch || level < 0 || level >= kNLevels || (level == 0 && !blurred)) { set_error("bad argument"); return VSLAM_ERR_ARG; }
+    VS_ENTER(c);
+    const OrbLevel& L = c->plan.lv[level];
+    if (out_stride < L.w || out_rows < L.h) { set_error("vslam_orb_level: level %d is %d x %d", level, L.w, L.h); return VSLAM_ERR_CAPACITY; }
+    const uint8_t* src = blurred ? c->orb.d_blur + (size_t)item * c->plan.blur_bytes + c->plan.blur_off[level]
+                                 : c->orb.d_pyr + (size_t)item * c->plan.pyr_bytes + L.pyr_off;
+    VS_HIP(hipStreamSynchronize(c->stream));
+    VS_HIP(hipMemcpy2D(out, (size_t)out_stride, src, (size_t)((L.w + 63) & ~63), (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+    *w = L.w; *h = L.h;
+    return VSLAM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- matcher
 int vslam_feature_matching_dev(vslam_ctx* ctx, const uint8_t* d_q, size_t q_stride_bytes, const int32_t* d_nq, const uint8_t* d_t,
                                size_t t_stride_bytes, const int32_t* d_nt, const double* d_gap, int gate, int B, int max_rows,

@@ -135,42 +135,70 @@ __device__ inline void load_tile_u8(uint8_t* lds, int lds_pitch, const uint8_t* 
 
 // Wide variant for tiles whose rows are CHUNKS x 16 bytes (lds_pitch = 16 * CHUNKS, 16-byte aligned): every thread first ISSUES
 // all of its 16-byte loads (a tile load is otherwise a chain of dependent round trips, one dword each), then stores them.
-// Chunks that straddle the image border are assembled byte by byte with reflect-101 (REFLECT) or clamped (!REFLECT) coordinates;
-// chunks nobody reads (more than 3 columns / rows beyond the image) are skipped.
+// Chunks nobody reads (more than 3 columns / rows beyond the image) are skipped.  Rows beyond the image come from the reflected
+// (REFLECT) or clamped (!REFLECT) row, as whole rows.  Columns: every chunk is ONE 16-byte load -- a chunk that starts left of the
+// image or ends beyond the row's pitch is loaded from the nearest 16 bytes inside the row and shifted into place (the pitch bounds the
+// address, not the width: bytes between W and the pitch are padding, loaded like pixels); after a workgroup barrier the <= 4 + 3
+// columns per row that lie outside the image are filled from their reflect-101 sources INSIDE the staged tile (LDS to LDS: 7 bytes
+// per row).  !REFLECT (the FAST tile): pixels outside the image are never read by a pixel that is emitted, they stay undefined.
+// [r5] The first version assembled every chunk that straddles the image border byte by byte from global memory (16 dependent-address
+// byte loads + reflect arithmetic, ~400 instructions, and a second memory round trip for the workgroup): edge tiles are 40 % of the
+// tiles of level 0 and all tiles of the small levels -- 0.5 ms of orb_pyrblur_kernel's 2.0 ms per 1024 images.
+__device__ inline uint4 shl_bytes_128(uint4 v, int s) { // out byte k = in byte k - s (s = 0..15, zero fill)
+    for (int t = 0; t < (s >> 2); ++t) { v.w = v.z; v.z = v.y; v.y = v.x; v.x = 0; }
+    const uint32_t b = (uint32_t)s & 3u;
+    if (b) {
+        v.w = __builtin_amdgcn_alignbyte(v.w, v.z, 4u - b); v.z = __builtin_amdgcn_alignbyte(v.z, v.y, 4u - b);
+        v.y = __builtin_amdgcn_alignbyte(v.y, v.x, 4u - b); v.x <<= 8u * b;
+    }
+    return v;
+}
+__device__ inline uint4 shr_bytes_128(uint4 v, int s) { // out byte k = in byte k + s (s = 0..15, zero fill)
+    for (int t = 0; t < (s >> 2); ++t) { v.x = v.y; v.y = v.z; v.z = v.w; v.w = 0; }
+    const uint32_t b = (uint32_t)s & 3u;
+    if (b) {
+        v.x = __builtin_amdgcn_alignbyte(v.y, v.x, b); v.y = __builtin_amdgcn_alignbyte(v.z, v.y, b);
+        v.z = __builtin_amdgcn_alignbyte(v.w, v.z, b); v.w >>= 8u * b;
+    }
+    return v;
+}
 template <int NTHREADS, int CHUNKS, int ROWS, bool REFLECT>
 __device__ inline void load_tile_b128(uint8_t* lds, const uint8_t* __restrict__ src, int spitch, int W, int H, int x0, int y0) {
     constexpr int kTotal = CHUNKS * ROWS, kIter = (kTotal + NTHREADS - 1) / NTHREADS;
     uint4 v[kIter];
-    int state[kIter]; // 0: nothing to do, 1: loaded, 2: border chunk (byte path)
+    int shift[kIter]; // bytes the loaded chunk has to move (0 for all but the <= 2 border chunks of a row); kSkip: nothing to do
+    constexpr int kSkip = 1 << 20;
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         const int i = threadIdx.x + it * NTHREADS;
         const int r = i / CHUNKS, c = i - r * CHUNKS, xa = x0 + 16 * c, ya = y0 + r;
-        state[it] = 0;
+        shift[it] = kSkip;
         if (i < kTotal && xa < W + 4 && ya < H + 3) {
-            if (xa >= 0 && xa + 16 <= W) {
-                const int y = REFLECT ? reflect101(ya, H) : min(max(ya, 0), H - 1);
-                __builtin_memcpy(&v[it], src + (size_t)y * spitch + xa, 16);
-                state[it] = 1;
-            } else state[it] = 2;
+            const int ay = ya < 0 ? -ya : ya;
+            const int y = REFLECT ? max(min(ay, 2 * (H - 1) - ay), 0) : min(max(ya, 0), H - 1);
+            const int xl = min(max(xa, 0), spitch - 16); // (spitch >= 64)
+            __builtin_memcpy(&v[it], src + (size_t)y * spitch + xl, 16);
+            shift[it] = xl - xa;
         }
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         const int i = threadIdx.x + it * NTHREADS;
-        const int r = i / CHUNKS, c = i - r * CHUNKS, xa = x0 + 16 * c;
-        if (state[it] == 2) {
-            const uint8_t* row = src + (size_t)(REFLECT ? reflect101(y0 + r, H) : min(max(y0 + r, 0), H - 1)) * spitch;
-            uint32_t w[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                w[d] = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w[d] |= (uint32_t)row[REFLECT ? reflect101(xa + 4 * d + k, W) : min(max(xa + 4 * d + k, 0), W - 1)] << (8 * k);
-            }
-            v[it] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (shift[it] == kSkip) continue;
+        if (shift[it] > 0) v[it] = shl_bytes_128(v[it], shift[it]);
+        else if (shift[it] < 0) v[it] = shr_bytes_128(v[it], -shift[it]);
+        *reinterpret_cast<uint4*>(lds + 16 * i) = v[it];
+    }
+    if (REFLECT && (x0 < 0 || x0 + 16 * CHUNKS > W)) { // (uniform) columns outside the image: reflect-101, from the staged pixels
+        __syncthreads();
+        for (int t = threadIdx.x; t < ROWS * 7; t += NTHREADS) {
+            const int r = t / 7, k = t - 7 * r;
+            const int x = k < 4 ? x0 + k : W + (k - 4);            // k < 4: the (<= 4) columns left of the image; else W, W + 1, W + 2
+            if (k < 4 ? x >= 0 : (x - x0 >= 16 * CHUNKS)) continue;
+            const int xs = x < 0 ? -x : 2 * (W - 1) - x;           // (W >= 5: one reflection)
+            const int js = min(max(xs - x0, 0), 16 * CHUNKS - 1);
+            lds[r * (16 * CHUNKS) + (x - x0)] = lds[r * (16 * CHUNKS) + js];
         }
-        if (state[it] != 0) *reinterpret_cast<uint4*>(lds + (r * CHUNKS + c) * 16) = v[it];
     }
 }
 
@@ -310,6 +338,24 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ inline uint32_t udot2_u16(uint32_t a, uint32_t b) { // v_dot2_u32_u16: a.lo * b.lo + a.hi * b.hi
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), 0u, false);
 }
+// Vertical pass + rounding + packing of four outputs of cv::resize's 8U INTER_LINEAR: v = ((b0 * (h0 >> 4) >> 16) + (b1 * (h1 >> 4) >> 16) + 2) >> 2.
+// The + 2 rides on the second product (+ 2 << 16, a v_mad), the two ">> 16" are one v_perm per PAIR of pixels (the high halves of two
+// products side by side), the sum and the ">> 2" are packed 16-bit operations on such pairs (the sum is <= 1023), one more v_perm picks
+// the four result bytes: 41 instead of ~60 instructions per four outputs (both resize kernels were at their instruction-issue bound).
+typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t resize_vertical4(const uint32_t (&h0)[4], const uint32_t (&h1)[4], uint32_t b0, uint32_t b1) {
+    uint32_t p0[4], p1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { p0[k] = __umul24(b0, h0[k] >> 4); p1[k] = __umul24(b1, h1[k] >> 4) + 0x20000u; } // (11-bit x 15-bit products)
+    rs_us2 t[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const rs_us2 x = __builtin_bit_cast(rs_us2, __builtin_amdgcn_perm(p0[2 * j + 1], p0[2 * j], 0x07060302u));
+        const rs_us2 y = __builtin_bit_cast(rs_us2, __builtin_amdgcn_perm(p1[2 * j + 1], p1[2 * j], 0x07060302u));
+        t[j] = (rs_us2)(x + y) >> (rs_us2){2, 2};
+    }
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, t[1]), __builtin_bit_cast(uint32_t, t[0]), 0x06040200u);
+}
 // Workgroup = 4 waves; a wave owns kResizeRows consecutive output rows (so the row tables and every row base address are scalar)
 // and a lane four consecutive output pixels: the column setup -- source offsets, coefficient words, byte selectors -- is done
 // once and reused for every row.  Per source row ONE unaligned 8-byte load covers the <= 6 source pixels the four outputs
@@ -349,14 +395,13 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t* __restri
         __builtin_memcpy(&r0, src + (size_t)y0 * spitch + wx, 8);
         __builtin_memcpy(&r1, src + (size_t)y1 * spitch + wx, 8);
         const uint32_t r0l = (uint32_t)r0, r0h = (uint32_t)(r0 >> 32), r1l = (uint32_t)r1, r1h = (uint32_t)(r1 >> 32);
-        uint32_t packed = 0;
+        uint32_t h0[4], h1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t h0 = udot2_u16(__builtin_amdgcn_perm(r0h, r0l, sel[k]), alw[k]);
-            const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(r1h, r1l, sel[k]), alw[k]);
-            const uint32_t v = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2; // (11-bit x 15-bit products)
-            packed |= (v & 0xFFu) << (8 * k);
+            h0[k] = udot2_u16(__builtin_amdgcn_perm(r0h, r0l, sel[k]), alw[k]);
+            h1[k] = udot2_u16(__builtin_amdgcn_perm(r1h, r1l, sel[k]), alw[k]);
         }
+        const uint32_t packed = resize_vertical4(h0, h1, b0, b1);
         *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + dx0) = packed; // dpitch is a multiple of 64; lanes past dw write padding
     }
 }
@@ -1473,7 +1518,10 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // ---- (1) level l + 1
-    if (a.dst_base) {
+#ifndef VSLAM_PYRBLUR_DBG
+#define VSLAM_PYRBLUR_DBG 0 // tuning aid (timing only, outputs incomplete): 1 = no blur half, 2 = no resize half
+#endif
+    if (a.dst_base && !(VSLAM_PYRBLUR_DBG & 2)) {
         const int dx_lo = a.tile_dx[tx], dx_hi = a.tile_dx[tx + 1], dy_lo = a.tile_dy[ty], dy_hi = a.tile_dy[ty + 1]; // uniform
         const int dx0 = (dx_lo & ~3) + 4 * lane; // this lane's aligned quad of output columns
         // the row tables of ALL rows of this wave are fetched once, one row per lane (<= 16 rows per wave: 64 source rows / 1.2 / 4 waves),
@@ -1512,14 +1560,13 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
                 const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], c0w = p1[0], c1w = p1[1], c2w = p1[2];
                 const uint32_t r0l = __builtin_amdgcn_alignbyte(a1, a0, off), r0h = __builtin_amdgcn_alignbyte(a2, a1, off);
                 const uint32_t r1l = __builtin_amdgcn_alignbyte(c1w, c0w, off), r1h = __builtin_amdgcn_alignbyte(c2w, c1w, off);
-                uint32_t packed = 0;
+                uint32_t h0[4], h1[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t h0 = udot2_u16(__builtin_amdgcn_perm(r0h, r0l, sel[k]), alw[k]);
-                    const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(r1h, r1l, sel[k]), alw[k]);
-                    const uint32_t v = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;
-                    packed |= (v & 0xFFu) << (8 * k);
+                    h0[k] = udot2_u16(__builtin_amdgcn_perm(r0h, r0l, sel[k]), alw[k]);
+                    h1[k] = udot2_u16(__builtin_amdgcn_perm(r1h, r1l, sel[k]), alw[k]);
                 }
+                const uint32_t packed = resize_vertical4(h0, h1, b0, b1);
                 uint8_t* o = dst + (size_t)dy * a.dpitch + dx0;
                 if (dx0 >= dx_lo && dx0 + 4 <= dx_hi) *reinterpret_cast<uint32_t*>(o) = packed;
                 else {
@@ -1531,6 +1578,7 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
     }
     // ---- (2) blurred level l (see orb_blur_kernel)
     uint8_t* dstb = a.blur_base + (size_t)b * a.blur_img_stride;
+    if (VSLAM_PYRBLUR_DBG & 1) return;
     const int row0 = wave * kBlurWaveRows;
     const int nrows = min(kBlurWaveRows, H - (oy + row0)); // wave-uniform
     const int x = ox + 4 * lane;

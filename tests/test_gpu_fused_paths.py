@@ -104,3 +104,32 @@ def test_sgbm_batched_both_paths(fuse_mode, pkg, oracle, synth):
             assert np.array_equal(got[b], oracle.disparity_map(Lc, R)), b
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(376, 1241), (257, 333), (200, 1324), (64, 64), (97, 300)])
+def test_pyramid_and_blur_levels_pixel_exact(fuse_mode, pkg, oracle, synth, shape):
+    """Every pixel of every pyramid level (cv::resize INTER_LINEAR 8U chain) and of every blurred level (GaussianBlur 7x7, 8-bit fixed point,
+    reflect-101) against the oracle -- vslam_orb_level reads back what the ORB kernels sample.  Covers the tile loader's border handling
+    (chunks shifted into place at the left edge / at the end of the pitch, reflect-101 columns filled from the staged tile; image sizes that
+    end anywhere inside a 16-byte chunk, tiles narrower than the 256-column workgroup tile) and, on the white image, the saturation of the
+    blur (taps add up to 257 per pass)."""
+    h, w = shape
+    imgs = [synth.noise_image(23, w, h), np.full((h, w), 255, np.uint8), np.zeros((h, w), np.uint8)]
+    g = np.add.outer(np.arange(h) * 3, np.arange(w) * 5) % 256
+    imgs.append(g.astype(np.uint8))
+    ctx = pkg.VO(device=0, max_batch=1, img_w=w, img_h=h, orb_nfeatures=500, anms_num=0)
+    try:
+        for img in imgs:
+            ctx.feature_detection(img)
+            lv = oracle.build_pyramid(img, 8, 500)
+            for l in range(8):
+                if l > 0:
+                    got = ctx.orb_level(0, l, False)
+                    assert got.shape == lv[l].shape and np.array_equal(got, lv[l]), ("pyramid", l, int((got != lv[l]).sum()))
+                got = ctx.orb_level(0, l, True)
+                want = oracle.gaussian_blur7(lv[l])
+                assert got.shape == want.shape, (got.shape, want.shape)
+                bad = np.argwhere(got != want)
+                assert len(bad) == 0, ("blur", l, len(bad), bad[:5].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
+    finally:
+        ctx.close()
