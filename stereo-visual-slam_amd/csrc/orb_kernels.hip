@@ -499,6 +499,10 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
     for (int i = threadIdx.x; i < (kScH * kScW + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
     __syncthreads();
     OPH(16);
+#ifndef VSLAM_FAST_DBG
+#define VSLAM_FAST_DBG 0 // tuning aid (timing only): 1 = tile load only, 2 = + pre-test, 3 = + corner score
+#endif
+    if (VSLAM_FAST_DBG == 1) { if (pix[threadIdx.x * 7] == 0xA7 && pix[threadIdx.x] == 0x3C && pix[5] == 1) atomicOr(&d_status[b], 64); return; }
 
     // (a) compass pre-test on the score region (tile + halo 1): a 9-arc always contains two ADJACENT compass pixels (ring
     // positions 0, 4, 8, 12), so a corner needs two adjacent compass pixels all brighter or all darker.  Cheap, and it
@@ -548,6 +552,7 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
     // (b) the survivors' corner score (largest threshold for which the pixel is still a FAST-9/16 corner).  A pixel is a corner at
     // `thr` exactly when that score is >= thr, so the score doubles as the full 16-pixel test: no separate ring-mask pass.
     const int nq = qcount;
+    if (VSLAM_FAST_DBG == 2) { if (nq == 77777 && queue[threadIdx.x] == 9) atomicOr(&d_status[b], 64); return; }
     for (int q = threadIdx.x; q < nq; q += 256) {
         const int i = queue[q];
         const int sy = i / kScW, sx = i - sy * kScW;
@@ -558,6 +563,7 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
     OPH(17);
     const int nc = ccount;
     OPH(18);
+    if (VSLAM_FAST_DBG == 3) { if (nc == 77777 && cqueue[threadIdx.x] == 9) atomicOr(&d_status[b], 64); return; }
     // (d) 3x3 non-max suppression + border cull (edgeThreshold 31): survivors collected in LDS, ONE global atomic per block
     for (int q = threadIdx.x; q < nc; q += 256) {
         const int i = cqueue[q];
@@ -683,7 +689,7 @@ __device__ inline void bitonic_sort_lds_e(K* a, int n) {
     __syncthreads();
 }
 template <typename K>
-__device__ inline void bitonic_sort_lds(K* a, int n) {
+__device__ __attribute__((always_inline)) inline void bitonic_sort_lds(K* a, int n) {
     const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x; // keys per lane so that the waves' chunks cover the array
     if (per <= 1) bitonic_sort_lds_e<K, 1>(a, n);
     else if (per <= 2) bitonic_sort_lds_e<K, 2>(a, n);
@@ -1101,7 +1107,13 @@ constexpr size_t anms_lds_bytes(int cap) { return (size_t)kMaxRows * 8 + (size_t
 constexpr int kAnmsCapPipe = 3328; // the detector emits at most nfeatures = 3000 keypoints plus ties at the per-level cuts
 static_assert(2 * anms_lds_bytes(kAnmsCapPipe) <= 160 * 1024, "two ANMS workgroups must fit one CU's LDS");
 
-template <int CAP>
+// [r5] SGPR budget: a wave of this device is allocated its SGPRs in blocks of 16 PLUS 16 (trap handler), out of 800 per SIMD: 8 waves per SIMD --
+// two of these 16-wave workgroups on a CU -- need a count of <= 80, while the compiler's occupancy model says 8 waves up to 96
+// (tools/scratch/occupancy_probe.hip).  The f64 cos / sin of `emit` is a real function CALL inside a kernel of this size (argument reduction
+// not inlined): the callee's 77 SGPRs and 8 bytes of stack became the kernel's, and with 83 SGPRs the second workgroup of a CU never
+// started -- ONE image per CU at a time, 1.04 ms per 1024 images, since round 2.  The batched pipeline never asks this kernel for the
+// rotation (orb_orient_kernel writes it), so that code lives in its own instance (WITH_CS: vslam_orb_compute, one image).
+template <int CAP, bool WITH_CS>
 __global__ __launch_bounds__(kAnmsBlock, 8) void orb_anms_kernel(const vslam_keypoint* __restrict__ d_in, const int32_t* __restrict__ d_nin,
                                                              int nlists, int in_capacity, int anms_num, int regroup, int img_w,
                                                              int img_h, vslam_keypoint* __restrict__ d_kps, float2* __restrict__ d_cs, int32_t* __restrict__ d_order, int kp_capacity,
@@ -1138,7 +1150,7 @@ __global__ __launch_bounds__(kAnmsBlock, 8) void orb_anms_kernel(const vslam_key
     // rotation of the rBRIEF pattern: a = (float)cos(angle * pi/180), b = (float)sin(...), evaluated in f64 like the CPU side
     auto emit = [&](int r, const vslam_keypoint* kp) {
         d_kps[(size_t)b * kp_capacity + r] = *kp;
-        if (d_cs) {
+        if (WITH_CS && d_cs) {
             const float ang = __fmul_rn(kp->angle, (float)(3.1415926535897932384626433832795 / 180.f));
             d_cs[(size_t)b * kp_capacity + r] = make_float2((float)cos((double)ang), (float)sin((double)ang));
         }
@@ -1357,12 +1369,17 @@ static int launch_anms_t(int B, const vslam_keypoint* d_in, const int32_t* d_nin
     int dev = 0;
     VS_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_anms_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_anms_kernel<CAP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(orb_anms_kernel<CAP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     ProfScope prof__(stream, "orb_anms_kernel");
-    hipLaunchKernelGGL(orb_anms_kernel<CAP>, dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
-                       img_w, img_h, d_kps, d_cs, d_order, kp_capacity, d_count, d_status, d_rad);
+    if (d_cs)
+        hipLaunchKernelGGL((orb_anms_kernel<CAP, true>), dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
+                           img_w, img_h, d_kps, d_cs, d_order, kp_capacity, d_count, d_status, d_rad);
+    else
+        hipLaunchKernelGGL((orb_anms_kernel<CAP, false>), dim3(B), dim3(kAnmsBlock), smem, stream, d_in, d_nin, nlists, in_capacity, anms_num, regroup,
+                           img_w, img_h, d_kps, d_cs, d_order, kp_capacity, d_count, d_status, d_rad);
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }
