@@ -30,12 +30,19 @@ namespace vslam {
 #ifndef VSLAM_RS_MIN_WAVES
 #define VSLAM_RS_MIN_WAVES 2 // waves per SIMD the register allocation must leave room for (2: 256 VGPRs)
 #endif
-constexpr int kRsBlock = 512;
+// [r5, second session] 256 lanes per window, TWO windows per CU (the launcher asks for half a CU's LDS): with 512 lanes a window held a whole CU
+// -- all of its registers, 156 KB of LDS -- at 20-27 % VALU activity, and its serial stretches (the 60-pivot factorisation: one or two waves busy
+// for 23 % of the time, barriers, exposed round trips) idled the other waves.  Two windows of four waves each use the same registers and fill each
+// other's gaps: 2.27 -> 1.82 ms per 512 small windows in the experiment that led here (profiles/r05_experiments.log).  What made a window fit half
+// the LDS: the positions of the SINGLES rows (87 % of the landmarks) live in global memory (L2), see `rl0` below.
+#ifndef VSLAM_RS_BLOCK
+#define VSLAM_RS_BLOCK 256
+#endif
+constexpr int kRsBlock = VSLAM_RS_BLOCK;
 constexpr int kRsWaves = kRsBlock / 64;
 constexpr int kRsKf = VSLAM_MAX_KF;
 constexpr int kRsNp = 6 * kRsKf;
-constexpr int kRsMaxRows = 96;                 // 64-landmark rows per window (6144 landmarks)
-constexpr int kRsRowsPerWave = kRsMaxRows / kRsWaves;
+constexpr int kRsMaxRows = 20 * kRsWaves;      // 64-landmark rows per window (5120 landmarks with four waves: the classification keeps six bits per row slot in two 64-bit words per lane)
 constexpr int kRsSlotsReg = 6;                 // observations per landmark preloaded into registers (the rest is fetched where it is used)
 constexpr int kRsSchedFinalIters = 10;         // run_vslam.cpp:66
 constexpr int kRsSortCap = 8192;               // keys of the in-kernel landmark sort (power of two >= landmarks)
@@ -44,6 +51,7 @@ constexpr int kRsPairs = kRsKf * (kRsKf + 1) / 2;
 constexpr int kRsHitChunk = 4;                 // 64-hit rows per work item of the hit-major Schur phase
 constexpr int kRsHitItems = 512;
 constexpr int kRsChunk = 4;                    // singles rows per work item of the linearisation pass
+constexpr int kRsHitReserveMax = 24 * 1024;    // most LDS bytes kept free for the hit lists when rows are dealt between LDS and global memory
 
 struct alignas(16) RsShared {
     double T[kRsKf * 7], TT[kRsKf * 7];
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     int n2 = 64;
     while (n2 < nl) n2 <<= 1;
     {   // does the window fit?  (uniform)
-        const size_t need_run = (size_t)nblk * 288 + (size_t)nlp * 26, need_setup = (size_t)nlp * 6 + (size_t)n2 * 4;
+        const size_t need_run = (size_t)nblk * 288 + (size_t)nlp * 2, need_setup = (size_t)nlp * 6 + (size_t)n2 * 4; // (need_run: without the position rows, see rl0)
         // (dense graphs -- more than ~2.2 observations per landmark, e.g. the synthetic config-4 windows at 3.5 -- stay on lm_window_kernel: their
         // Schur work is hits, not landmarks, and its stored hit lists / weights win there: 3.78 vs 4.3 ms per 256 such windows)
         const bool dense = ra.dense_to_general && 5 * (long long)ne > 11 * (long long)nl;
@@ -116,8 +124,12 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     }
     long long* Sq = reinterpret_cast<long long*>(dyn);
     double* Sb = reinterpret_cast<double*>(dyn);
-    double* P = reinterpret_cast<double*>(dyn + (size_t)nblk * 288);                       // x[nlp], y[nlp], z[nlp]
-    unsigned short* live = reinterpret_cast<unsigned short*>(dyn + (size_t)nblk * 288 + (size_t)nlp * 24);
+    // Positions: rows [rl0, nrows) in LDS (x[nlpL], y[nlpL], z[nlpL], nlpL = nlp - 64 rl0), rows [0, rl0) in the global working array Pw (same
+    // role: the state the current phase works on; the accepted state during a trial is Pbak for both).  rl0 is decided after the setup (it needs the
+    // first multi-observation landmark: only singles rows may live in global memory, the hit-major phase reads its landmarks from LDS).
+    int rl0 = 0, sl0 = 0, nlpL = nlp;
+    double* P = reinterpret_cast<double*>(dyn + (size_t)nblk * 288);
+    unsigned short* live = nullptr; // (set with rl0)
     const float* xyz = a.xyz + 3 * (size_t)lm0;
     const int32_t* kfi = a.kf_idx + e0;
     const int32_t* lmi = a.lm_idx + e0;
@@ -130,8 +142,9 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     double* Pbak = ra.Pbak + 3 * (size_t)lm0;
     double* Dc = ra.Dc + 6 * (size_t)lm0;
     double* blc = ra.blc + 3 * (size_t)lm0;
-    unsigned short* hit = reinterpret_cast<unsigned short*>(dyn + (size_t)nblk * 288 + (size_t)nlp * 26); // sorted landmark per Schur hit, pair-major
-    const int hit_cap = (int)min(((size_t)ra.dyn_bytes - ((size_t)nblk * 288 + (size_t)nlp * 26)) / 2, (size_t)0x7FFFFFF);
+    unsigned short* hit = nullptr; // sorted landmark per Schur hit, pair-major (set with rl0)
+    int hit_cap = 0;
+    double* Pw = ra.tab + 6 * (size_t)lm0 + nl; // (the window's slice of `tab` is 6 nl doubles; perm / mstat take the first 4 nl bytes)
     const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
     const CamK ck = make_camk(K);
     const double delta = a.huber_delta;
@@ -286,6 +299,25 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
         }
         __syncthreads(); // (the tables are in global memory / sm; the dynamic region is free from here on)
     }
+    {   // ---- which rows keep their positions in LDS (uniform).  Landmarks with several observations are the suffix [nl - nq[1], nl) of the sorted order.
+        const int rm_static = (nl - sm.nq[1]) >> 6; // rows before it hold single-observation landmarks in every pass
+        const long long fixed = (long long)nblk * 288 + (long long)nlp * 2;
+        // the hit lists of the first pass (the longest: later passes only lose landmarks): a landmark with c >= 2 observations is named by c (c + 1) / 2 pairs
+        long long hits = 0;
+        for (int c = 2; c <= kRsKf; ++c) hits += (long long)(sm.nq[c - 1] - (c < kRsKf ? sm.nq[c] : 0)) * (c * (c + 1) / 2);
+        const long long hit_bytes = min((2 * hits + 127) & ~63ll, (long long)kRsHitReserveMax);
+        int rows_lds = (int)max(((long long)ra.dyn_bytes - fixed - hit_bytes) / (64 * 24), 0ll);
+        if (nrows - rows_lds > rm_static) rows_lds = (int)max(((long long)ra.dyn_bytes - fixed) / (64 * 24), 0ll); // (give up the hit lists -- the row-wise pair path -- before the window)
+        rl0 = max(nrows - rows_lds, 0);
+        if (rl0 > rm_static) { // the multi-observation rows alone exceed the LDS: lm_window_kernel takes the window
+            if (tid == 0) ra.defer[w] = 1;
+            return;
+        }
+        sl0 = 64 * rl0; nlpL = nlp - sl0;
+        live = reinterpret_cast<unsigned short*>(dyn + (size_t)nblk * 288 + (size_t)nlpL * 24);
+        hit = live + nlp;
+        hit_cap = (int)min(((size_t)ra.dyn_bytes - ((size_t)nblk * 288 + (size_t)nlpL * 24 + (size_t)nlp * 2)) / 2, (size_t)0x7FFFFFF);
+    }
     RPH(0);
 
     // ------------------------------------------------------------------ row helpers
@@ -295,24 +327,31 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     // trip to L2 / HBM per row on their own (2.9 k cycles per row measured before the prefetch).
     // Rows [0, rm0) are SINGLES rows: every live landmark in them has exactly one observation (the sorted order puts them first).
     struct Row { int s; unsigned m; int lastq; double px, py, pz; float2 z[kRsSlotsReg]; unsigned U; int rc; };
-    auto uv_issue = [&](int r, float2 (&z)[kRsSlotsReg]) {
+    struct Pref { float2 z[kRsSlotsReg]; double p[3]; }; // what is requested a row ahead: the observations, and the position of a row that lives in global memory
+    auto uv_issue = [&](int r, Pref& F) {
         if (r >= nrows) return;
         const int s = 64 * r + lane;
         const int rc = __builtin_amdgcn_readfirstlane((int)sm.rowC[r]);
-        z[0] = uvs[max(min(sm.slotoff[0] + s, ne - 1), 0)];
+        F.z[0] = uvs[max(min(sm.slotoff[0] + s, ne - 1), 0)];
 #pragma unroll
         for (int q = 1; q < kRsSlotsReg; ++q)
-            if (q < rc) z[q] = uvs[max(min(sm.slotoff[q] + s, ne - 1), 0)]; // (uniform branch)
+            if (q < rc) F.z[q] = uvs[max(min(sm.slotoff[q] + s, ne - 1), 0)]; // (uniform branch)
+        if (r < rl0) { const int sc = min(s, nl - 1); F.p[0] = Pw[sc]; F.p[1] = Pw[nl + sc]; F.p[2] = Pw[2 * (size_t)nl + sc]; } // (uniform branch)
     };
-    auto row_open = [&](int r, const float2 (&z)[kRsSlotsReg], Row& R) {
+    auto row_open = [&](int r, const Pref& F, Row& R) {
         R.s = 64 * r + lane;
         const unsigned lv = live[R.s];
         R.m = lv & 0xFFFu; R.lastq = (int)(lv >> 12);
         R.U = __builtin_amdgcn_readfirstlane((unsigned)sm.rowU[r]);
         R.rc = __builtin_amdgcn_readfirstlane((int)sm.rowC[r]);
 #pragma unroll
-        for (int q = 0; q < kRsSlotsReg; ++q) R.z[q] = z[q];
-        R.px = P[R.s]; R.py = P[nlp + R.s]; R.pz = P[2 * nlp + R.s];
+        for (int q = 0; q < kRsSlotsReg; ++q) R.z[q] = F.z[q];
+        if (r < rl0) { R.px = F.p[0]; R.py = F.p[1]; R.pz = F.p[2]; }
+        else { const int sl = R.s - sl0; R.px = P[sl]; R.py = P[nlpL + sl]; R.pz = P[2 * nlpL + sl]; }
+    };
+    auto store_pos = [&](int r, int sidx, double x, double y, double z) { // the working position of sorted landmark sidx (row r)
+        if (r < rl0) { if (sidx < nl) { Pw[sidx] = x; Pw[nl + sidx] = y; Pw[2 * (size_t)nl + sidx] = z; } }
+        else { const int sl = sidx - sl0; P[sl] = x; P[nlpL + sl] = y; P[2 * nlpL + sl] = z; }
     };
     auto obs_uv = [&](const Row& R, int q) -> float2 { // observation q of the lane's landmark (q < its count)
         float2 z = R.z[0];
@@ -341,7 +380,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     // ---- evaluation at (Rsel, positions in LDS): robust cost and the fixed-point bound.  Static rows (row r -> wave r mod 8): fixed order.
     auto chi_pass = [&](const double* Rsel, double& bound_out) -> double {
         double part = 0, bpart = 0;
-        float2 zn[kRsSlotsReg];
+        Pref zn;
         uv_issue(wave, zn);
         for (int r = wave; r < nrows; r += kRsWaves) {
             Row R; row_open(r, zn, R);
@@ -380,7 +419,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
             if (lane == 0) it = atomicAdd(&sm.flag[6], 1);
             return __builtin_amdgcn_readfirstlane(it);
         };
-        float2 zn[kRsSlotsReg];
+        Pref zn;
         int item = draw();
         if (item < nitems) uv_issue(item_row(item), zn);
         while (item < nitems) {
@@ -642,7 +681,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                     const float2 z2 = uvs[max(min(sm.slotoff[min(q2, kRsKf - 1)] + s, ne - 1), 0)];
                     const double2* dq = reinterpret_cast<const double2*>(Dc + 6 * (size_t)s);
                     const double2 Da = dq[0], Db = dq[1], Dcc = dq[2];
-                    const double px = P[s], py = P[nlp + s], pz = P[2 * nlp + s];
+                    const double px = P[s - sl0], py = P[nlpL + s - sl0], pz = P[2 * nlpL + s - sl0]; // (a hit's landmark has several observations: its row is in LDS)
                     double g0 = 0, g1 = 0, g2 = 0;
                     if (k1 == k2) { g0 = blc[3 * (size_t)s]; g1 = blc[3 * (size_t)s + 1]; g2 = blc[3 * (size_t)s + 2]; }
                     if (!valid) continue;
@@ -725,7 +764,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     auto backsub_pass = [&](double lambda, bool backup, double& scale_out, double& bound_out) -> double {
         double part = 0, bpart = 0, spart = 0;
         const int rm0 = sm.flag[8];
-        float2 zn[kRsSlotsReg];
+        Pref zn;
         uv_issue(wave, zn);
         for (int r = wave; r < nrows; r += kRsWaves) {
             Row R; row_open(r, zn, R);
@@ -760,7 +799,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                         spart += dx[i] * (lambda * dx[i] + bl);
                     }
                     R.px += dx[0]; R.py += dx[1]; R.pz += dx[2];
-                    P[R.s] = R.px; P[nlp + R.s] = R.py; P[2 * nlp + R.s] = R.pz;
+                    store_pos(r, R.s, R.px, R.py, R.pz);
                     cam_norm(&sm.RtT[12 * k], R.px, R.py, R.pz, x, y, rho);
                     eval_obs(ck, x, y, R.z[0], delta, enx, eny, c, rob, wg);
                     part += rob;
@@ -807,7 +846,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                 const double x2 = Di[2] * c0 + Di[4] * c1 + Di[5] * c2;
                 spart += x0 * (lambda * x0 + g[0]) + x1 * (lambda * x1 + g[1]) + x2 * (lambda * x2 + g[2]);
                 R.px += x0; R.py += x1; R.pz += x2;
-                P[R.s] = R.px; P[nlp + R.s] = R.py; P[2 * nlp + R.s] = R.pz;
+                store_pos(r, R.s, R.px, R.py, R.pz);
             }
             {
                 unsigned mm = R.m;
@@ -833,7 +872,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
         return part;
     };
     auto restore_positions = [&]() {
-        for (int s = tid; s < nl; s += kRsBlock) { P[s] = Pbak[s]; P[nlp + s] = Pbak[nl + s]; P[2 * nlp + s] = Pbak[2 * (size_t)nl + s]; }
+        for (int s = tid; s < nl; s += kRsBlock) store_pos(s >> 6, s, Pbak[s], Pbak[nl + s], Pbak[2 * (size_t)nl + s]);
         __syncthreads();
     };
 
@@ -866,7 +905,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                 const int s = s0 + u * kRsBlock;
                 if (s >= nlp) break; // (uniform per wave: s0 is 64-aligned per wave)
                 live[s] = (unsigned short)lvv[u];
-                P[s] = (double)v[u][0]; P[nlp + s] = (double)v[u][1]; P[2 * nlp + s] = (double)v[u][2];
+                store_pos(s >> 6, s, (double)v[u][0], (double)v[u][1], (double)v[u][2]);
                 unsigned um = lvv[u] & 0xFFFu;
                 int cm = __popc(um);
                 for (int o = 32; o > 0; o >>= 1) { um |= __shfl_xor(um, o); cm = max(cm, __shfl_xor(cm, o)); }
@@ -937,7 +976,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
             for (int i = 1; i < 6; ++i) thv[i] = thv[i - 1] * 2;
             double* chi2 = (ra.want_chi2 && a.chi2) ? a.chi2 + e0 : nullptr;
             if (chi2) { for (int e = tid; e < ne; e += kRsBlock) chi2[e] = 0.0; __syncthreads(); }
-            float2 zn[kRsSlotsReg];
+            Pref zn;
             uv_issue(wave, zn);
             for (int j = 0; wave + kRsWaves * j < nrows; ++j) {
                 const int r = wave + kRsWaves * j;
@@ -1226,7 +1265,10 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
             for (int s = tid; s < nl; s += kRsBlock)
                 if (live[s] & 0xFFFu) {
                     const int l = perm[s];
-                    const double vx = p_is_trial ? Pbak[s] : P[s], vy = p_is_trial ? Pbak[nl + s] : P[nlp + s], vz = p_is_trial ? Pbak[2 * (size_t)nl + s] : P[2 * nlp + s];
+                    double vx, vy, vz; // (the accepted state: the backup while a rejected trial sits in the working arrays)
+                    if (p_is_trial) { vx = Pbak[s]; vy = Pbak[nl + s]; vz = Pbak[2 * (size_t)nl + s]; }
+                    else if (s < sl0) { vx = Pw[s]; vy = Pw[nl + s]; vz = Pw[2 * (size_t)nl + s]; }
+                    else { vx = P[s - sl0]; vy = P[nlpL + s - sl0]; vz = P[2 * nlpL + s - sl0]; }
                     a.xyz[3 * ((size_t)lm0 + l)] = (float)vx; a.xyz[3 * ((size_t)lm0 + l) + 1] = (float)vy; a.xyz[3 * ((size_t)lm0 + l) + 2] = (float)vz;
                 }
         }
@@ -1259,6 +1301,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
 int rs_dyn_lds_bytes(int device) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || v <= 0) v = 64 * 1024;
+    v /= 2; // two windows (workgroups of four waves at 256 VGPRs) share a CU: half of its LDS each
     const int avail = v - (int)sizeof(RsShared) - 256;
     return avail > 0 ? (avail & ~255) : 0;
 }
