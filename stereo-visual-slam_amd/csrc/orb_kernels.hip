@@ -1038,23 +1038,62 @@ __global__ __launch_bounds__(kOrientThreads) void orb_orient_kernel(LevelTable T
     __syncthreads();
     const int wave_first = grp - ((threadIdx.x >> 4) & 3); // first group of this wave: the trip count must be uniform per wave (shuffles)
     const int32_t* order = d_order ? d_order + (size_t)b * kp_capacity : nullptr;
-    int trip = 0;
-    for (int j0 = wave_first; j0 < n; j0 += ngrp, ++trip) {
-        const int i = j0 + ((threadIdx.x >> 4) & 3); // position in the walk; j: the output slot it refers to
-        const bool valid = i < n;
-        const int j = valid ? (order ? min(max(order[i], 0), n - 1) : i) : 0;
-        const vslam_keypoint kp = kps[j];
-        const int l = min(max(kp.octave, 0), kNLevels - 1);
-        const LevelView V = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
-        const float inv_scale = __fdiv_rn(1.f, T.scale[l]);
-        const int x = __float2int_rn(__fmul_rn(kp.x, inv_scale)), y = __float2int_rn(__fmul_rn(kp.y, inv_scale));
-        // (keypoints come from the detector: >= 31 px from the level border, so the 31 x 31 patch is inside the level)
-        const bool ok = valid && x >= 15 && y >= 15 && x + 16 <= V.w && y + 15 < V.h;
-        const float ang = ic_angle_group16(V, x, y, ok, icw);
-        if (valid && (threadIdx.x & 15) == 0) {
-            kps[j].angle = ang;
-            const int slot = trip * (kOrientThreads >> 4) + (threadIdx.x >> 4);
-            s_ang[slot] = ang; s_j[slot] = j;
+    // [r5] Two trips of the walk per loop turn, stage by stage: both walk indices, then both keypoint records, then both patches are in flight
+    // together.  A trip is three DEPENDENT round trips (order -> record -> patch) for ~80 instructions of arithmetic; with one trip at a time
+    // the waves of this kernel issued instructions 6 % of the time (SQ counters: active 5.8 %, VALU 3.8 % of the wave cycles at full occupancy).
+    const IcRowWeights& w = icw;
+    const int v16 = threadIdx.x & 15, sub = (threadIdx.x >> 4) & 3;
+    for (int j0 = wave_first, trip = 0; j0 < n; j0 += 2 * ngrp, trip += 2) {
+        int iv[2], jv[2]; bool val[2], okv[2]; int xv[2], yv[2];
+        LevelView Vv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { iv[u] = j0 + u * ngrp + sub; val[u] = iv[u] < n; } // position in the walk; j: the output slot it refers to
+#pragma unroll
+        for (int u = 0; u < 2; ++u) jv[u] = val[u] ? (order ? order[iv[u]] : iv[u]) : 0;
+        vslam_keypoint kpv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { jv[u] = min(max(jv[u], 0), n - 1); kpv[u] = kps[jv[u]]; }
+        uint32_t wp[2][8], wm[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int l = min(max(kpv[u].octave, 0), kNLevels - 1);
+            Vv[u] = level_view(T, l, d_imgs + (size_t)b * img_bytes, pitch0, d_pyr + (size_t)b * pyr_bytes);
+            const float inv_scale = __fdiv_rn(1.f, T.scale[l]);
+            xv[u] = __float2int_rn(__fmul_rn(kpv[u].x, inv_scale)); yv[u] = __float2int_rn(__fmul_rn(kpv[u].y, inv_scale));
+            // (keypoints come from the detector: >= 31 px from the level border, so the 31 x 31 patch is inside the level)
+            okv[u] = val[u] && xv[u] >= 15 && yv[u] >= 15 && xv[u] + 16 <= Vv[u].w && yv[u] + 15 < Vv[u].h;
+            const int xs = okv[u] ? xv[u] : 15, ys = okv[u] ? yv[u] : 15; // (a lane without a patch reads the level's first patch: its sums are dropped)
+            const uint8_t* cp = Vv[u].ptr + (size_t)(ys + (okv[u] ? v16 : 0)) * Vv[u].pitch + xs - 15;
+            const uint8_t* cm = Vv[u].ptr + (size_t)(ys - (okv[u] ? v16 : 0)) * Vv[u].pitch + xs - 15;
+            // two unaligned 16-B loads per row: every lane reads its own row, so the cost is cache lines touched per instruction
+            __builtin_memcpy(&wp[u][0], cp, 16); __builtin_memcpy(&wp[u][4], cp + 16, 16);
+            __builtin_memcpy(&wm[u][0], cm, 16); __builtin_memcpy(&wm[u][4], cm + 16, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (j0 + u * ngrp >= n) break; // (uniform per wave: the whole second trip lies beyond the walk)
+            int m10 = 0, vsum = 0;
+            if (okv[u]) {
+                uint32_t sp = 0, smn = 0, tp = 0, tm = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    sp = __builtin_amdgcn_udot4(wp[u][q], w.wmask[q], sp, false);
+                    smn = __builtin_amdgcn_udot4(wm[u][q], w.wmask[q], smn, false);
+                    tp = __builtin_amdgcn_udot4(wp[u][q], w.wt[q], tp, false);
+                    tm = __builtin_amdgcn_udot4(wm[u][q], w.wt[q], tm, false);
+                }
+                vsum = (int)sp - (int)smn;
+                m10 = (int)(tp + tm) - 15 * (int)(sp + smn); // row 0: both windows are the same row, halved below
+                if (v16 == 0) m10 >>= 1; // exact: m10 = 2 * sum(u * I) on the centre row
+            }
+            int m01 = v16 * vsum;
+            for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+            const float ang = fast_atan2_dev((float)m01, (float)m10);
+            if (val[u] && v16 == 0) {
+                kps[jv[u]].angle = ang;
+                const int slot = (trip + u) * (kOrientThreads >> 4) + (threadIdx.x >> 4);
+                s_ang[slot] = ang; s_j[slot] = jv[u];
+            }
         }
     }
     __syncthreads();
