@@ -707,8 +707,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is repeated this many times; the median is reported")
-    ap.add_argument("--batch", type=int, default=512, help="stereo keyframes per GPU per step (two BA windows per CU one after the other: 39.5 k keyframes/s against "
-                                                            "37.5 k at 256, 34.5 k at 384, 40.3 k at 1024 -- profiles/r04_batch_sweep.json)")
+    ap.add_argument("--batch", type=int, default=1024, help="stereo keyframes per GPU per step.  Round 5: 1024 (two rounds of two BA windows per CU: the windows of a round finish at "
+                                                             "different times and the next round fills the tail): 56.2 k keyframes/s against 53.1 k at 512, 55.7 k at 768, 56.6 k at 2048 with two "
+                                                             "batches in flight (profiles/r05_experiments.log); rounds 1-4 ran 256 / 512")
     ap.add_argument("--in-flight", type=int, default=2, metavar="P",
                     help="batches in flight per GPU: P pipelines (context + HIP stream + buffers each), step k goes to pipeline k mod P without waiting for "
                          "step k - 1 (pipeline.PipelineRing): 41.6 k keyframes/s at 2 x 512 against 38.6 k at 1 x 512; per-kernel durations and the roofline "

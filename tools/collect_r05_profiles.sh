@@ -1,11 +1,11 @@
 #!/bin/bash
 # Copies the summaries tools/profile_r05.sh left under gpurun_out/prof_r05_<cfg>/ into profiles/ (the tracked evidence):
-#   tracks -> r05_bench_b512_*, config4 -> r05_ba_config4_b256_*, sgbm -> r05_reference_pipeline_b256_*; counter JSONs -> profiles/{traffic*.json,orb_valu.json}
+#   tracks -> r05_bench_b1024_*, config4 -> r05_ba_config4_b256_*, sgbm -> r05_reference_pipeline_b256_*; counter JSONs -> profiles/{traffic*.json,orb_valu.json}
 set -eu
 cd "$(dirname "$0")/.."
 for CFG in ${@:-tracks config4 sgbm}; do
   case $CFG in
-    tracks)  NAME=r05_bench_b512;               TJ=traffic_tracks.json;;
+    tracks)  NAME=r05_bench_b1024;              TJ=traffic_tracks.json;;
     config4) NAME=r05_ba_config4_b256;          TJ=traffic.json;;
     sgbm)    NAME=r05_reference_pipeline_b256;  TJ=traffic_sgbm.json;;
   esac

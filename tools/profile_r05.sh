@@ -9,7 +9,7 @@ STEPS=3
 COMMON="--steps $STEPS --warmup 1 --repeats 1 --in-flight 1 --no-plain-schedule --no-cpu-baseline --no-config4 --no-reference-pipeline --no-config4-step --no-live-dropin --render-workers 0 --unique-frames 128 --inputs resident"
 for CFG in ${@:-tracks config4 sgbm}; do
   case $CFG in
-    tracks)  ARGS="$COMMON";                                   BATCH=512;;
+    tracks)  ARGS="$COMMON";                                   BATCH=1024;;
     config4) ARGS="$COMMON --ba-windows synthetic --batch 256"; BATCH=256;;
     sgbm)    ARGS="$COMMON --depth sgbm --pose ransac --batch 256"; BATCH=256;;
   esac
@@ -55,7 +55,7 @@ root = os.environ.get("GRAFT_REPO_ROOT", ".")
 p = os.path.join(root, "gpurun_out", "prof_r05_tracks", "sq_summary.txt")
 if os.path.exists(p):
     per = {}
-    n_img = 1024 * 7   # 2 x 512 images per step, 7 steps in the profiled command
+    n_img = 2048 * 7   # 2 x 1024 images per step, 7 steps in the profiled command
     for line in open(p):
         name = line.split()[0]
         m = re.search(r"valu_insts ([0-9.e+]+)", line)
