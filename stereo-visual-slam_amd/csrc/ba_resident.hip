@@ -5,8 +5,10 @@
 // walks it with one dependent round trip per phase; at two waves per SIMD nothing hides those trips, and on the windows a real sequence
 // produces (3.5 k landmarks, 4.6 k edges) an LM iteration took ~280 k cycles for ~40 k cycles of arithmetic.  This kernel turns the
 // design around:
-//   * the landmark positions (f64, 24 B each) live in LDS for the whole schedule; the only per-iteration global traffic is the read-only
-//     observation table (8 B per edge, slot-major, coalesced, L2-resident across iterations) and one fire-and-forget backup of the
+//   * the landmark positions (f64, 24 B each) live in LDS for the whole schedule -- [r5] those of every multi-observation row and of as many
+//     single-observation rows as half a CU's LDS holds (two windows share a CU, see kRsBlock); the other singles rows, visited once per pass
+//     and in order, keep their working positions in a global array requested a row ahead; the other per-iteration global traffic is the
+//     read-only observation table (8 B per edge, slot-major, coalesced, L2-resident across iterations) and one fire-and-forget backup of the
 //     accepted positions per accepted step.  Nothing else is stored: no H_ll, b_l, D^-1, Huber weights, keyframe-major copies, hit lists.
 //   * landmarks are SORTED by (observation count descending, keyframe set): a row of 64 consecutive landmarks then sees (almost always)
 //     one keyframe set, so "which keyframe is observation q" is wave-uniform and ONE landmark-wise pass does everything the old kernel
@@ -18,7 +20,7 @@
 //   * the back-substitution re-derives D^-1 and b_l from the landmark's own observations, updates the position IN PLACE in LDS and
 //     evaluates the trial cost in the same visit; a rejected step restores the positions from the backup (rare).
 // Reduced system: blocked right-looking Cholesky as in lm_kernels.hip, on a block-packed lower triangle (nk (nk + 1) / 2 blocks of 36).
-// Windows that do not fit (landmarks x 26 B + blocks beyond the LDS budget, > 6144 landmarks) are marked deferred and taken by
+// Windows that do not fit (multi-observation rows x 1536 B + 2 B per landmark + blocks beyond the LDS budget, > 5120 landmarks) are marked deferred and taken by
 // lm_window_kernel in the same launch set.  Same LM rules (g2o Levenberg, Huber 5.991, <= 10 trials), same chi2 classification, same
 // statistics as lm_kernels.hip; sums differ from it in rounding only.
 #include "vslam_internal.h"
