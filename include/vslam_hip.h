@@ -341,7 +341,8 @@ int vslam_ba_schedule_passes_dev(vslam_ctx* ctx, int n_windows, int32_t* h_passe
 int vslam_edge_jacobians(vslam_ctx* ctx, int n, const float* xyz_w, const float* uv, const double T_c_w[7], const double* K4,
                          double* err, double* J_pose, double* J_point, double* chi2, double* huber_w);
 /* Kernel-choice overrides of a context (tuning aid, and how the tests force every kernel path): name in {"orb_fuse_min", "sgbm_fuse_min",
- * "sgbm_fwd_min" (items per call from which the fused kernel is used), "sgbm_fw_rows" (32 | 64), "pose_only_window", "pnp_window", "ba_adaptive" (0 | 1)};
+ * "sgbm_fwd_min" (items per call from which the fused kernel is used), "sgbm_fw_rows" (32 | 64), "pose_only_window", "pnp_window", "ba_adaptive" (0 | 1), "ba_lanes" (256 | 512: lanes per window of the
+ * LDS-resident optimize_map kernel; default by the number of windows in the call; the results do not depend on it)};
  * value -1 = the library's batch-size rule.  vslam_create seeds them once from the environment variables VSLAM_<NAME> (an unparsable
  * or out-of-range value makes vslam_create fail with VSLAM_ERR_ARG); nothing reads the environment afterwards. */
 int vslam_set_tuning(vslam_ctx* ctx, const char* name, int value);

@@ -112,10 +112,11 @@ static const TuneKey kTuneKeys[] = {
     {"ba_resident", "VSLAM_BA_RESIDENT", &Tuning::ba_resident, 0, 1},
     {"pnp_window", "VSLAM_PNP_WINDOW", &Tuning::pnp_window, 0, 1},
     {"ba_adaptive", "VSLAM_BA_ADAPTIVE", &Tuning::ba_adaptive, 0, 1},
+    {"ba_lanes", "VSLAM_BA_LANES", &Tuning::ba_lanes, 256, 512},
 };
 static int tune_set(Tuning& t, const TuneKey& k, long v) {
     if (v == -1) { t.*(k.field) = -1; return VSLAM_OK; } // back to the library's rule
-    if (v < k.lo || v > k.hi || (k.field == &Tuning::sgbm_fw_rows && v != 32 && v != 64)) {
+    if (v < k.lo || v > k.hi || (k.field == &Tuning::sgbm_fw_rows && v != 32 && v != 64) || (k.field == &Tuning::ba_lanes && v != 256 && v != 512)) {
         set_error("tuning value %s = %ld out of range (%d..%d%s, or -1 = default)", k.name, v, k.lo, k.hi, k.field == &Tuning::sgbm_fw_rows ? ", 32 or 64" : "");
         return VSLAM_ERR_ARG;
     }

@@ -37,14 +37,16 @@ namespace vslam {
 // for 23 % of the time, barriers, exposed round trips) idled the other waves.  Two windows of four waves each use the same registers and fill each
 // other's gaps: 2.27 -> 1.82 ms per 512 small windows in the experiment that led here (profiles/r05_experiments.log).  What made a window fit half
 // the LDS: the positions of the SINGLES rows (87 % of the landmarks) live in global memory (L2), see `rl0` below.
-#ifndef VSLAM_RS_BLOCK
-#define VSLAM_RS_BLOCK 256
-#endif
-constexpr int kRsBlock = VSLAM_RS_BLOCK;
-constexpr int kRsWaves = kRsBlock / 64;
+// Two widths of the same kernel (template parameter BLOCK): 256 lanes and half a CU's LDS per window -- two windows per CU, the throughput form,
+// used when a launch has more windows than the device has CUs -- and 512 lanes with a whole CU's LDS for small launches, where a window's LATENCY
+// is what counts (a 50-frame sequence pass, a host-tier call).  Both give the same bits: every floating-point sum that crosses waves is
+// taken over EIGHT row streams (row r belongs to stream r mod 8; a wave of the narrow form carries two of them), everything else that crosses
+// waves is an integer sum or a maximum.  tests/test_gpu_ba_resident.py::test_both_widths_bit_identical.
+constexpr int kRsStreams = 8;
+constexpr int kRsWavesMax = 8;
 constexpr int kRsKf = VSLAM_MAX_KF;
 constexpr int kRsNp = 6 * kRsKf;
-constexpr int kRsMaxRows = 20 * kRsWaves;      // 64-landmark rows per window (5120 landmarks with four waves: the classification keeps six bits per row slot in two 64-bit words per lane)
+constexpr int kRsMaxRowsMax = 20 * kRsWavesMax; // 64-landmark rows per window: 20 per wave (the classification keeps six bits per row slot in two 64-bit words per lane): 5120 / 10240 landmarks
 constexpr int kRsSlotsReg = 6;                 // observations per landmark preloaded into registers (the rest is fetched where it is used)
 constexpr int kRsSchedFinalIters = 10;         // run_vslam.cpp:66
 constexpr int kRsSortCap = 8192;               // keys of the in-kernel landmark sort (power of two >= landmarks)
@@ -61,13 +63,13 @@ struct alignas(16) RsShared {
     double bp[kRsNp], bs[kRsNp], xp[kRsNp], rdiag[kRsNp];
     double Ld[kRsKf * 24];
     long long bpq[kRsNp], bsq[kRsNp], hdq[kRsNp]; // fixed-point accumulators: pose gradient, reduced right-hand side, diag(H_pp)
-    double red[kRsWaves * 2];
-    int redi[kRsWaves * 8];
+    double red[kRsStreams * 2];
+    int redi[kRsWavesMax * 8];
     int slotoff[kRsKf + 2];                       // observation slot q of sorted landmark s sits at entry slotoff[q] + s of the slot-major tables (may be negative: slot q starts at landmark nl - n_q)
     int nq[kRsKf + 2];
     int flag[16];
-    unsigned short rowU[kRsMaxRows];              // union of the keyframe sets of a row's live landmarks
-    unsigned char rowC[kRsMaxRows];               // most observations of a live landmark in the row
+    unsigned short rowU[kRsMaxRowsMax];           // union of the keyframe sets of a row's live landmarks
+    unsigned char rowC[kRsMaxRowsMax];            // most observations of a live landmark in the row
     int pairoff[kRsPairs + 2];                    // first hit of keyframe pair p (k1 <= k2, diagonal pairs included) in the LDS hit list
     int itemoff[kRsPairs + 2];                    // first work item (chunk of kRsHitChunk hit rows) of pair p
     unsigned char pk1[kRsPairs + 2], pk2[kRsPairs + 2];
@@ -90,6 +92,7 @@ struct RsArgs {
     const int32_t* order;
     long long* dbg;
     int dyn_bytes;
+    int dyn_narrow;        // the dynamic LDS of the 256-lane form: WHICH windows the kernel takes and on which path (hit-major / row-wise) is decided against it in both widths, so that a window's bits do not depend on the width
     int want_chi2;
     int dense_to_general;  // 1: windows with more than 2.2 observations per landmark are left to lm_window_kernel (Tuning::ba_resident = 1 forces them here)
 };
@@ -99,8 +102,10 @@ __device__ inline long long to_fixed(double v, double scale) { return __double2l
 // lower block (I >= K) of the packed reduced system
 __device__ inline int rs_blk(int I, int K) { return (I * (I + 1) / 2 + K) * 36; }
 
-template <bool SCHED>
-__global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kernel(RsArgs ra, int iters, int update_poses, int update_lms, int classify, int adaptive) {
+template <bool SCHED, int BLOCK>
+__global__ __launch_bounds__(BLOCK, VSLAM_RS_MIN_WAVES) void ba_resident_kernel(RsArgs ra, int iters, int update_poses, int update_lms, int classify, int adaptive) {
+    constexpr int kRsBlock = BLOCK, kRsWaves = BLOCK / 64, kRsMaxRows = 20 * kRsWaves;
+    constexpr int kRsSub = kRsStreams / kRsWaves; // row streams a wave carries (1 or 2)
     const LmWindowArgs& a = ra.a;
     extern __shared__ __align__(16) unsigned char dyn[];
     __shared__ RsShared sm;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
         // (dense graphs -- more than ~2.2 observations per landmark, e.g. the synthetic config-4 windows at 3.5 -- stay on lm_window_kernel: their
         // Schur work is hits, not landmarks, and its stored hit lists / weights win there: 3.78 vs 4.3 ms per 256 such windows)
         const bool dense = ra.dense_to_general && 5 * (long long)ne > 11 * (long long)nl;
-        if (dense || nl <= 0 || ne <= 0 || nrows > kRsMaxRows || n2 > kRsSortCap || need_run > (size_t)ra.dyn_bytes || need_setup > (size_t)ra.dyn_bytes) {
+        if (dense || nl <= 0 || ne <= 0 || nrows > 20 * (256 / 64) || n2 > kRsSortCap || need_run > (size_t)ra.dyn_narrow || need_setup > (size_t)ra.dyn_narrow) { // (the narrow form's limits, in both widths)
             if (tid == 0) ra.defer[w] = 1;
             return;
         }
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     double* Dc = ra.Dc + 6 * (size_t)lm0;
     double* blc = ra.blc + 3 * (size_t)lm0;
     unsigned short* hit = nullptr; // sorted landmark per Schur hit, pair-major (set with rl0)
-    int hit_cap = 0;
+    int hit_cap = 0, hit_cap_narrow = 0;
     double* Pw = ra.tab + 6 * (size_t)lm0 + nl; // (the window's slice of `tab` is 6 nl doubles; perm / mstat take the first 4 nl bytes)
     const double K[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
     const CamK ck = make_camk(K);
@@ -159,15 +164,22 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     long long t_ph = cyc ? clock64() : 0;
 #define RPH(i) do { if (cyc && tid == 0) { const long long t1__ = clock64(); atomicAdd(reinterpret_cast<unsigned long long*>(cyc) + (i), (unsigned long long)(t1__ - t_ph)); t_ph = t1__; } } while (0)
 
-    auto block_sum2 = [&](double& v0, double& v1) { // deterministic: wave butterflies, waves in order
-        v0 = wave_sum(v0); v1 = wave_sum(v1);
+    // sum over the block of two per-lane values kept per row stream (v0[u], v1[u]: this wave's stream u = row stream wave + kRsWaves u):
+    // deterministic and the same for both widths -- a butterfly per stream, the eight streams in order
+    auto block_sum2 = [&](double (&v0)[kRsSub], double (&v1)[kRsSub], double& o0, double& o1) {
+#pragma unroll
+        for (int u = 0; u < kRsSub; ++u) { v0[u] = wave_sum(v0[u]); v1[u] = wave_sum(v1[u]); }
         __syncthreads();
-        if (lane == 0) { sm.red[2 * wave] = v0; sm.red[2 * wave + 1] = v1; }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < kRsSub; ++u) { sm.red[2 * (wave + kRsWaves * u)] = v0[u]; sm.red[2 * (wave + kRsWaves * u) + 1] = v1[u]; }
+        }
         __syncthreads();
         double s0 = 0, s1 = 0;
-        for (int ww = 0; ww < kRsWaves; ++ww) { s0 += sm.red[2 * ww]; s1 += sm.red[2 * ww + 1]; }
-        v0 = s0; v1 = s1;
+        for (int ww = 0; ww < kRsStreams; ++ww) { s0 += sm.red[2 * ww]; s1 += sm.red[2 * ww + 1]; }
+        o0 = s0; o1 = s1;
     };
+    auto stream_of = [&](int r) -> int { return (r / kRsWaves) % kRsSub; }; // which of this wave's streams row r (r mod kRsWaves == wave) belongs to (uniform)
     auto block_max1 = [&](double v) -> double {
         v = wave_max(v);
         __syncthreads();
@@ -308,13 +320,19 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
         long long hits = 0;
         for (int c = 2; c <= kRsKf; ++c) hits += (long long)(sm.nq[c - 1] - (c < kRsKf ? sm.nq[c] : 0)) * (c * (c + 1) / 2);
         const long long hit_bytes = min((2 * hits + 127) & ~63ll, (long long)kRsHitReserveMax);
-        int rows_lds = (int)max(((long long)ra.dyn_bytes - fixed - hit_bytes) / (64 * 24), 0ll);
-        if (nrows - rows_lds > rm_static) rows_lds = (int)max(((long long)ra.dyn_bytes - fixed) / (64 * 24), 0ll); // (give up the hit lists -- the row-wise pair path -- before the window)
-        rl0 = max(nrows - rows_lds, 0);
-        if (rl0 > rm_static) { // the multi-observation rows alone exceed the LDS: lm_window_kernel takes the window
+        // decisions (take the window? hit lists?) against the NARROW form's LDS, the layout against this width's
+        auto rows_for = [&](long long dynb, bool with_hits) -> int { return (int)max((dynb - fixed - (with_hits ? hit_bytes : 0)) / (64 * 24), 0ll); };
+        int rows_n = rows_for(ra.dyn_narrow, true);
+        if (nrows - rows_n > rm_static) rows_n = rows_for(ra.dyn_narrow, false); // (give up the hit lists -- the row-wise pair path -- before the window)
+        const int rl0n = max(nrows - rows_n, 0);
+        if (rl0n > rm_static) { // the multi-observation rows alone exceed the LDS: lm_window_kernel takes the window
             if (tid == 0) ra.defer[w] = 1;
             return;
         }
+        hit_cap_narrow = (int)min(((long long)ra.dyn_narrow - (fixed + (long long)(nlp - 64 * rl0n) * 24)) / 2, (long long)0x7FFFFFF);
+        int rows_lds = rows_for(ra.dyn_bytes, true);
+        if (nrows - rows_lds > rm_static) rows_lds = rows_for(ra.dyn_bytes, false);
+        rl0 = min(max(nrows - rows_lds, 0), rl0n);
         sl0 = 64 * rl0; nlpL = nlp - sl0;
         live = reinterpret_cast<unsigned short*>(dyn + (size_t)nblk * 288 + (size_t)nlpL * 24);
         hit = live + nlp;
@@ -381,12 +399,16 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
 
     // ---- evaluation at (Rsel, positions in LDS): robust cost and the fixed-point bound.  Static rows (row r -> wave r mod 8): fixed order.
     auto chi_pass = [&](const double* Rsel, double& bound_out) -> double {
-        double part = 0, bpart = 0;
+        double part[kRsSub], bpart[kRsSub];
+#pragma unroll
+        for (int u = 0; u < kRsSub; ++u) { part[u] = 0; bpart[u] = 0; }
         Pref zn;
         uv_issue(wave, zn);
         for (int r = wave; r < nrows; r += kRsWaves) {
             Row R; row_open(r, zn, R);
             uv_issue(r + kRsWaves, zn);
+            const int su = stream_of(r);
+            double prow = 0, brow = 0;
             // (every lane walks ITS OWN observations, q-th with q-th: a row of mixed keyframe sets costs its longest track, not the size of the union)
             unsigned mm = R.m;
             for (int q = 0; q < R.rc; ++q) {
@@ -396,14 +418,16 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                     double x, y, rho, enx, eny, c, rob, wg;
                     cam_norm(&Rsel[12 * k], R.px, R.py, R.pz, x, y, rho);
                     eval_obs(ck, x, y, z, delta, enx, eny, c, rob, wg);
-                    part += rob;
-                    bpart += obs_bound(x, y, rho, wg * c);
+                    prow += rob;
+                    brow += obs_bound(x, y, rho, wg * c);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < kRsSub; ++u) if (u == su) { part[u] += prow; bpart[u] += brow; }
         }
-        block_sum2(part, bpart);
-        bound_out = bpart;
-        return part;
+        double tot = 0;
+        block_sum2(part, bpart, tot, bound_out);
+        return tot;
     };
 
     // ---- one landmark-wise pass builds the whole reduced system at (sm.Rt, positions in LDS) for the given lambda.  Work items, drawn from an
@@ -764,7 +788,9 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
     // ---- back-substitution + trial evaluation in one visit: D^-1, b_l re-derived at the accepted state (sm.Rt, LDS positions), the
     // position moved IN PLACE, the robust cost and the bound at the trial state (sm.RtT).  Static rows.
     auto backsub_pass = [&](double lambda, bool backup, double& scale_out, double& bound_out) -> double {
-        double part = 0, bpart = 0, spart = 0;
+        double part[kRsSub], bpart[kRsSub], spart[kRsSub], zero_[kRsSub];
+#pragma unroll
+        for (int u = 0; u < kRsSub; ++u) { part[u] = 0; bpart[u] = 0; spart[u] = 0; zero_[u] = 0; }
         const int rm0 = sm.flag[8];
         Pref zn;
         uv_issue(wave, zn);
@@ -772,6 +798,12 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
             Row R; row_open(r, zn, R);
             uv_issue(r + kRsWaves, zn);
             if (R.U == 0) continue;
+            const int su = stream_of(r);
+            double prow = 0, brow = 0, srow = 0;
+            auto fold_row = [&]() {
+#pragma unroll
+                for (int u = 0; u < kRsSub; ++u) if (u == su) { part[u] += prow; bpart[u] += brow; spart[u] += srow; }
+            };
             const bool on = R.m != 0;
             if (backup && R.s < nl) { Pbak[R.s] = R.px; Pbak[nl + R.s] = R.py; Pbak[2 * (size_t)nl + R.s] = R.pz; }
             if (r < rm0) { // singles row
@@ -798,15 +830,16 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                     for (int i = 0; i < 3; ++i) {
                         dx[i] = -(B[i] * m0 + B[3 + i] * m1);
                         const double bl = -(B[i] * l0e + B[3 + i] * l1e);
-                        spart += dx[i] * (lambda * dx[i] + bl);
+                        srow += dx[i] * (lambda * dx[i] + bl);
                     }
                     R.px += dx[0]; R.py += dx[1]; R.pz += dx[2];
                     store_pos(r, R.s, R.px, R.py, R.pz);
                     cam_norm(&sm.RtT[12 * k], R.px, R.py, R.pz, x, y, rho);
                     eval_obs(ck, x, y, R.z[0], delta, enx, eny, c, rob, wg);
-                    part += rob;
-                    bpart += obs_bound(x, y, rho, wg * c);
+                    prow += rob;
+                    brow += obs_bound(x, y, rho, wg * c);
                 }
+                fold_row();
                 continue;
             }
             double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, cacc[3] = {0, 0, 0};
@@ -846,7 +879,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                 const double x0 = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
                 const double x1 = Di[1] * c0 + Di[3] * c1 + Di[4] * c2;
                 const double x2 = Di[2] * c0 + Di[4] * c1 + Di[5] * c2;
-                spart += x0 * (lambda * x0 + g[0]) + x1 * (lambda * x1 + g[1]) + x2 * (lambda * x2 + g[2]);
+                srow += x0 * (lambda * x0 + g[0]) + x1 * (lambda * x1 + g[1]) + x2 * (lambda * x2 + g[2]);
                 R.px += x0; R.py += x1; R.pz += x2;
                 store_pos(r, R.s, R.px, R.py, R.pz);
             }
@@ -859,19 +892,19 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                         double x, y, rho, enx, eny, c, rob, wg;
                         cam_norm(&sm.RtT[12 * k], R.px, R.py, R.pz, x, y, rho);
                         eval_obs(ck, x, y, z, delta, enx, eny, c, rob, wg);
-                        part += rob;
-                        bpart += obs_bound(x, y, rho, wg * c);
+                        prow += rob;
+                        brow += obs_bound(x, y, rho, wg * c);
                     }
                 }
             }
+            fold_row();
         }
-        if (tid < np) spart += sm.xp[tid] * (lambda * sm.xp[tid] + sm.bp[tid]);
-        block_sum2(part, bpart);
-        double dummy = 0;
-        block_sum2(spart, dummy);
-        scale_out = spart + 1e-3;
-        bound_out = bpart;
-        return part;
+        if (tid < np) spart[0] += sm.xp[tid] * (lambda * sm.xp[tid] + sm.bp[tid]); // (lanes of wave 0: row stream 0 in both widths)
+        double tot = 0, stot = 0, dummy = 0;
+        block_sum2(part, bpart, tot, bound_out);
+        block_sum2(spart, zero_, stot, dummy);
+        scale_out = stot + 1e-3;
+        return tot;
     };
     auto restore_positions = [&]() {
         for (int s = tid; s < nl; s += kRsBlock) store_pos(s >> 6, s, Pbak[s], Pbak[nl + s], Pbak[2 * (size_t)nl + s]);
@@ -957,7 +990,7 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
                             sm.itemoff[p + 1] = items;
                         }
                         sm.pairoff[npairs] = acc;
-                        sm.flag[9] = (rm0 < nrows && acc > 0 && acc <= hit_cap && items <= kRsHitItems) ? 1 : 0;
+                        sm.flag[9] = (rm0 < nrows && acc > 0 && acc <= min(hit_cap, hit_cap_narrow) && items <= kRsHitItems) ? 1 : 0; // (the narrow form's capacity decides in both widths)
                     }
                     __syncthreads();
                 }
@@ -1300,11 +1333,14 @@ __global__ __launch_bounds__(kRsBlock, VSLAM_RS_MIN_WAVES) void ba_resident_kern
 }
 
 // ------------------------------------------------------------------------------------------------------------- launcher
-int rs_dyn_lds_bytes(int device) {
+static int rs_lds_per_cu(int device) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || v <= 0) v = 64 * 1024;
-    v /= 2; // two windows (workgroups of four waves at 256 VGPRs) share a CU: half of its LDS each
-    const int avail = v - (int)sizeof(RsShared) - 256;
+    return v;
+}
+// dynamic LDS of the narrow form: two windows (workgroups of four waves at 256 VGPRs) share a CU, half of its LDS each
+int rs_dyn_lds_bytes(int device) {
+    const int avail = rs_lds_per_cu(device) / 2 - (int)sizeof(RsShared) - 256;
     return avail > 0 ? (avail & ~255) : 0;
 }
 
@@ -1314,13 +1350,36 @@ int launch_ba_resident(const RsLaunch& L, hipStream_t stream) {
     ra.a = L.a;
     ra.uv_s = reinterpret_cast<float2*>(L.uv_s); ra.epos = L.epos; ra.tab = L.tab; ra.xin = L.xin; ra.Pbak = L.Pbak; ra.Dc = L.Dc; ra.blc = L.blc;
     ra.status = L.status; ra.passes = L.passes; ra.defer = L.defer; ra.order = L.order; ra.dbg = L.dbg;
-    ra.dyn_bytes = L.dyn_bytes; ra.want_chi2 = L.a.chi2 != nullptr; ra.dense_to_general = L.dense_to_general;
-    if (!L.opt_in_done) { // more than 64 KB of dynamic LDS needs the opt-in (once per context, i.e. per device)
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, L.dyn_bytes));
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, L.dyn_bytes));
+    ra.want_chi2 = L.a.chi2 != nullptr; ra.dense_to_general = L.dense_to_general;
+    // width: more windows than CUs -> 256 lanes, two windows per CU (throughput); otherwise 512 lanes and the whole CU's LDS (a window's latency).
+    // Both widths give the same bits (see kRsStreams), so the choice may depend on the launch.
+    static int s_cus[16] = {0}, s_full[16] = {0};
+    int dev = 0;
+    VS_HIP(hipGetDevice(&dev));
+    const int di = dev >= 0 && dev < 16 ? dev : 0;
+    if (!s_cus[di]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        const int full = rs_lds_per_cu(dev) - (int)sizeof(RsShared) - 256;
+        s_full[di] = full > 0 ? (full & ~255) : 0;
+        s_cus[di] = n;
     }
-    if (L.schedule) hipLaunchKernelGGL((ba_resident_kernel<true>), dim3(L.a.n_windows), dim3(kRsBlock), (size_t)L.dyn_bytes, stream, ra, 5, 0, 0, 1, L.adaptive);
-    else hipLaunchKernelGGL((ba_resident_kernel<false>), dim3(L.a.n_windows), dim3(kRsBlock), (size_t)L.dyn_bytes, stream, ra, L.iters, L.update_poses, L.update_lms, 1, 0);
+    const int lanes = L.lanes == 256 || L.lanes == 512 ? L.lanes : (L.a.n_windows <= s_cus[di] ? 512 : 256);
+    const int dyn = lanes == 512 ? s_full[di] : L.dyn_bytes;
+    ra.dyn_bytes = dyn; ra.dyn_narrow = L.dyn_bytes;
+    if (!L.opt_in_done) { // more than 64 KB of dynamic LDS needs the opt-in (once per context, i.e. per device)
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_resident_kernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, L.dyn_bytes));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_resident_kernel<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, L.dyn_bytes));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_resident_kernel<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, s_full[di]));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_resident_kernel<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, s_full[di]));
+    }
+    if (lanes == 512) {
+        if (L.schedule) hipLaunchKernelGGL((ba_resident_kernel<true, 512>), dim3(L.a.n_windows), dim3(512), (size_t)dyn, stream, ra, 5, 0, 0, 1, L.adaptive);
+        else hipLaunchKernelGGL((ba_resident_kernel<false, 512>), dim3(L.a.n_windows), dim3(512), (size_t)dyn, stream, ra, L.iters, L.update_poses, L.update_lms, 1, 0);
+    } else {
+        if (L.schedule) hipLaunchKernelGGL((ba_resident_kernel<true, 256>), dim3(L.a.n_windows), dim3(256), (size_t)dyn, stream, ra, 5, 0, 0, 1, L.adaptive);
+        else hipLaunchKernelGGL((ba_resident_kernel<false, 256>), dim3(L.a.n_windows), dim3(256), (size_t)dyn, stream, ra, L.iters, L.update_poses, L.update_lms, 1, 0);
+    }
     VS_HIP(hipGetLastError());
     return VSLAM_OK;
 }

@@ -1977,6 +1977,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         memset(&L, 0, sizeof(L));
         L.a = ka.a; L.uv_s = ka.uvk; L.epos = ka.kf_pos; L.tab = ka.a.Hll; L.xin = ka.a.Ptrial; L.Pbak = ka.a.P; L.Dc = ka.a.Dinv; L.blc = ka.a.bl;
         L.status = ka.status; L.passes = ka.passes; L.defer = scratch->defer; L.order = ka.order; L.dbg = getenv("VSLAM_RS_PROFILE") ? ka.dbg_cycles : nullptr;
+        L.lanes = (scratch->tune && scratch->tune->ba_lanes > 0) ? scratch->tune->ba_lanes : 0;
         L.dyn_bytes = scratch->rs_dyn_bytes; L.schedule = schedule; L.adaptive = adaptive ? 1 : 0; L.iters = iters; L.update_poses = update_poses; L.update_lms = update_lms;
         L.opt_in_done = scratch->rs_opt_in;
         L.dense_to_general = !(scratch->tune && scratch->tune->ba_resident == 1);

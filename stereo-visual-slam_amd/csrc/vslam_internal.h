@@ -200,6 +200,7 @@ struct Tuning {
     int sgbm_fw_rows = -1;    // VSLAM_SGBM_FW_ROWS: 32 or 64 image rows per slab of the forward sweep
     int pose_only_window = -1; // VSLAM_POSE_ONLY_WINDOW: 1 = the schedule's pose-only pass on lm_window_kernel instead of pose_only_wave_kernel
     int pnp_window = -1;      // VSLAM_PNP_WINDOW: 1 = single-pose problems on lm_window_kernel<pnp> instead of pnp_wave_kernel
+    int ba_lanes = -1;        // VSLAM_BA_LANES: 256 | 512 = lanes per window of ba_resident_kernel (default: 512 when a launch has at most as many windows as the device has CUs, else 256 -- two windows per CU; same bits either way)
     int ba_resident = -1;     // VSLAM_BA_RESIDENT: 0 = optimize_map windows always on lm_window_kernel; 1 = on ba_resident_kernel whenever they fit its LDS budget;
                               // default: ba_resident_kernel for the windows that fit and have at most 2.2 observations per landmark (the windows of a real sequence)
     int ba_adaptive = -1;     // VSLAM_BA_ADAPTIVE: 0 = the BA schedule runs all three optimize_map passes for every window (default: a pass that flags nothing new is continued instead of repeated)
@@ -225,6 +226,7 @@ struct RsLaunch {
     void* uv_s; int32_t* epos; double* tab; double* xin; double* Pbak; double* Dc; double* blc; // scratch slices (see RsArgs)
     int32_t* status; int32_t* passes; int32_t* defer; const int32_t* order; long long* dbg;
     int dyn_bytes, schedule, adaptive, iters, update_poses, update_lms, dense_to_general;
+    int lanes;               // 256 | 512 forces a width of ba_resident_kernel (Tuning::ba_lanes); 0: by the number of windows in the launch
     bool opt_in_done;
 };
 int rs_dyn_lds_bytes(int device);

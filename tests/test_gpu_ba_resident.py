@@ -156,3 +156,47 @@ def test_resident_defers_windows_that_do_not_fit(pkg, synth):
     assert np.array_equal(res[1][0][1], res[0][0][1])        # the deferred window ran on the same kernel both times: same bits
     assert (res[1][1] != res[0][1]).mean() < 2e-3
 
+
+
+def test_both_widths_bit_identical(pkg, synth):
+    """ba_resident_kernel has two widths -- 512 lanes and a whole CU's LDS per window (small launches: latency), 256 lanes and half of it (two windows per
+    CU: throughput) -- and the launcher picks by the number of windows in the launch, so they must give the SAME BITS (a short last chunk of a sharded
+    sequence must not differ from the unsharded run): every floating-point sum that crosses waves runs over eight row streams in both.  One optimize_map
+    call on windows with single- and multi-observation landmarks, and the whole schedule on windows built from a rendered sequence's tracks."""
+    import torch
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    for n_lm, seed, mx in ((2000, 13, 6), (3400, 5, 2), (600, 3, 4)):
+        w = synth.ba_window(n_kf=10, n_lm=n_lm, seed=seed, min_obs=1, max_obs=mx)
+        outs = []
+        for lanes in (256, 512):
+            ctx = pkg.VO(device=0, max_batch=1)
+            try:
+                ctx.set_tuning(ba_resident=1, ba_lanes=lanes)
+                outs.append(ctx.optimize_map(w["T0"], w["xyz"], w["kf_idx"], w["lm_idx"], w["uv"], True, True, 10))
+            finally:
+                ctx.close()
+        a, b = outs
+        for k in ("T", "xyz", "chi2", "lm_inlier"):
+            assert np.array_equal(a[k], b[k]), (n_lm, k)
+        assert a["stats"]["chi2_iter"] == b["stats"]["chi2_iter"] and a["stats"]["lambda_iter"] == b["stats"]["lambda_iter"] and a["threshold"] == b["threshold"]
+    B = 24
+    pipe = KeyframePipeline(B, anms_num=1500, unique_frames=24, seed=11, ba_windows="tracks")
+    try:
+        pipe.stage_orb(); pipe.stage_stereo_match(); pipe.stage_track(); pipe.stage_build_windows()
+        pipe.vo.sync(); torch.cuda.synchronize()
+        T0 = pipe.ba_T.clone(); inl0 = pipe.ba_inl.clone()
+        res = []
+        for lanes in (256, 512, -1):
+            pipe.ba_T.copy_(T0); pipe.ba_inl.copy_(inl0)
+            torch.cuda.synchronize()  # (the copies run on torch's stream, the library on its own)
+            pipe.vo.set_tuning(ba_lanes=lanes)
+            pipe.vo.ba_batch_dev(pipe.ba_batch, schedule=1)
+            passes = pipe.vo.ba_schedule_passes(B)
+            assert (pipe.vo.ba_status(B) == 0).all()
+            torch.cuda.synchronize()
+            res.append((pipe.ba_T.cpu().numpy().view(np.uint64).copy(), pipe.ba_inl.cpu().numpy().copy(), passes.copy()))  # (bit patterns: unused pose slots of the growing-map windows may hold anything)
+        for other in res[1:]:
+            assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
+    finally:
+        pipe.vo.set_tuning(ba_lanes=-1)
+        pipe.close()
