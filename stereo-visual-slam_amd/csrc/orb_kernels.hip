@@ -872,8 +872,9 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // kCandCap x u64: (harris order key << 32) | packed xy
-    unsigned long long* keep = cand + kCandCap;                             // kCandCap x u64 sort buffer
-    int* hist = reinterpret_cast<int*>(keep + kCandCap);                    // 256 bins
+    unsigned long long* keep = cand;                                        // the sort buffer of the survivors: the SAME storage ([r5] the candidates pass through registers,
+                                                                            // below: 33 KB instead of 65 KB of LDS per workgroup, three or four (level, image) pairs per CU instead of two)
+    int* hist = reinterpret_cast<int*>(cand + kCandCap);                    // 256 bins
     int& s_cut = hist[256]; int& s_ncand = hist[257]; int& s_rank = hist[258]; int& s_keep = hist[259];
     uint32_t& s_prefix = reinterpret_cast<uint32_t*>(hist)[260];
 
@@ -935,10 +936,16 @@ __global__ __launch_bounds__(kSelBlock) void orb_select_kernel(LevelTable T, con
     __syncthreads();
     OPH(2);
     if (threadIdx.x == 0) s_keep = 0;
+    constexpr int kPerThread = kCandCap / kSelBlock;
+    unsigned long long ev[kPerThread]; // this thread's candidates leave the buffer before any survivor is written into it
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) { const int i = threadIdx.x + u * kSelBlock; ev[u] = i < m ? cand[i] : 0ull; }
     __syncthreads();
-    for (int i = threadIdx.x; i < m; i += kSelBlock) {
-        const unsigned long long e = cand[i];
-        if ((uint32_t)(e >> 32) >= cutkey) {
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+        const int i = threadIdx.x + u * kSelBlock;
+        const unsigned long long e = ev[u];
+        if (i < m && (uint32_t)(e >> 32) >= cutkey) {
             const int slot = atomicAdd(&s_keep, 1);
             const uint32_t xy = (uint32_t)e & 0xFFFFFFu;
             const uint32_t raster = ((xy >> 12) << 12) | (xy & 0xFFF); // y major, x minor (already that layout)
@@ -983,7 +990,7 @@ int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_byt
                       int32_t* d_status, hipStream_t stream) {
     LevelTable T;
     fill_level_table(plan, &T);
-    const size_t smem = (size_t)kCandCap * 8 * 2 + 272 * 4;
+    const size_t smem = (size_t)kCandCap * 8 + 272 * 4;
     static bool attr_set[16] = {false}; // per device
     int dev = 0;
     VS_HIP(hipGetDevice(&dev));
