@@ -157,10 +157,14 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
     // dependent launches that each do resize AND blur are slower than seven short resize launches + one blur launch over all levels
     // (0.37 vs 0.47 ms for two images, break-even at ~300 images).  Tuning::orb_fuse_min overrides the threshold (tests run both paths).
     const bool fused = describe && B >= (c->tune.orb_fuse_min >= 0 ? c->tune.orb_fuse_min : 384);
-    if (fused) { if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc; }
-    else if ((rc = launch_orb_pyramid(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->stream))) return rc;
-    if ((rc = launch_orb_fast(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->p.fast_threshold, c->orb.d_corners,
-                              c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
+    if (fused) { // [r6] ... and FAST + NMS of every level from the same staged tile
+        if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->p.fast_threshold, c->orb.d_corners,
+                                     c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
+    } else {
+        if ((rc = launch_orb_pyramid(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->stream))) return rc;
+        if ((rc = launch_orb_fast(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->p.fast_threshold, c->orb.d_corners,
+                                  c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
+    }
     if ((rc = launch_orb_select(c->plan, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_corners, c->orb.d_corner_cnt, c->orb.d_sel,
                                 c->orb.d_sel_cnt, c->orb.d_status, c->stream))) return rc;
     if ((rc = launch_orb_anms(c->plan, B, c->orb.d_sel, c->orb.d_sel_cnt, c->plan.sel_cap, anms_num, regroup, d_kps, nullptr, c->orb.d_order, c->p.kp_capacity,
@@ -406,7 +410,7 @@ int vslam_orb_compute(vslam_ctx* ctx, const uint8_t* img, int w, int h, int stri
     VS_HIP(hipMemcpyAsync(d_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
     VS_HIP(hipMemsetAsync(c->orb.d_status, 0, sizeof(int32_t), c->stream));
     const bool fused = 1 >= (c->tune.orb_fuse_min >= 0 ? c->tune.orb_fuse_min : 384); // (one image: the separate kernels unless a test forces the fused one)
-    if (fused) { if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc; }
+    if (fused) { if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, 0, nullptr, nullptr, nullptr, c->stream))) return rc; }
     else {
         if ((rc = launch_orb_pyramid(c->plan, c->tab, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->stream))) return rc;
         if ((rc = launch_orb_blur(c->plan, d_img, (size_t)dp * h, dp, 1, c->orb.d_pyr, c->orb.d_blur, c->stream))) return rc;

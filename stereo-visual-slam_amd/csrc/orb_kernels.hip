@@ -42,27 +42,30 @@ __device__ __constant__ signed char c_pattern[256 * 4];
 __device__ long long* g_orb_dbg = nullptr;
 // (per-block rows, plain stores: atomics on shared counters would serialise the blocks and distort the timing)
 constexpr int kDbgRows = 8192;
-#define OPH_INIT() long long* dbg__ = g_orb_dbg ? g_orb_dbg + 32 * (size_t)((blockIdx.x + 977u * blockIdx.y) % kDbgRows) : nullptr; long long tph__ = dbg__ ? clock64() : 0
-#define OPH(slot) do { if (dbg__ && threadIdx.x == 0) { const long long t1__ = clock64(); dbg__[(slot) & 31] += t1__ - tph__; tph__ = t1__; } } while (0)
+#define OPH_INIT() long long* dbg__ = g_orb_dbg ? g_orb_dbg + 64 * (size_t)((blockIdx.x + 977u * blockIdx.y) % kDbgRows) : nullptr; long long tph__ = dbg__ ? clock64() : 0
+#define OPH_ON() (dbg__ != nullptr)
+#define OPH(slot) do { if (dbg__ && threadIdx.x == 0) { const long long t1__ = clock64(); dbg__[(slot) & 63] += t1__ - tph__; tph__ = t1__; } } while (0)
 static long long* g_orb_dbg_host = nullptr;
 void orb_debug_enable() {
     if (g_orb_dbg_host) return;
-    hipMalloc((void**)&g_orb_dbg_host, sizeof(long long) * 32 * kDbgRows);
-    hipMemset(g_orb_dbg_host, 0, sizeof(long long) * 32 * kDbgRows);
+    hipMalloc((void**)&g_orb_dbg_host, sizeof(long long) * 64 * kDbgRows);
+    hipMemset(g_orb_dbg_host, 0, sizeof(long long) * 64 * kDbgRows);
     hipMemcpyToSymbol(HIP_SYMBOL(g_orb_dbg), &g_orb_dbg_host, sizeof(g_orb_dbg_host));
 }
 void orb_debug_dump(hipStream_t stream) {
     if (!g_orb_dbg_host) return;
     hipStreamSynchronize(stream);
-    static long long hall[32 * kDbgRows];
+    static long long hall[64 * kDbgRows];
     hipMemcpy(hall, g_orb_dbg_host, sizeof(hall), hipMemcpyDeviceToHost);
     hipMemset(g_orb_dbg_host, 0, sizeof(hall));
     long long h[64] = {0};
-    for (int r = 0; r < kDbgRows; ++r) for (int i = 0; i < 32; ++i) h[i] += hall[32 * r + i];
+    for (int r = 0; r < kDbgRows; ++r) for (int i = 0; i < 64; ++i) h[i] += hall[64 * r + i];
     static const char* names[64] = {"sel: hist+cut", "sel: harris", "sel: radix select", "sel: compact+sort", "sel: angle+out", nullptr, nullptr, nullptr,
                                     "desc: patch load", "desc: row blur", "desc: col blur", "desc: sincos+tests", nullptr, nullptr, nullptr, nullptr,
                                     "fast: tile load", "fast: corner test", "fast: score", "fast: nms+append", nullptr, nullptr, nullptr, nullptr,
-                                    "anms: gather+sort", "anms: radii", "anms: radius sort", "anms: compact+regroup+out"};
+                                    "anms: gather+sort", "anms: radii", "anms: radius sort", "anms: compact+regroup+out", nullptr, nullptr, nullptr, nullptr,
+                                    "pyrfast: tile load", "pyrfast: resize", "pyrfast: blur", "pyrfast: edge columns", "pyrfast: pre-test", "pyrfast: queue pushes", "pyrfast: scores",
+                                    "pyrfast: flush + barrier", "pyrfast: nms", "pyrfast: output"};
     for (int i = 0; i < 64; ++i) if (names[i] && h[i]) fprintf(stderr, "  [orb profile] %-28s %14lld block-cycles (sum over blocks)\n", names[i], h[i]);
 }
 static bool g_pattern_uploaded[16] = {false};
@@ -448,9 +451,10 @@ __device__ inline s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_
 // register as packed i16: pair j = (d[2j], d[2j+1]); the pair shifted by one position is one v_alignbyte, the minima over 2, 4 and 9
 // consecutive positions are v_pk_min_i16 on aligned pairs (shift by 2, 4, 8 positions = 1, 2, 4 pairs), and the maximum over the arcs
 // is a packed tree: ~110 instructions instead of ~200 with one ring position per register.
+template <int PITCH>
 __device__ inline int fast_score(const uint8_t* p, int thr) {
     const int v = p[0];
-    const int r[16] = RING_LOAD(p, kPixPitch);
+    const int r[16] = RING_LOAD(p, PITCH);
     const s16x2 vv = {(short)v, (short)v};
     s16x2 P[8], Q[8], n2[8], x2[8], n4[8], x4[8];
 #pragma unroll
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
     for (int q = threadIdx.x; q < nq; q += 256) {
         const int i = queue[q];
         const int sy = i / kScW, sx = i - sy * kScW;
-        const int score = fast_score(&pix[(sy + 3) * kPixPitch + sx + 3], thr);
+        const int score = fast_score<kPixPitch>(&pix[(sy + 3) * kPixPitch + sx + 3], thr);
         if (score >= thr) { sc[i] = (uint8_t)score; cqueue[atomicAdd(&ccount, 1)] = (uint16_t)i; }
     }
     __syncthreads();
@@ -1565,6 +1569,31 @@ int launch_orb_blur(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes
 #ifndef VSLAM_ORB_BLUR_NT
 #define VSLAM_ORB_BLUR_NT 1 // non-temporal stores of the blurred pyramid (pyramid + blur 1.04 -> 1.02 ms, FAST 0.90 -> 0.89 ms per 512 images)
 #endif
+// [r6] (3) FAST-9/16 + 3x3 NMS of level l run on the SAME staged tile (orb_fast_kernel staged every level a second time: 0.54 of its
+// 1.82 ms per 1024 images, and 8 GB of re-reads per step).  The tile carries a halo of 4 rows above / below (the blur needs 3, the ring of a
+// score-halo pixel 3 + 1) and 4 / 12 columns left / right, so every pixel the 256 x 64 tile emits finds its ring and its eight neighbours'
+// rings in LDS.  Structure (per wave, no workgroup barrier until the NMS):
+//   pre-test   a lane owns the 4 columns of an aligned dword and walks 6 centre rows at a time: the dwords of 12 raw rows are widened once to
+//              packed i16 (even / odd pixels), the compass rule "two adjacent compass pixels both brighter than v + t or both darker than
+//              v - t" costs 12 packed operations per pixel pair, the verdict is the sign of a packed difference shifted into a per-lane mask;
+//   queue      set bits become 16-bit tile positions in a 128-entry per-wave LDS queue (ballot ranks, the count lives in an SGPR);
+//              whenever 64 are queued they are scored with ALL lanes busy (fast_score: corner <=> score >= threshold);
+//   corners    scores go to the (66 x 258) score tile, corners that can be emitted to a per-wave list;
+//   NMS        after one barrier every wave checks its own list against the score tile; survivors are collected in the (now dead) pixel
+//              tile and appended to the level's corner list with ONE global atomic per workgroup.
+// The workgroup's corner list holds kPfCornerCap entries (7 % of the tile's pixels); a denser tile takes the slow path: every thread scans score dwords.
+constexpr int kPfRawH = kBlurTileH + 8;                       // raw rows: tile rows -4 .. kBlurTileH + 3
+constexpr int kPfScPitch = 264, kPfScH = kBlurTileH + 2;      // score tile: rows -1 .. kBlurTileH, byte column = raw column (tile column + 4)
+#ifndef VSLAM_PF_WAVES
+#define VSLAM_PF_WAVES 8
+#endif
+constexpr int kPfWaves = VSLAM_PF_WAVES;     // waves per tile (4 | 8): the LDS tile allows four workgroups per CU, so 8 waves per tile fill the CU's 32 wave slots
+constexpr int kPfQueue = 128;                // per wave: < 64 left over + the <= 64 candidates of one ballot
+constexpr int kPfRawBytes = kPfRawH * kBlurRawPitch, kPfScBytes = kPfScH * kPfScPitch;
+constexpr int kPfCornerCap = (40960 - 32 - kPfRawBytes - kPfScBytes - 2 * kPfQueue * kPfWaves) / 2; // per workgroup: corners (score >= threshold) the tile may emit, before the NMS (what is left of a quarter of the CU's LDS)
+static_assert(kPfCornerCap >= 900, "corner list of orb_pyrblur_kernel");
+static_assert(kBlurTileW == 256 && kBlurRawPitch == 272, "the FAST phase of orb_pyrblur_kernel assumes 64 lanes x 4 columns and 272-byte raw rows");
+static_assert(kPfRawBytes >= 4 * (kBlurTileW * kBlurTileH / 4), "the NMS survivors are collected in the pixel tile's storage");
 struct PyrBlurArgs {
     const uint8_t* src_base; size_t src_img_stride; int spitch, sw, sh;      // level l (raw)
     uint8_t* blur_base; size_t blur_img_stride; int bpitch;                  // blurred level l
@@ -1572,20 +1601,41 @@ struct PyrBlurArgs {
     const int* xofs; const short* ialpha; const int* yofs; const short* ibeta; // resize tables of level l + 1
     const int* tile_dx; const int* tile_dy;                                  // output ownership per tile column / row
     int tiles_x;
+    // FAST of level l (corners == nullptr: descriptor-only call, no detection)
+    uint32_t* corners; size_t corner_img_stride; int corner_cap; int32_t* corner_cnt; int32_t* status; int thr, level;
 };
-__global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
+__device__ inline int mbcnt64(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void orb_pyrblur_kernel(PyrBlurArgs a) {
+    constexpr int NT = 64 * NW;
     const int b = blockIdx.y;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int ox = tx * kBlurTileW, oy = ty * kBlurTileH;
     const int W = a.sw, H = a.sh;
     const uint8_t* src = a.src_base + (size_t)b * a.src_img_stride;
-    __shared__ __attribute__((aligned(16))) uint8_t raw[kBlurRawH * kBlurRawPitch];
-    load_tile_b128<256, kBlurRawChunks, kBlurRawH, true>(raw, src, a.spitch, W, H, ox - 4, oy - 3);
-    __syncthreads();
+    // (one array: the pre-test of the last wave reads up to two pixel rows past the tile for centre rows it then skips -- they land in the score tile)
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[kPfRawBytes + kPfScBytes];
+    uint8_t* const raw = s_tile;
+    uint8_t* const sc = s_tile + kPfRawBytes;
+    __shared__ uint16_t s_wq[NW * kPfQueue];
+    __shared__ uint16_t s_cq[kPfCornerCap];
+    __shared__ int s_ocount, s_obase, s_dense, s_ccount;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the emitted pixels of this tile (cv::ORB keeps corners >= edgeThreshold from the level border), in image coordinates, inclusive
+    const int ex_lo = max(ox, kEdge), ex_hi = min(ox + kBlurTileW, W - kEdge) - 1, ey_lo = max(oy, kEdge), ey_hi = min(oy + kBlurTileH, H - kEdge) - 1;
+    const bool do_fast = a.corners != nullptr && ex_lo <= ex_hi && ey_lo <= ey_hi; // uniform
+    if (do_fast) {
+        for (int i = threadIdx.x; i < kPfScBytes / 16; i += NT) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x == 0) { s_ocount = 0; s_dense = 0; s_ccount = 0; }
+    }
+    OPH_INIT();
+    load_tile_b128<NT, kBlurRawChunks, kPfRawH, true>(raw, src, a.spitch, W, H, ox - 4, oy - 4);
+    __syncthreads();
+    OPH(32);
     // ---- (1) level l + 1
 #ifndef VSLAM_PYRBLUR_DBG
-#define VSLAM_PYRBLUR_DBG 0 // tuning aid (timing only, outputs incomplete): 1 = no blur half, 2 = no resize half
+#define VSLAM_PYRBLUR_DBG 0 // tuning aid (timing only, outputs incomplete): 1 = no blur half, 2 = no resize half, 4 = no FAST, 8 = FAST pre-test without the scores
 #endif
     if (a.dst_base && !(VSLAM_PYRBLUR_DBG & 2)) {
         const int dx_lo = a.tile_dx[tx], dx_hi = a.tile_dx[tx + 1], dy_lo = a.tile_dy[ty], dy_hi = a.tile_dy[ty + 1]; // uniform
@@ -1593,7 +1643,7 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
         // the row tables of ALL rows of this wave are fetched once, one row per lane (<= 16 rows per wave: 64 source rows / 1.2 / 4 waves),
         // by every lane (v_readlane below reads lanes that own no output column), and handed out with v_readlane: a table load per row
         // would be a dependent memory round trip at the head of every row
-        const int my_dy = min(dy_lo + wave + 4 * lane, a.dh - 1);
+        const int my_dy = min(dy_lo + wave + NW * lane, a.dh - 1);
         const int my_sy = a.yofs[my_dy];
         const uint32_t my_beta = *reinterpret_cast<const uint32_t*>(a.ibeta + 2 * my_dy); // (b0, b1) as two shorts
         // EVERY lane runs the loop below (lanes past the tile's last quad compute on clamped table entries and store nothing): the row
@@ -1616,10 +1666,10 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
             for (int k = 0; k < 4; ++k) sel[k] = 0x0c010c00u + __umul24((uint32_t)(sxs[k] - (ox - 4) - c0) & 7u, 0x00010001u); // rel = 0..7 (garbage for unowned columns)
             const uint32_t* rawd = reinterpret_cast<const uint32_t*>(raw);
             int it = 0;
-            for (int dy = dy_lo + wave; dy < dy_hi; dy += 4, ++it) { // wave-uniform
+            for (int dy = dy_lo + wave; dy < dy_hi; dy += NW, ++it) { // wave-uniform
                 const int sy = __builtin_amdgcn_readlane(my_sy, it);
                 const uint32_t beta = (uint32_t)__builtin_amdgcn_readlane((int)my_beta, it);
-                const int r0 = min(max(sy, 0), H - 1) - (oy - 3), r1 = min(max(sy + 1, 0), H - 1) - (oy - 3);
+                const int r0 = min(max(sy, 0), H - 1) - (oy - 4), r1 = min(max(sy + 1, 0), H - 1) - (oy - 4);
                 const uint32_t b0 = (uint32_t)(int)(short)(beta & 0xFFFFu), b1 = (uint32_t)(int)(short)(beta >> 16);
                 const uint32_t* p0 = rawd + r0 * (kBlurRawPitch / 4) + i0;
                 const uint32_t* p1 = rawd + r1 * (kBlurRawPitch / 4) + i0;
@@ -1642,49 +1692,260 @@ __global__ __launch_bounds__(256) void orb_pyrblur_kernel(PyrBlurArgs a) {
             }
         }
     }
-    // ---- (2) blurred level l (see orb_blur_kernel)
-    uint8_t* dstb = a.blur_base + (size_t)b * a.blur_img_stride;
-    if (VSLAM_PYRBLUR_DBG & 1) return;
-    const int row0 = wave * kBlurWaveRows;
-    const int nrows = min(kBlurWaveRows, H - (oy + row0)); // wave-uniform
-    const int x = ox + 4 * lane;
-    if (nrows <= 0) return;
-    constexpr uint32_t W0 = 18u | 34u << 8 | 49u << 16 | 55u << 24, W1 = 49u | 34u << 8 | 18u << 16;
-    constexpr uint32_t V0 = 18u | 34u << 16, V1 = 49u | 55u << 16, V2 = 49u | 34u << 16, V3 = 18u << 16;
-    const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + row0 * kBlurRawPitch) + lane;
-    uint8_t* out = dstb + (size_t)(oy + row0) * a.bpitch + x;
-    uint32_t P[kBlurWaveRows + 6][4], hprev[4] = {0, 0, 0, 0};
+    OPH(33);
+    // ---- (2) blurred level l (see orb_blur_kernel).  NW = 4: a wave owns 16 rows x 256 columns, a lane four pixels.  NW = 8: a wave owns
+    // 16 rows x 128 columns, a lane two pixels (the row pass of the 6 halo rows is repeated per row band, so halving the bands' height would cost more)
+    if (!(VSLAM_PYRBLUR_DBG & 1)) {
+        uint8_t* dstb = a.blur_base + (size_t)b * a.blur_img_stride;
+        constexpr uint32_t W0 = 18u | 34u << 8 | 49u << 16 | 55u << 24, W1 = 49u | 34u << 8 | 18u << 16;
+        constexpr uint32_t V0 = 18u | 34u << 16, V1 = 49u | 55u << 16, V2 = 49u | 34u << 16, V3 = 18u << 16;
+        const us2_t lim = {255, 255};
+        if constexpr (NW == 4) {
+            const int row0 = wave * kBlurWaveRows;
+            const int nrows = min(kBlurWaveRows, H - (oy + row0)); // wave-uniform
+            const int x = ox + 4 * lane;
+            if (nrows > 0) {
+                const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + (row0 + 1) * kBlurRawPitch) + lane; // tile row r reads raw rows r + 1 .. r + 7
+                uint8_t* out = dstb + (size_t)(oy + row0) * a.bpitch + x;
+                uint32_t P[kBlurWaveRows + 6][4], hprev[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < kBlurWaveRows + 6; ++t) {
-        if (t - 6 >= nrows) break; // uniform
-        const uint32_t A = rp[t * (kBlurRawPitch / 4)], Bw = rp[t * (kBlurRawPitch / 4) + 1], C = rp[t * (kBlurRawPitch / 4) + 2];
+                for (int t = 0; t < kBlurWaveRows + 6; ++t) {
+                    if (t - 6 >= nrows) break; // uniform
+                    const uint32_t A = rp[t * (kBlurRawPitch / 4)], Bw = rp[t * (kBlurRawPitch / 4) + 1], C = rp[t * (kBlurRawPitch / 4) + 2];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const uint32_t lo = o == 3 ? Bw : __builtin_amdgcn_alignbyte(Bw, A, o + 1), hi = o == 3 ? C : __builtin_amdgcn_alignbyte(C, Bw, o + 1);
-            const uint32_t h = __builtin_amdgcn_udot4(hi, W1, __builtin_amdgcn_udot4(lo, W0, 0u, false), false);
-            P[t][o] = hprev[o] | h << 16;
-            hprev[o] = h;
-        }
-        if (t >= 6) {
-            uint32_t sum[4];
+                    for (int o = 0; o < 4; ++o) {
+                        const uint32_t lo = o == 3 ? Bw : __builtin_amdgcn_alignbyte(Bw, A, o + 1), hi = o == 3 ? C : __builtin_amdgcn_alignbyte(C, Bw, o + 1);
+                        const uint32_t h = __builtin_amdgcn_udot4(hi, W1, __builtin_amdgcn_udot4(lo, W0, 0u, false), false);
+                        P[t][o] = hprev[o] | h << 16;
+                        hprev[o] = h;
+                    }
+                    if (t >= 6) {
+                        uint32_t sum[4];
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                sum[o] = udot2(P[t][o], V3, udot2(P[t - 1][o], V2, udot2(P[t - 3][o], V1, udot2(P[t - 5][o], V0, 1u << 15))));
-            const us2_t lim = {255, 255};
-            const us2_t p01 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u)), lim);
-            const us2_t p23 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u)), lim);
-            const uint32_t px = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
+                        for (int o = 0; o < 4; ++o)
+                            sum[o] = udot2(P[t][o], V3, udot2(P[t - 1][o], V2, udot2(P[t - 3][o], V1, udot2(P[t - 5][o], V0, 1u << 15))));
+                        const us2_t p01 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u)), lim);
+                        const us2_t p23 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u)), lim);
+                        const uint32_t px = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
 #if VSLAM_ORB_BLUR_NT
-            if (x < W) __builtin_nontemporal_store(px, reinterpret_cast<uint32_t*>(out + (size_t)(t - 6) * a.bpitch)); // read again only by the descriptor kernel, five kernels later
+                        if (x < W) __builtin_nontemporal_store(px, reinterpret_cast<uint32_t*>(out + (size_t)(t - 6) * a.bpitch)); // read again only by the descriptor kernel, five kernels later
 #else
-            if (x < W) *reinterpret_cast<uint32_t*>(out + (size_t)(t - 6) * a.bpitch) = px;
+                        if (x < W) *reinterpret_cast<uint32_t*>(out + (size_t)(t - 6) * a.bpitch) = px;
 #endif
+                    }
+                }
+            }
+        } else {
+            const int band = wave >> 1, half = wave & 1;
+            const int row0 = band * kBlurWaveRows;
+            const int nrows = min(kBlurWaveRows, H - (oy + row0)); // wave-uniform
+            const int xt = 128 * half + 2 * lane;                  // tile column of this lane's first pixel
+            const int x = ox + xt;
+            if (nrows > 0) {
+                // taps of pixel xt: raw columns xt + 1 .. xt + 7 (raw column = tile column + 4); of pixel xt + 1: xt + 2 .. xt + 8.  Three aligned dwords from
+                // raw column xt & ~3 on hold them; sh = (xt & 3) + 1 = 1 | 3 bytes bring the window's first byte to the front
+                const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + (row0 + 1) * kBlurRawPitch) + (xt >> 2);
+                const uint32_t sh = (uint32_t)(xt & 3) + 1u;
+                uint8_t* out = dstb + (size_t)(oy + row0) * a.bpitch + x;
+                uint32_t P[kBlurWaveRows + 6][2], hprev[2] = {0, 0};
+#pragma unroll
+                for (int t = 0; t < kBlurWaveRows + 6; ++t) {
+                    if (t - 6 >= nrows) break; // uniform
+                    const uint32_t A = rp[t * (kBlurRawPitch / 4)], Bw = rp[t * (kBlurRawPitch / 4) + 1], C = rp[t * (kBlurRawPitch / 4) + 2];
+                    const uint32_t wl = __builtin_amdgcn_alignbyte(Bw, A, sh), wh = __builtin_amdgcn_alignbyte(C, Bw, sh); // window bytes 0 .. 7
+                    const uint32_t lo1 = __builtin_amdgcn_alignbyte(wh, wl, 1u), hi1 = wh >> 8;
+                    const uint32_t hA = __builtin_amdgcn_udot4(wh, W1, __builtin_amdgcn_udot4(wl, W0, 0u, false), false); // (W1's top byte is 0: window byte 7 does not count)
+                    const uint32_t hB = __builtin_amdgcn_udot4(hi1, W1, __builtin_amdgcn_udot4(lo1, W0, 0u, false), false);
+                    P[t][0] = hprev[0] | hA << 16; hprev[0] = hA;
+                    P[t][1] = hprev[1] | hB << 16; hprev[1] = hB;
+                    if (t >= 6) {
+                        uint32_t sum[2];
+#pragma unroll
+                        for (int o = 0; o < 2; ++o)
+                            sum[o] = udot2(P[t][o], V3, udot2(P[t - 1][o], V2, udot2(P[t - 3][o], V1, udot2(P[t - 5][o], V0, 1u << 15))));
+                        const us2_t p01 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u)), lim);
+                        const uint16_t px = (uint16_t)__builtin_amdgcn_perm(0u, __builtin_bit_cast(uint32_t, p01), 0x0c0c0200u);
+#if VSLAM_ORB_BLUR_NT
+                        if (x < W) __builtin_nontemporal_store(px, reinterpret_cast<uint16_t*>(out + (size_t)(t - 6) * a.bpitch));
+#else
+                        if (x < W) *reinterpret_cast<uint16_t*>(out + (size_t)(t - 6) * a.bpitch) = px;
+#endif
+                    }
+                }
+            }
         }
     }
+    OPH(34);
+    // ---- (3) FAST-9/16 of level l
+    if (!do_fast || (VSLAM_PYRBLUR_DBG & 4)) return; // uniform
+    const int thr = a.thr;
+    // score region = emitted pixels dilated by one, in TILE coordinates (column -1 .. 256, row -1 .. kBlurTileH), inclusive
+    const int vx_lo = ex_lo - 1 - ox, vx_hi = ex_hi + 1 - ox, vy_lo = ey_lo - 1 - oy, vy_hi = ey_hi + 1 - oy;
+    uint16_t* wq = s_wq + wave * kPfQueue;
+    int qn = 0; // wave-uniform count (an SGPR)
+    // position id = raw row << 9 | raw column
+    auto score_batch = [&](int first, int cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the queue entries were written by other lanes of this wave
+        if (VSLAM_PYRBLUR_DBG & 8) { if (lane < cnt && wq[first + lane] == 0xFFFF) sc[lane] = 1; return; } // (timing aid: pre-test only)
+        bool corner = false; int id = 0;
+        if (lane < cnt) {
+            id = wq[first + lane];
+            const int R = id >> 9, c = id & 511;
+            const int s = fast_score<kBlurRawPitch>(raw + R * kBlurRawPitch + c, thr);
+            if (s >= thr) {
+                sc[(R - 3) * kPfScPitch + c] = (uint8_t)s;
+                const int tcx = c - 4, tcy = R - 4; // tile coordinates: only positions this tile emits go on to the NMS
+                corner = tcx > vx_lo && tcx < vx_hi && tcy > vy_lo && tcy < vy_hi;
+            }
+        }
+        const unsigned long long bal = __ballot(corner);
+        if (bal) { // uniform
+            const int n = __popcll(bal);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ccount, n); // one returning LDS atomic per 64 scored candidates
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + n <= kPfCornerCap) { if (corner) s_cq[base + mbcnt64(bal)] = (uint16_t)id; }
+            else if (lane == 0) s_dense = 1; // (benign race: every writer stores 1)
+        }
+    };
+    // queue the lanes of the lane mask `bal` (uniform), lane i at position id; 64 queued candidates are scored on the spot
+    auto push = [&](unsigned long long bal, int id) {
+        if (bal) { // uniform
+            if (__builtin_amdgcn_inverse_ballot_w64(bal)) wq[qn + mbcnt64(bal)] = (uint16_t)id;
+            qn += __popcll(bal);
+            if (qn >= 64) { qn -= 64; score_batch(qn, 64); }
+        }
+    };
+    // columns -1 and 256 of the score region belong to no lane's dword: one thread per position, scalar form of the same rule
+    if (wave < (2 * kPfScH + 63) / 64) { // (whole waves: the pushes are wave-wide ballots) -- waves 0 .. 2 at kBlurTileH = 64
+        const int t = threadIdx.x, side = t >= kPfScH ? 1 : 0, rr = t - side * kPfScH; // rr: score row
+        const int tcx = side ? kBlurTileW : -1, tcy = rr - 1;
+        bool cand = false;
+        const int R = tcy + 4, c = tcx + 4;
+        if (t < 2 * kPfScH && tcx >= vx_lo && tcx <= vx_hi && tcy >= vy_lo && tcy <= vy_hi) {
+            const uint8_t* p = raw + R * kBlurRawPitch + c;
+            const int v = p[0], c0 = p[3 * kBlurRawPitch], c8 = p[-3 * kBlurRawPitch], c4 = p[3], c12 = p[-3];
+            const int bp = min(max(c0, c8), max(c4, c12)), dp = max(min(c0, c8), min(c4, c12));
+            cand = bp - v > thr || v - dp > thr;
+        }
+        push(__ballot(cand), R << 9 | c);
+    }
+    OPH(35);
+    {
+        constexpr int kRows = kBlurTileH / NW;                      // centre rows per wave (+ 2 for the last wave)
+        constexpr int kG = NW == 4 ? 6 : 4;                         // centre rows per group: their kG + 6 raw rows are widened once
+        constexpr int kGroups = (kRows + 2 + kG - 1) / kG;
+        static_assert(kRows * (NW - 1) + kGroups * kG + 6 <= kPfRawH + 2, "the pre-test reads at most two rows past the staged tile");
+        const int cb0 = kRows * wave - 1;                                                  // first centre row (tile coordinates) of this wave
+        const int c_last = wave == NW - 1 ? kBlurTileH : cb0 + kRows - 1;                  // last one it owns (the next wave starts one row above its band)
+        const int o_lo = max(cb0, vy_lo), o_hi = min(c_last, vy_hi);
+        // this lane's four columns 4 lane + k: inside the score region?
+        unsigned long long colm[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) colm[k] = __ballot(4 * lane + k >= vx_lo && 4 * lane + k <= vx_hi);
+        const int thr_hi = thr << 16 | 0xFFFF; // high half of a packed pair > thr  <=>  the whole word (signed) > thr_hi
+        const int idv = 4 * lane + 4;           // raw column of this lane's first pixel
+#pragma unroll 1
+        for (int g = 0; g < kGroups; ++g) {
+            const int cb = cb0 + kG * g; // centre rows cb .. cb + kG - 1
+            if (cb > o_hi || cb + kG - 1 < o_lo) continue; // uniform
+            // raw rows cb + 1 .. cb + kG + 6 (centre row cb + j is raw row cb + j + 4); rows never loaded (beyond the image) or past the tile
+            // only feed centre rows outside the score region, which are skipped
+            const uint32_t* rawd = reinterpret_cast<const uint32_t*>(raw) + (cb + 1) * (kBlurRawPitch / 4) + lane;
+            s16x2 E[kG + 6], O[kG + 6];
+#pragma unroll
+            for (int k = 0; k < kG + 6; ++k) {
+                const uint32_t Bw = rawd[k * (kBlurRawPitch / 4) + 1];
+                E[k] = as_s16x2(Bw & 0x00FF00FFu);                                   // pixels 0, 2
+                O[k] = as_s16x2(__builtin_amdgcn_perm(0u, Bw, 0x0c030c01u));          // pixels 1, 3
+            }
+#pragma unroll
+            for (int j = 0; j < kG; ++j) {
+                if (cb + j < o_lo || cb + j > o_hi) continue; // uniform
+                const uint32_t A = rawd[(j + 3) * (kBlurRawPitch / 4)], Bw = rawd[(j + 3) * (kBlurRawPitch / 4) + 1], C = rawd[(j + 3) * (kBlurRawPitch / 4) + 2];
+                // ring positions 4 (x + 3) and 12 (x - 3) of the even and of the odd pixels
+                const s16x2 c4E = as_s16x2(__builtin_amdgcn_perm(C, Bw, 0x0c050c03u)), c4O = as_s16x2(C & 0x00FF00FFu);
+                const s16x2 c12E = as_s16x2(__builtin_amdgcn_perm(0u, A, 0x0c030c01u)), c12O = as_s16x2(__builtin_amdgcn_perm(Bw, A, 0x0c040c02u));
+                // "two adjacent compass pixels both brighter than v + t": every adjacent pair takes one of {0, 8} and one of {4, 12}, so the
+                // brightest pair's darker pixel is min(max(c0, c8), max(c4, c12)); likewise the dark side
+                const s16x2 bpE = pk_min(pk_max(E[j], E[j + 6]), pk_max(c4E, c12E)), dpE = pk_max(pk_min(E[j], E[j + 6]), pk_min(c4E, c12E));
+                const s16x2 bpO = pk_min(pk_max(O[j], O[j + 6]), pk_max(c4O, c12O)), dpO = pk_max(pk_min(O[j], O[j + 6]), pk_min(c4O, c12O));
+                const s16x2 mE = pk_max(bpE - E[j + 3], E[j + 3] - dpE), mO = pk_max(bpO - O[j + 3], O[j + 3] - dpO); // > thr: candidate
+                // one lane mask per pixel column (the queue then holds runs of neighbouring lanes of ONE row, whose ring loads fall into different LDS
+                // banks); the four pushes are ONE site in a rolled loop: the score code is inlined once per row, not once per push
+                const unsigned long long m0 = __ballot((int)mE.x > thr) & colm[0], m1 = __ballot((int)mO.x > thr) & colm[1];
+                const unsigned long long m2 = __ballot(__builtin_bit_cast(int, mE) > thr_hi) & colm[2], m3 = __ballot(__builtin_bit_cast(int, mO) > thr_hi) & colm[3];
+                if (OPH_ON()) OPH(36);
+                const int idr = ((cb + 4 + j) << 9) + idv;
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) push(k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : m3, idr + k);
+                if (OPH_ON()) OPH(37);
+            }
+        }
+    }
+    if (qn > 0) score_batch(0, qn);
+    __syncthreads();
+    OPH(39);
+    // ---- 3x3 non-maximum suppression: a corner survives when its score is larger than all eight neighbours'
+    uint32_t* outq = reinterpret_cast<uint32_t*>(raw); // (the pixel tile is dead)
+    auto nms_emit = [&](bool is, int id) { // whole wave; `is`: this lane holds a corner at position id that the tile may emit
+        bool keep = false; uint32_t rec = 0;
+        if (is) {
+            const int R = id >> 9, c = id & 511;
+            const uint8_t* s = sc + (R - 3) * kPfScPitch + c;
+            const int v = s[0];
+            keep = v > s[-1] && v > s[1] && v > s[-kPfScPitch - 1] && v > s[-kPfScPitch] && v > s[-kPfScPitch + 1] && v > s[kPfScPitch - 1] &&
+                   v > s[kPfScPitch] && v > s[kPfScPitch + 1];
+            rec = (uint32_t)(ox + c - 4) | (uint32_t)(oy + R - 4) << 12 | (uint32_t)v << 24;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (bal) { // uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ocount, __popcll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (keep) outq[base + mbcnt64(bal)] = rec;
+        }
+    };
+    if (!s_dense) { // uniform
+        const int nc = s_ccount;
+        for (int q = 64 * wave; q < nc; q += NT) nms_emit(q + lane < nc, q + lane < nc ? s_cq[q + lane] : 0);
+    } else { // a tile with more corners than the list holds: every thread walks score dwords (rows 0 .. kBlurTileH - 1, columns 0 .. 255)
+        for (int i = threadIdx.x; i < 64 * kBlurTileH; i += NT) { // (whole waves take every turn)
+            const int r = i >> 6, d = i & 63;
+            uint32_t m = reinterpret_cast<const uint32_t*>(sc + (r + 1) * kPfScPitch)[1 + d];
+            if (r <= vy_lo || r >= vy_hi) m = 0;
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const int tcx = 4 * d + k;
+                const bool is = ((m >> (8 * k)) & 0xFFu) != 0 && tcx > vx_lo && tcx < vx_hi;
+                if (__ballot(is)) nms_emit(is, (r + 4) << 9 | (tcx + 4));
+            }
+        }
+    }
+    __syncthreads();
+    OPH(40);
+    const int no = s_ocount; // a strict 3x3 maximum: at most one survivor per 2x2 cell
+    if (no > 0) {
+        if (threadIdx.x == 0) s_obase = atomicAdd(a.corner_cnt + b * kNLevels, no);
+        __syncthreads();
+        uint32_t* corners = a.corners + (size_t)b * a.corner_img_stride;
+        const int cap = a.corner_cap, base = s_obase;
+        for (int q = threadIdx.x; q < no; q += NT) {
+            if (base + q < cap) corners[base + q] = outq[q];
+            else atomicOr(&a.status[b], kStCornerOverflow);
+        }
+    }
+    OPH(41);
 }
 
+// d_corners == nullptr: pyramid + blur only (the descriptor-only entry point); else the level's FAST corners are appended to d_corners /
+// d_corner_cnt (zeroed here, like d_status) exactly as launch_orb_fast would
 int launch_orb_pyrblur(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, uint8_t* d_pyr,
-                       uint8_t* d_blur, hipStream_t stream) {
+                       uint8_t* d_blur, int fast_thr, uint32_t* d_corners, int32_t* d_corner_cnt, int32_t* d_status, hipStream_t stream) {
+    if (d_corners) {
+        VS_HIP(hipMemsetAsync(d_corner_cnt, 0, sizeof(int32_t) * B * kNLevels, stream));
+        VS_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * B, stream));
+    }
     ProfScope prof__(stream, "orb_pyrblur_kernel", kNLevels);
     for (int l = 0; l < kNLevels; ++l) {
         const OrbLevel& S = plan.lv[l];
@@ -1704,7 +1965,11 @@ int launch_orb_pyrblur(const OrbPlan& plan, const OrbTables& tab, const uint8_t*
             a.yofs = tab.d_yofs + tab.y_off[l + 1]; a.ibeta = tab.d_ibeta + 2 * tab.y_off[l + 1];
             a.tile_dx = tab.d_tile_dx + tab.tdx_off[l]; a.tile_dy = tab.d_tile_dy + tab.tdy_off[l];
         }
-        hipLaunchKernelGGL(orb_pyrblur_kernel, dim3(a.tiles_x * tiles_y, B), dim3(256), 0, stream, a);
+        if (d_corners) {
+            a.corners = d_corners + S.corner_off; a.corner_img_stride = (size_t)plan.corner_total; a.corner_cap = S.corner_cap;
+            a.corner_cnt = d_corner_cnt + l; a.status = d_status; a.thr = fast_thr; a.level = l;
+        }
+        hipLaunchKernelGGL(orb_pyrblur_kernel<kPfWaves>, dim3(a.tiles_x * tiles_y, B), dim3(64 * kPfWaves), 0, stream, a);
     }
     VS_HIP(hipGetLastError());
     return VSLAM_OK;

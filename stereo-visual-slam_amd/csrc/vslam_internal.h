@@ -103,8 +103,9 @@ struct OrbBuffers {
 int launch_orb_pyramid(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch,
                        int B, uint8_t* d_pyr, hipStream_t stream);
 // pyramid level l + 1 AND the blurred level l from ONE staging of the level-l tile (8 launches: the levels depend on each other)
+// [r6] ... and, with d_corners != nullptr, FAST + NMS of level l from the same tile (then launch_orb_fast is not called)
 int launch_orb_pyrblur(const OrbPlan& plan, const OrbTables& tab, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, uint8_t* d_pyr,
-                       uint8_t* d_blur, hipStream_t stream);
+                       uint8_t* d_blur, int fast_thr, uint32_t* d_corners, int32_t* d_corner_cnt, int32_t* d_status, hipStream_t stream);
 int launch_orb_fast(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
                     int fast_thr, uint32_t* d_corners, int32_t* d_corner_cnt, int32_t* d_status, hipStream_t stream);
 int launch_orb_select(const OrbPlan& plan, const uint8_t* d_imgs, size_t img_bytes, int pitch, int B, const uint8_t* d_pyr,
