@@ -448,29 +448,34 @@ __device__ inline s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_
 
 // cornerScore<16> of cv::FAST: the largest threshold for which the pixel still is a 9-of-16 corner = max over the 16 arcs of
 // min(d[k..k+8]) (bright side) and of -max(d[k..k+8]) (dark side), d[k] = v - ring[k].  |d| <= 255, so two ring positions share a
-// register as packed i16: pair j = (d[2j], d[2j+1]); the pair shifted by one position is one v_alignbyte, the minima over 2, 4 and 9
-// consecutive positions are v_pk_min_i16 on aligned pairs (shift by 2, 4, 8 positions = 1, 2, 4 pairs), and the maximum over the arcs
-// is a packed tree: ~110 instructions instead of ~200 with one ring position per register.
+// register as packed i16.  [r6] Pair j = (d[j], d[j+8]): with pre[k] = min(pair 0..k) and suf[k] = min(pair k..7) the arcs k and k + 8 are
+// the two halves of min(suf[k], swap(pre[k])) -- arc k = positions k..7 (low halves of pairs k..7) and 8..k+8 (high halves of pairs 0..k), arc
+// k + 8 the mirror image -- so all 16 arc minima cost 7 + 7 + 8 + 8 packed operations, the maximum over them 7 more: ~95 instructions for both
+// sides (the doubling scheme -- minima over 2, 4, 9 consecutive positions of adjacent pairs -- took 112, one position per register ~200).
+// `p` points at the ring's top-left corner (centre - 3 rows - 3 columns): every LDS offset below is non-negative and rides in the load instruction.
 template <int PITCH>
 __device__ inline int fast_score(const uint8_t* p, int thr) {
-    const int v = p[0];
-    const int r[16] = RING_LOAD(p, PITCH);
-    const s16x2 vv = {(short)v, (short)v};
-    s16x2 P[8], Q[8], n2[8], x2[8], n4[8], x4[8];
+#define RP(dx, dy) ((uint32_t)p[((dy) + 3) * PITCH + (dx) + 3])
+    const uint32_t v = RP(0, 0);
+    // ring positions in the order of cv::FAST (pattern 16): 0 = (0, 3), 1 = (1, 3), 2 = (2, 2), 3 = (3, 1), 4 = (3, 0), ... clockwise
+    const uint32_t r0 = RP(0, 3), r1 = RP(1, 3), r2 = RP(2, 2), r3 = RP(3, 1), r4 = RP(3, 0), r5 = RP(3, -1), r6 = RP(2, -2), r7 = RP(1, -3);
+    const uint32_t r8 = RP(0, -3), r9 = RP(-1, -3), r10 = RP(-2, -2), r11 = RP(-3, -1), r12 = RP(-3, 0), r13 = RP(-3, 1), r14 = RP(-2, 2), r15 = RP(-1, 3);
+#undef RP
+    const s16x2 vv = as_s16x2(v | v << 16);
+    const s16x2 R[8] = {vv - as_s16x2(r0 | r8 << 16),  vv - as_s16x2(r1 | r9 << 16),  vv - as_s16x2(r2 | r10 << 16), vv - as_s16x2(r3 | r11 << 16),
+                        vv - as_s16x2(r4 | r12 << 16), vv - as_s16x2(r5 | r13 << 16), vv - as_s16x2(r6 | r14 << 16), vv - as_s16x2(r7 | r15 << 16)};
+    s16x2 pn[8], sn[8], px[8], sx[8];
+    pn[0] = R[0]; px[0] = R[0]; sn[7] = R[7]; sx[7] = R[7];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) P[j] = vv - as_s16x2((uint32_t)r[2 * j] | (uint32_t)r[2 * j + 1] << 16);
+    for (int k = 1; k < 8; ++k) { pn[k] = pk_min(pn[k - 1], R[k]); px[k] = pk_max(px[k - 1], R[k]); }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) // (d[2j+1], d[2j+2])
-        Q[j] = as_s16x2(__builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, P[(j + 1) & 7]), __builtin_bit_cast(uint32_t, P[j]), 2));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { n2[j] = pk_min(P[j], Q[j]); x2[j] = pk_max(P[j], Q[j]); }                       // over positions k, k+1
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { n4[j] = pk_min(n2[j], n2[(j + 1) & 7]); x4[j] = pk_max(x2[j], x2[(j + 1) & 7]); } // k .. k+3
+    for (int k = 6; k >= 0; --k) { sn[k] = pk_min(sn[k + 1], R[k]); sx[k] = pk_max(sx[k + 1], R[k]); }
     s16x2 bright = {(short)-32768, (short)-32768}, dark = {(short)32767, (short)32767};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {                                                                                  // k .. k+8
-        bright = pk_max(bright, pk_min(pk_min(n4[j], n4[(j + 2) & 7]), P[(j + 4) & 7]));
-        dark = pk_min(dark, pk_max(pk_max(x4[j], x4[(j + 2) & 7]), P[(j + 4) & 7]));
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t pnk = __builtin_bit_cast(uint32_t, pn[k]), pxk = __builtin_bit_cast(uint32_t, px[k]);
+        bright = pk_max(bright, pk_min(sn[k], as_s16x2(__builtin_amdgcn_alignbit(pnk, pnk, 16))));
+        dark = pk_min(dark, pk_max(sx[k], as_s16x2(__builtin_amdgcn_alignbit(pxk, pxk, 16))));
     }
     const int a0 = max(thr, max((int)bright.x, (int)bright.y));
     const int b0 = -min((int)dark.x, (int)dark.y);
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(LevelTable T, const uint8
     for (int q = threadIdx.x; q < nq; q += 256) {
         const int i = queue[q];
         const int sy = i / kScW, sx = i - sy * kScW;
-        const int score = fast_score<kPixPitch>(&pix[(sy + 3) * kPixPitch + sx + 3], thr);
+        const int score = fast_score<kPixPitch>(&pix[sy * kPixPitch + sx], thr);
         if (score >= thr) { sc[i] = (uint8_t)score; cqueue[atomicAdd(&ccount, 1)] = (uint16_t)i; }
     }
     __syncthreads();
@@ -1607,7 +1612,7 @@ struct PyrBlurArgs {
 __device__ inline int mbcnt64(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void orb_pyrblur_kernel(PyrBlurArgs a) {
+__global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) { // (four tiles per CU: 8 waves per SIMD at NW = 8)
     constexpr int NT = 64 * NW;
     const int b = blockIdx.y;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
@@ -1791,7 +1796,7 @@ __global__ __launch_bounds__(64 * NW) void orb_pyrblur_kernel(PyrBlurArgs a) {
         if (lane < cnt) {
             id = wq[first + lane];
             const int R = id >> 9, c = id & 511;
-            const int s = fast_score<kBlurRawPitch>(raw + R * kBlurRawPitch + c, thr);
+            const int s = fast_score<kBlurRawPitch>(raw + (R - 3) * kBlurRawPitch + c - 3, thr);
             if (s >= thr) {
                 sc[(R - 3) * kPfScPitch + c] = (uint8_t)s;
                 const int tcx = c - 4, tcy = R - 4; // tile coordinates: only positions this tile emits go on to the NMS
@@ -1835,7 +1840,7 @@ __global__ __launch_bounds__(64 * NW) void orb_pyrblur_kernel(PyrBlurArgs a) {
         constexpr int kRows = kBlurTileH / NW;                      // centre rows per wave (+ 2 for the last wave)
         constexpr int kG = NW == 4 ? 6 : 4;                         // centre rows per group: their kG + 6 raw rows are widened once
         constexpr int kGroups = (kRows + 2 + kG - 1) / kG;
-        static_assert(kRows * (NW - 1) + kGroups * kG + 6 <= kPfRawH + 2, "the pre-test reads at most two rows past the staged tile");
+        static_assert(kRows * (NW - 1) + kGroups * kG + 6 <= kPfRawH + 8, "the pre-test reads a few rows past the staged tile (into the score tile), for centre rows it skips");
         const int cb0 = kRows * wave - 1;                                                  // first centre row (tile coordinates) of this wave
         const int c_last = wave == NW - 1 ? kBlurTileH : cb0 + kRows - 1;                  // last one it owns (the next wave starts one row above its band)
         const int o_lo = max(cb0, vy_lo), o_hi = min(c_last, vy_hi);
@@ -1875,11 +1880,9 @@ __global__ __launch_bounds__(64 * NW) void orb_pyrblur_kernel(PyrBlurArgs a) {
                 // banks); the four pushes are ONE site in a rolled loop: the score code is inlined once per row, not once per push
                 const unsigned long long m0 = __ballot((int)mE.x > thr) & colm[0], m1 = __ballot((int)mO.x > thr) & colm[1];
                 const unsigned long long m2 = __ballot(__builtin_bit_cast(int, mE) > thr_hi) & colm[2], m3 = __ballot(__builtin_bit_cast(int, mO) > thr_hi) & colm[3];
-                if (OPH_ON()) OPH(36);
                 const int idr = ((cb + 4 + j) << 9) + idv;
 #pragma unroll 1
                 for (int k = 0; k < 4; ++k) push(k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : m3, idr + k);
-                if (OPH_ON()) OPH(37);
             }
         }
     }
