@@ -118,8 +118,19 @@ def other_rooflines(prof, pipe, args, n_steps, copy_gbs):
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "note": "ORB-family algorithmic bytes per step over THIS kernel's time"})
     if orb_total_ms > 0:
         gbs = orb_alg / (orb_total_ms / 1e3) / 1e9
-        out.append({"kernel": "orb_* (family)", "bound": "hbm", "ms_per_step": round(orb_total_ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # counter traffic of the family per step (profiles/traffic_orb.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes on these sources, same batch)
+        oj, osrc = load_counter_json("traffic_orb.json")
+        n_img = pipe.B if pipe.depth == "sgbm" else 2 * pipe.B
+        otraffic = None
+        if oj is not None:
+            if oj.get("batch") == pipe.B:
+                otraffic = int(oj["hbm_bytes_per_launch_set"])
+            else:
+                osrc = "profiles/traffic_orb.json was measured at batch %s, not %d" % (oj.get("batch"), pipe.B)
+        out.append({"kernel": "orb_* (family)", "bound": "hbm", "ms_per_step": round(orb_total_ms, 4), "ms_per_1024_images": round(orb_total_ms * 1024.0 / n_img, 4),
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(orb_alg),
+                    "traffic": otraffic, "traffic_per_1024_images": None if otraffic is None else int(otraffic * 1024.0 / n_img), "traffic_source": osrc,
                     "frac_of_copy_ceiling": round(gbs / copy_gbs, 5) if copy_gbs > 0 else None})
     # ORB is bound by VALU issue, not by bytes: the right ruler is wave-instructions per second.  SQ_INSTS_VALU per image
     # from the counter pass (profiles/orb_valu.json, tools/profile_sq.sh); a wave64 integer / packed-16 instruction holds its SIMD ~4 cycles.
@@ -397,6 +408,8 @@ def ba_config4_measure(args, local, torch):
         if int((pipe.vo.ba_status(B) != 0).sum()):
             return {"error": "windows rejected"}
         pipe.ba_passes = pipe.vo.ba_schedule_passes(B)
+        nd = int(pipe.vo.ba_deferred(B).sum())   # windows ba_resident_kernel left to lm_window_kernel (config 4's 3.5 observations per landmark: all of them)
+        ran = "lm_window_kernel+pose_only_wave_kernel" if nd == B else ("ba_resident_kernel+pose_only_wave_kernel" if nd == 0 else "ba_resident_kernel+lm_window_kernel+pose_only_wave_kernel")
         pipe.vo.set_tuning(ba_adaptive=0)   # ... and every pass for every window, three launches (the schedule of rounds 1-3)
         pipe.stage_ba(); pipe.vo.profile_read()
         pipe.vo.profile_enable(True)
@@ -412,7 +425,8 @@ def ba_config4_measure(args, local, torch):
         res = {"workload": "BA schedule (5+5+10 LM + 10 pose-only) on %d unique synthetic windows, 10 KF x 3000 landmarks x %.0f edges" % (B, pipe.edges_per_window),
                "ms_per_schedule_batch": round(ms, 4), "wall_ms_per_schedule_batch": round(1e3 * wall, 4), "windows_per_s": round(B / (ms / 1e3), 1),
                "schedule": schedule_stats(pipe.ba_passes), "plain_schedule_ms_per_batch": round(prof_plain["lm_window_kernel"][0] / n, 4),
-               "roofline": {"bound": "hbm", "kernel": "lm_window_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "roofline": {"bound": "hbm", "kernel": ran, "stage_family": "lm_window_kernel", "windows_left_to_lm_window_kernel": nd,
+                            "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": src,
                             "algorithmic_bytes_per_launch_set": int(alg), "formula": formula},
                "other_rooflines": [r for r in other_rooflines(prof, pipe, args, n, 0.0) if r["kernel"] == "lm_window_kernel"]}
@@ -973,6 +987,21 @@ def main():
             else:
                 traffic_src = "profiles/%s was measured for kernel %s at batch %s, not %s at %d" % (tname, tj.get("kernel"), tj.get("batch"), dom, B)
         nt = max(B - 1, 1)
+        # the roofline line is named after the kernels that ran inside the dominant stage bracket (the BA schedule's bracket keeps the family name
+        # `lm_window_kernel` of rounds 1-4): vslam_ba_deferred_dev says which windows ba_resident_kernel took
+        dom_kernels = dom; res_deferred = None
+        if dom == "lm_window_kernel" and pipe.with_ba:
+            try:
+                nd = int(pipe.vo.ba_deferred(n_ba_windows).sum())
+            except Exception:
+                nd = n_ba_windows
+            if nd == 0:
+                dom_kernels = "ba_resident_kernel+pose_only_wave_kernel"
+            elif nd == n_ba_windows:
+                dom_kernels = "lm_window_kernel+pose_only_wave_kernel"
+            else:
+                dom_kernels = "ba_resident_kernel+lm_window_kernel+pose_only_wave_kernel"
+            res_deferred = nd
         pose_txt = ("motion-only LM pose (10 its)" if args.pose == "lm" else
                     "solvePnPRansac(100, 4.0, 0.99) pose [the reference's own pose stage; not the BASELINE metric]")
         win_txt = ("BA windows built on the device from this step's own tracks (window b = keyframes [b-9, b]: poses = chained pose-stage estimates, "
@@ -1018,7 +1047,9 @@ def main():
                                                                                 "(three launches; vslam_set_tuning ba_adaptive = 0)"}),
                        "stage_profiler": "off in the timed repeats; on in one extra repeat of the same %d steps with ONE batch in flight (%.4f ms/step) that feeds "
                                          "`roofline` and `kernels_ms_per_step`" % (args.steps, 1e3 * profiled_s / args.steps)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom_kernels, "stage_family": dom,
+                         "windows_left_to_lm_window_kernel": (res_deferred if dom == "lm_window_kernel" and pipe.with_ba else None),
+                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_gbs": round(copy_gbs, 1), "copy_probe": copy_probe, "copy_ceiling_guide_gbs": 6290.0, "frac_of_copy_ceiling": round(achieved / copy_gbs, 6) if copy_gbs > 0 else None,
                          "algorithmic_bytes_per_launch_set": int(alg), "formula": formula,
@@ -1095,22 +1126,26 @@ def main():
             for k_ in ks:
                 d = d.get(k_) if isinstance(d, dict) else None
             return d
-        res["config"]["extras"] = {
-            "one_batch_in_flight_keyframes_per_s": _g(res, "timing", "in_flight", "one_batch_in_flight", "value"),
-            "plain_ba_schedule_keyframes_per_s": _g(res, "timing", "ba_schedule", "plain_schedule", "value"),
+        # [r6] FLAT scalar keys of `config` (round 5 nested them under config.extras, which a parser that keeps scalar config keys dropped)
+        orb_fam = [r for r in res["other_rooflines"] if r.get("kernel") == "orb_* (family)"]
+        res["config"].update({
+            "one_in_flight_kfps": _g(res, "timing", "in_flight", "one_batch_in_flight", "value"),
+            "plain_ba_schedule_kfps": _g(res, "timing", "ba_schedule", "plain_schedule", "value"),
             "overlap_share_two_or_more_kernels": _g(res, "timing", "in_flight", "overlap", "overlap_share"),
             "sum_kernel_ms_over_span_ms": _g(res, "timing", "in_flight", "overlap", "sum_kernel_ms_over_span_ms"),
-            "inputs_from_host_keyframes_per_s": _g(res, "inputs_from_host", "value"),
-            "value_config4_windows_keyframes_per_s": _g(res, "value_config4_windows", "value"),
-            "reference_pipeline_keyframes_per_s": _g(res, "reference_pipeline", "value"),
+            "inputs_from_host_kfps": _g(res, "inputs_from_host", "value"),
+            "value_config4_windows_kfps": _g(res, "value_config4_windows", "value"),
+            "reference_pipeline_kfps": _g(res, "reference_pipeline", "value"),
             "reference_pipeline_sgbm_ms_per_pair": _g(res, "reference_pipeline", "roofline", "ms_per_pair"),
-            "ba_config4_ms_per_schedule_batch_256": _g(res, "ba_config4", "ms_per_schedule_batch"),
+            "ba_config4_ms_per_256": _g(res, "ba_config4", "ms_per_schedule_batch"),
             "ba_built_windows_ms_per_schedule_batch": _g(res, "roofline", "avg_ms_per_launch_set"),
-            "live_dropin_frames_per_s": _g(res, "live_dropin", "gpu", "frames_per_s"),
-            "live_dropin_keyframes_per_s": _g(res, "live_dropin", "gpu", "keyframes_per_s"),
-            "live_dropin_cpu_path_frames_per_s": _g(res, "live_dropin", "cpu", "frames_per_s"),
+            "orb_family_ms_per_1024_images": orb_fam[0].get("ms_per_1024_images") if orb_fam else None,
+            "orb_family_traffic_bytes_per_1024_images": orb_fam[0].get("traffic_per_1024_images") if orb_fam else None,
+            "live_dropin_fps": _g(res, "live_dropin", "gpu", "frames_per_s"),
+            "live_dropin_kfps": _g(res, "live_dropin", "gpu", "keyframes_per_s"),
+            "live_dropin_cpu_path_fps": _g(res, "live_dropin", "cpu", "frames_per_s"),
             "pose_rmse_vs_oracle_m": _g(res, "pose_rmse_vs_oracle", "ba_translation_rmse_m"),
-        }
+        })
         print(json.dumps(res), flush=True)
     ring.close()
     if world > 1:

@@ -332,6 +332,11 @@ int vslam_ba_status_dev(vslam_ctx* ctx, int n_windows, int32_t* h_status);
  * poses and landmarks; only the flags carry over) and it was continued to the last pass's 10 iterations instead -- same result, 10 or 15 LM
  * iterations instead of 20.  vslam_set_tuning(ctx, "ba_adaptive", 0) runs every pass.  Synchronises the context stream. */
 int vslam_ba_schedule_passes_dev(vslam_ctx* ctx, int n_windows, int32_t* h_passes);
+/* Which kernel took each window of the most recent vslam_ba_batch_dev / vslam_local_ba call (optimization.cpp:103-288): h_deferred[w] = 0 when
+ * ba_resident_kernel (landmark state in LDS) ran its optimize_map passes, 1 when it was left to lm_window_kernel (state in HBM: the window does not
+ * fit half a CU's LDS, is denser than 2.2 observations per landmark, or the call did not involve the resident kernel).  Diagnostic for the
+ * measurement tier (bench.py names the roofline kernel after what ran); synchronises the context stream. */
+int vslam_ba_deferred_dev(vslam_ctx* ctx, int n_windows, int32_t* h_deferred);
 
 /* Diagnostic (rows A10 / A11): the residual and the Jacobians of EdgeProjection (optimization.cpp:41-73) and PoseOnlyEdgeProjection
  * (:75-101) as THE DEVICE CODE OF THE LM KERNELS evaluates them -- the same device functions (normalised-coordinate factors At, Bt,

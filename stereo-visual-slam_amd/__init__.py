@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "vslam_orb_compute", "vslam_feature_detection_dev", "vslam_feature_matching", "vslam_feature_matching_dev",
     "vslam_find_3d_disparity", "vslam_triangulate", "vslam_triangulate_dev", "vslam_gather_matched_uv_dev",
     "vslam_pnp_motion_only", "vslam_pnp_motion_only_dev", "vslam_check_motion", "vslam_local_ba",
-    "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_ba_schedule_passes_dev", "vslam_edge_jacobians", "vslam_orb_status_dev", "vslam_orb_level", "vslam_dev_alloc",
+    "vslam_pose_only_window", "vslam_ba_batch_dev", "vslam_ba_status_dev", "vslam_ba_schedule_passes_dev", "vslam_ba_deferred_dev", "vslam_edge_jacobians", "vslam_orb_status_dev", "vslam_orb_level", "vslam_dev_alloc",
     "vslam_dev_free", "vslam_dev_upload", "vslam_dev_download", "vslam_dev_memset", "vslam_build_pnp_inputs_dev",
     "vslam_profile_enable", "vslam_profile_read", "vslam_profile_intervals", "vslam_hbm_copy_probe", "vslam_disparity_map", "vslam_disparity_map_dev", "vslam_pnp_ransac", "vslam_pnp_ransac_models", "vslam_find_3d_disparity_dev",
     "vslam_abi_version", "vslam_hbm_copy_probe_variants", "vslam_hbm_copy_probe_variant", "vslam_sgbm_status_dev", "vslam_set_tuning", "vslam_build_windows_dev", "vslam_pnp_ransac_dev",
@@ -475,6 +475,12 @@ class VO:
         self._chk(self.lib.vslam_edge_jacobians(self.h, n, _p(xyz), _p(z), _p(T), _p(K4) if K4 is not None else None, _p(out["err"]), _p(out["J_pose"]),
                                                 _p(out["J_point"]), _p(out["chi2"]), _p(out["huber_w"])), "vslam_edge_jacobians")
         return out
+
+    def ba_deferred(self, n_windows):
+        """per window of the last BA launch: 0 = ba_resident_kernel ran it, 1 = lm_window_kernel did"""
+        st = np.zeros(n_windows, np.int32)
+        self._chk(self.lib.vslam_ba_deferred_dev(self.h, int(n_windows), _p(st)), "vslam_ba_deferred_dev")
+        return st
 
     def ba_schedule_passes(self, n_windows):
         """optimize_map passes the last schedule executed per window (3, or 1 / 2 when a pass flagged nothing new and was continued instead of repeated)"""

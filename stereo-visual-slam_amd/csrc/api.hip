@@ -1040,6 +1040,13 @@ int vslam_ba_schedule_passes_dev(vslam_ctx* ctx, int n_windows, int32_t* h_passe
     return lm_fetch_passes(&c->lm, n_windows, h_passes, c->stream);
 }
 
+int vslam_ba_deferred_dev(vslam_ctx* ctx, int n_windows, int32_t* h_deferred) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !h_deferred || n_windows <= 0) return VSLAM_ERR_ARG;
+    VS_ENTER(c);
+    return lm_fetch_deferred(&c->lm, n_windows, h_deferred, c->stream);
+}
+
 // ---------------------------------------------------------------------------------------------- profiling + glue
 int vslam_profile_enable(vslam_ctx* ctx, int on) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);

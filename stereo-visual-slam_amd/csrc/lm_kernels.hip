@@ -1971,6 +1971,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
     // optimize_map passes: ba_resident_kernel takes every window whose landmark state fits the LDS of a CU (Tuning::ba_resident = 0: none) and marks
     // the others in `defer`; lm_window_kernel then runs with that list and returns at once for the windows that are done
     const bool resident = (schedule || mode == 0) && !(scratch->tune && scratch->tune->ba_resident == 0);
+    scratch->defer_valid = resident;
     if (resident) {
         if (scratch->rs_dyn_bytes < 0) { int dev = 0; (void)hipGetDevice(&dev); scratch->rs_dyn_bytes = rs_dyn_lds_bytes(dev); }
         RsLaunch L;
@@ -2030,6 +2031,15 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         for (int i = 0; i < kDbgSlots; ++i) { double s = 0; for (int w = 0; w < a.n_windows; ++w) s += (double)h[kDbgSlots * (size_t)w + i]; s /= a.n_windows; if (i < 13 || i >= 16) tot += s; fprintf(stderr, "  [lm profile] %-20s %10.0f ticks/window\n", names[i], s); }
         fprintf(stderr, "  [lm profile] total %.0f cycles (clock64 = shader clock, thread 0 of every window; setup sub-splits not included)\n", tot);
     }
+    return VSLAM_OK;
+}
+
+int lm_fetch_deferred(const LmScratch* scratch, int n_windows, int32_t* h_defer, hipStream_t stream) {
+    if (!scratch->buf || !scratch->defer || !h_defer || n_windows > scratch->status_n) return VSLAM_ERR_ARG;
+    if (!scratch->defer_valid) { for (int w = 0; w < n_windows; ++w) h_defer[w] = 1; return VSLAM_OK; } // the last launch did not involve ba_resident_kernel: every window on lm_window_kernel
+    VS_HIP(hipMemcpyAsync(h_defer, scratch->defer, sizeof(int32_t) * n_windows, hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    for (int w = 0; w < n_windows; ++w) h_defer[w] &= 1;
     return VSLAM_OK;
 }
 

@@ -220,6 +220,7 @@ struct LmScratch {
     bool rs_opt_in = false;  // ... of ba_resident_kernel
     int rs_dyn_bytes = -1;   // dynamic LDS a ba_resident_kernel workgroup may use on this context's device (-1: not queried yet)
     int32_t* defer = nullptr; // per window of the most recent launch: 1 = left to lm_window_kernel by ba_resident_kernel
+    bool defer_valid = false; // ... written by that launch (it involved ba_resident_kernel)
 };
 // ba_resident.hip: optimize_map / the BA schedule on windows whose landmark state fits the LDS of one CU (the rest is marked in `defer`)
 struct RsLaunch {
@@ -237,6 +238,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
 size_t lm_hits_per_edge();
 int lm_fetch_status(const LmScratch* scratch, int n_windows, int32_t* h_status, hipStream_t stream);
 int lm_fetch_passes(const LmScratch* scratch, int n_windows, int32_t* h_passes, hipStream_t stream);
+int lm_fetch_deferred(const LmScratch* scratch, int n_windows, int32_t* h_defer, hipStream_t stream);
 
 struct PnpArgs {
     const float* xyz; const float* uv; const int32_t* n; int capacity; int B;

@@ -30,7 +30,10 @@ def test_bench_line_contract():
     rf = r["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernel"] == "lm_window_kernel"
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    # [r6] the roofline line is named after the kernels that ran in the BA bracket (the windows built from tracks all fit ba_resident_kernel), the stage
+    # profiler's family name stays beside it
+    assert rf["kernel"] == "ba_resident_kernel+pose_only_wave_kernel" and rf["stage_family"] == "lm_window_kernel" and rf["windows_left_to_lm_window_kernel"] == 0
     assert rf["copy_ceiling_gbs"] > 3000
     cb = r["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
@@ -46,7 +49,7 @@ def test_bench_line_contract():
     assert "build_windows_kernels" in r["kernels_ms_per_step"]
     # ... the same run measures the BA schedule on the config-4 shape and the reference's own stages (SGBM depth + RANSAC pose)
     c4 = r["ba_config4"]
-    assert c4["ms_per_schedule_batch"] > 0 and c4["roofline"]["kernel"] == "lm_window_kernel" and "traffic" in c4["roofline"]
+    assert c4["ms_per_schedule_batch"] > 0 and c4["roofline"]["kernel"] == "lm_window_kernel+pose_only_wave_kernel" and c4["roofline"]["windows_left_to_lm_window_kernel"] == 256 and "traffic" in c4["roofline"]
     rp = r["reference_pipeline"]
     assert rp["value"] > 0 and rp["unit"] == "keyframes/s" and rp["roofline"]["kernel"].startswith("sgbm_*") and rp["stats"]["ransac_inliers"] > 10
     assert "pnp_epnp_kernels" in rp["kernels_ms_per_step"] and "sgbm_down_kernel" in rp["kernels_ms_per_step"] or rp["batch"] < 8
@@ -64,10 +67,14 @@ def test_bench_line_contract():
     assert v4["value"] > 0 and v4["unit"] == "keyframes/s" and v4["batch"] == 16
     ld = r["live_dropin"]
     assert ld["gpu"]["frames"] == 50 and ld["gpu"]["frames_per_s"] > 1 and ld["gpu"]["keyframes_per_s"] > 0 and ld["cpu"]["frames_per_s"] > 0
-    ex = r["config"]["extras"]
-    assert ex["value_config4_windows_keyframes_per_s"] == v4["value"] and ex["reference_pipeline_keyframes_per_s"] == rp["value"]
-    assert ex["ba_config4_ms_per_schedule_batch_256"] == c4["ms_per_schedule_batch"] and ex["one_batch_in_flight_keyframes_per_s"] == fl["one_batch_in_flight"]["value"]
-    assert ex["live_dropin_frames_per_s"] == ld["gpu"]["frames_per_s"] and ex["overlap_share_two_or_more_kernels"] == ov["overlap_share"]
+    # [r6] ... as FLAT scalar keys of `config` (no nested dict: a parser that keeps the scalar keys of `config` keeps them)
+    ex = r["config"]
+    assert "extras" not in ex and all(not isinstance(v, (dict, list)) for v in ex.values())
+    assert ex["value_config4_windows_kfps"] == v4["value"] and ex["reference_pipeline_kfps"] == rp["value"]
+    assert ex["ba_config4_ms_per_256"] == c4["ms_per_schedule_batch"] and ex["one_in_flight_kfps"] == fl["one_batch_in_flight"]["value"]
+    assert ex["live_dropin_fps"] == ld["gpu"]["frames_per_s"] and ex["overlap_share_two_or_more_kernels"] == ov["overlap_share"]
+    fam = [o for o in r["other_rooflines"] if o["kernel"] == "orb_* (family)"][0]
+    assert "traffic" in fam and ex["orb_family_ms_per_1024_images"] == fam["ms_per_1024_images"] > 0
     assert fl["one_batch_in_flight"]["value"] > 0 and r["inputs_from_host"]["batches_in_flight"] == 2
     assert rp["batches_in_flight"] == 2 and rp["one_batch_in_flight"]["value"] > 0
     # the BA schedule continues a pass that flags nothing new instead of repeating it: the line says what it did and carries the plain schedule's figure
