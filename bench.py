@@ -534,6 +534,45 @@ def live_dropin_measure(n_frames=50, anms=500, with_cpu=True, cpu_frames=12):
         return res
 
 
+def kitti_measure(n_frames=50, anms=500):
+    """Real-data hook: when KITTI_ROOT names a KITTI odometry tree on this box ($KITTI_ROOT/sequences/00/image_0/%06d.png, or the
+    sequence directory itself), the first `n_frames` pairs of sequence 00 go through the drop-in host/run_vslam exactly as visual_odometry.cpp:37-68
+    reads them, and the per-frame trace is condensed to detection / match / inlier statistics.  No KITTI on the box: {"available": False}."""
+    import subprocess
+    import tempfile
+    root = os.environ.get("KITTI_ROOT")
+    if not root:
+        return {"available": False, "reason": "KITTI_ROOT not set"}
+    cands = [os.path.join(root, "sequences", "00"), os.path.join(root, "dataset", "sequences", "00"), os.path.join(root, "00"), root]
+    seq = next((c for c in cands if os.path.exists(os.path.join(c, "image_0", "000000.png")) and os.path.exists(os.path.join(c, "image_1", "000000.png"))), None)
+    if seq is None:
+        return {"available": False, "reason": "no image_0/000000.png + image_1/000000.png under KITTI_ROOT=%s (tried sequences/00, dataset/sequences/00, 00, .)" % root}
+    exe = os.path.join(ROOT, "stereo-visual-slam_amd", "host", "run_vslam")
+    if not os.path.exists(exe):
+        return {"available": True, "error": "host/run_vslam not built"}
+    n = 0
+    while n < n_frames and os.path.exists(os.path.join(seq, "image_0", "%06d.png" % n)):
+        n += 1
+    with tempfile.TemporaryDirectory() as d:
+        trace = os.path.join(d, "trace.txt")
+        r = subprocess.run([exe, seq + "/", str(n), "0", str(anms), os.path.join(d, "traj.txt"), "1", "1", "1", trace], capture_output=True, text=True, timeout=1500)
+        if r.returncode != 0:
+            return {"available": True, "sequence_dir": seq, "error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
+        det, mat, inl, lms = [], [], [], []
+        for line in open(trace):
+            t = line.split()
+            if t and t[0] == "frame":
+                kv = {t[i]: t[i + 1] for i in range(1, len(t) - 1, 2) if t[i] in ("det", "matches", "inliers", "landmarks")}
+                det.append(int(kv.get("det", 0))); mat.append(int(kv.get("matches", 0))); inl.append(int(kv.get("inliers", 0))); lms.append(int(kv.get("landmarks", 0)))
+        out = {"available": True, "sequence_dir": seq, "frames": n, "config": "ANMS %d, SGBM depth, solvePnPRansac pose, BA schedule per keyframe (the reference's configuration)" % anms,
+               "summary": [l for l in r.stdout.splitlines() if l.startswith("frames ")][-1:], "final_position": [l for l in r.stdout.splitlines() if l.startswith("final_position")][-1:],
+               "timing": [l for l in r.stdout.splitlines() if l.startswith("timing ")][-1:]}
+        if det:
+            out.update(keypoints_per_frame_mean=float(np.mean(det)), keypoints_per_frame_min=int(min(det)), f2f_matches_mean=float(np.mean(mat[1:] or [0])),
+                       pnp_inliers_mean=float(np.mean(inl[1:] or [0])), pnp_inliers_min=int(min(inl[1:] or [0])), landmarks_in_map_last=int(lms[-1]))
+        return out
+
+
 def reference_pipeline_measure(args, local, torch, seq, B=256):
     """The REFERENCE's own stages in throughput mode, measured in the default run so that the driver records it: depth from StereoSGBM +
     Frame::find_3d on the left keypoints (visual_odometry.cpp:159-217) instead of L/R match + DLT, pose from cv::solvePnPRansac(..., 100, 4.0,
@@ -1101,6 +1140,10 @@ def main():
                     res["live_dropin"] = live_dropin_measure(with_cpu=not args.no_cpu_baseline)
                 except Exception as e:
                     res["live_dropin"] = {"error": repr(e)}
+                try:   # real KITTI pairs, when the box has them (KITTI_ROOT); otherwise a one-line "not available"
+                    res["kitti_seq00"] = kitti_measure()
+                except Exception as e:
+                    res["kitti_seq00"] = {"available": None, "error": repr(e)}
         if extras_ok and not args.no_cpu_baseline:
             res["cpu_baseline"], res["pose_rmse_vs_oracle"] = (cpu_baseline_tracks if pipe.ba_windows == "tracks" else cpu_baseline)(pipe, out, args.anms)
             info, have_cv2 = host_info()
@@ -1141,6 +1184,7 @@ def main():
             "ba_built_windows_ms_per_schedule_batch": _g(res, "roofline", "avg_ms_per_launch_set"),
             "orb_family_ms_per_1024_images": orb_fam[0].get("ms_per_1024_images") if orb_fam else None,
             "orb_family_traffic_bytes_per_1024_images": orb_fam[0].get("traffic_per_1024_images") if orb_fam else None,
+            "kitti_seq00_available": _g(res, "kitti_seq00", "available"),
             "live_dropin_fps": _g(res, "live_dropin", "gpu", "frames_per_s"),
             "live_dropin_kfps": _g(res, "live_dropin", "gpu", "keyframes_per_s"),
             "live_dropin_cpu_path_fps": _g(res, "live_dropin", "cpu", "frames_per_s"),

@@ -386,8 +386,8 @@ typedef struct vslam_kernel_time {
 } vslam_kernel_time;
 int vslam_profile_enable(vslam_ctx* ctx, int on);
 int vslam_profile_read(vslam_ctx* ctx, vslam_kernel_time* out, int cap, int* n_out);
-/* The same brackets as INTERVALS on one time axis for the whole process (milliseconds since the first vslam_profile_enable(.., 1) of any context
- * on the device): with several contexts / streams in flight together this is what tells how much their kernel families overlap.  Synchronises
+/* The same brackets as INTERVALS on one time axis PER DEVICE (milliseconds since the first vslam_profile_enable(.., 1) of any context of this
+ * process on the context's device; contexts on different devices have different origins -- HIP events of two devices share no clock): with several contexts / streams in flight together this is what tells how much their kernel families overlap.  Synchronises
  * the stream, returns up to `cap` brackets recorded since the last read of either kind (in launch order) and resets, like vslam_profile_read. */
 typedef struct vslam_stage_interval {
     char name[48];

@@ -439,7 +439,7 @@ class VO:
         return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches, buf[i].calls) for i in range(n.value)}
 
     def profile_intervals(self, cap=4096):
-        """[(kernel family, t0_ms, t1_ms)] of the brackets recorded since the last read, on the process-wide time axis (comparable across contexts)"""
+        """[(kernel family, t0_ms, t1_ms)] of the brackets recorded since the last read, on the device's time axis (comparable across the contexts of one device)"""
         buf = (StageInterval * cap)(); n = C.c_int()
         self._chk(self.lib.vslam_profile_intervals(self.h, buf, cap, C.byref(n)), "vslam_profile_intervals")
         return [(buf[i].name.decode(), buf[i].t0_ms, buf[i].t1_ms) for i in range(n.value)]

@@ -14,6 +14,8 @@
 #include "se3_device.h"
 #include "vslam_internal.h"
 
+#include <mutex>
+
 namespace vslam {
 
 static thread_local char g_err[512] = "";
@@ -38,7 +40,10 @@ struct Prof {
     }
 };
 static thread_local Prof* g_prof = nullptr;
-static hipEvent_t g_prof_origin = nullptr; // time origin shared by every context's brackets (vslam_profile_intervals)
+// time origin shared by the brackets of every context ON ONE DEVICE (vslam_profile_intervals; events of different devices have no common clock):
+// one event per device, created under a mutex by the first context of that device that profiles
+static hipEvent_t g_prof_origin[16] = {nullptr};
+static std::mutex g_prof_origin_mu;
 Prof* prof_current() { return g_prof; }
 void prof_set_current(Prof* p) { g_prof = p; }
 void prof_begin(hipStream_t s, const char* name, int launches) {
@@ -1052,11 +1057,17 @@ int vslam_profile_enable(vslam_ctx* ctx, int on) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return VSLAM_ERR_ARG;
     if (!c->prof) c->prof = new Prof();
-    if (on && !g_prof_origin) { // the common time origin of vslam_profile_intervals: recorded once per process, on the first context that profiles
-        VS_HIP(hipSetDevice(c->device));
-        VS_HIP(hipEventCreate(&g_prof_origin));
-        VS_HIP(hipEventRecord(g_prof_origin, c->stream));
-        VS_HIP(hipEventSynchronize(g_prof_origin));
+    if (on) { // the common time origin of vslam_profile_intervals: recorded once per device, on the first context that profiles there
+        if (c->device < 0 || c->device >= 16) { set_error("vslam_profile_enable: device %d beyond the profiler's table (16)", c->device); return VSLAM_ERR_ARG; }
+        std::lock_guard<std::mutex> lock(g_prof_origin_mu);
+        if (!g_prof_origin[c->device]) {
+            hipEvent_t ev = nullptr;
+            VS_HIP(hipSetDevice(c->device));
+            VS_HIP(hipEventCreate(&ev));
+            VS_HIP(hipEventRecord(ev, c->stream));
+            VS_HIP(hipEventSynchronize(ev));
+            g_prof_origin[c->device] = ev;
+        }
     }
     c->prof->on = on != 0;
     prof_set_current(on ? c->prof : nullptr);
@@ -1096,14 +1107,15 @@ int vslam_profile_intervals(vslam_ctx* ctx, vslam_stage_interval* out, int cap, 
     if (!c || !out || !n_out || cap <= 0) return VSLAM_ERR_ARG;
     *n_out = 0;
     Prof* p = c->prof;
-    if (!p || !g_prof_origin) return VSLAM_OK;
+    hipEvent_t origin = (c->device >= 0 && c->device < 16) ? g_prof_origin[c->device] : nullptr;
+    if (!p || !origin) return VSLAM_OK;
     VS_ENTER(c);
     VS_HIP(hipStreamSynchronize(c->stream));
     int n = 0;
     for (const Prof::Rec& r : p->recs) {
         if (n < cap) {
             float a0 = 0.f, a1 = 0.f;
-            if (hipEventElapsedTime(&a0, g_prof_origin, r.e0) == hipSuccess && hipEventElapsedTime(&a1, g_prof_origin, r.e1) == hipSuccess) {
+            if (hipEventElapsedTime(&a0, origin, r.e0) == hipSuccess && hipEventElapsedTime(&a1, origin, r.e1) == hipSuccess) {
                 memset(&out[n], 0, sizeof(out[n]));
                 strncpy(out[n].name, r.name, sizeof(out[n].name) - 1);
                 out[n].t0_ms = a0; out[n].t1_ms = a1;

@@ -1350,7 +1350,7 @@ int launch_ba_resident(const RsLaunch& L, hipStream_t stream) {
     ra.a = L.a;
     ra.uv_s = reinterpret_cast<float2*>(L.uv_s); ra.epos = L.epos; ra.tab = L.tab; ra.xin = L.xin; ra.Pbak = L.Pbak; ra.Dc = L.Dc; ra.blc = L.blc;
     ra.status = L.status; ra.passes = L.passes; ra.defer = L.defer; ra.order = L.order; ra.dbg = L.dbg;
-    ra.want_chi2 = L.a.chi2 != nullptr; ra.dense_to_general = L.dense_to_general;
+    ra.want_chi2 = L.want_chi2; ra.dense_to_general = L.dense_to_general;
     // width: more windows than CUs -> 256 lanes, two windows per CU (throughput); otherwise 512 lanes and the whole CU's LDS (a window's latency).
     // Both widths give the same bits (see kRsStreams), so the choice may depend on the launch.
     static int s_cus[16] = {0}, s_full[16] = {0};

@@ -1980,7 +1980,7 @@ int launch_lm_windows(const LmWindowArgs& a, int schedule, int mode, int iters, 
         L.status = ka.status; L.passes = ka.passes; L.defer = scratch->defer; L.order = ka.order; L.dbg = getenv("VSLAM_RS_PROFILE") ? ka.dbg_cycles : nullptr;
         L.lanes = (scratch->tune && scratch->tune->ba_lanes > 0) ? scratch->tune->ba_lanes : 0;
         L.dyn_bytes = scratch->rs_dyn_bytes; L.schedule = schedule; L.adaptive = adaptive ? 1 : 0; L.iters = iters; L.update_poses = update_poses; L.update_lms = update_lms;
-        L.opt_in_done = scratch->rs_opt_in;
+        L.opt_in_done = scratch->rs_opt_in; L.want_chi2 = ka.want_chi2;
         L.dense_to_general = !(scratch->tune && scratch->tune->ba_resident == 1);
         if (schedule && !adaptive) hipLaunchKernelGGL(lm_fill_kernel, dim3((a.n_windows + 255) / 256), dim3(256), 0, stream, ka.passes, a.n_windows, 3);
         rc = launch_ba_resident(L, stream);

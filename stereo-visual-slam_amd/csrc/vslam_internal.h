@@ -228,6 +228,7 @@ struct RsLaunch {
     void* uv_s; int32_t* epos; double* tab; double* xin; double* Pbak; double* Dc; double* blc; // scratch slices (see RsArgs)
     int32_t* status; int32_t* passes; int32_t* defer; const int32_t* order; long long* dbg;
     int dyn_bytes, schedule, adaptive, iters, update_poses, update_lms, dense_to_general;
+    int want_chi2;           // the CALLER asked for per-edge chi2 (L.a.chi2 is never null here: carve() substitutes scratch)
     int lanes;               // 256 | 512 forces a width of ba_resident_kernel (Tuning::ba_lanes); 0: by the number of windows in the launch
     bool opt_in_done;
 };

@@ -136,18 +136,28 @@ def sequence_windows_and_ba(pipe, total, rank, world, dist, rel_all):
     SEQUENCE's world (rel_all = every frame's relative pose, gathered; chained identically on every rank), the window builder continues the tracks
     that cross the chunk's start (carry from the previous rank), and the BA schedule runs on the windows of the frames this rank owns -- the same
     windows, bit for bit, as one unsharded pass over the sequence builds (tests/test_gpu_sequence.py).  Returns the local index of the first owned window."""
+    if total < world:
+        raise ValueError("sequence mode needs at least one frame per rank (%d frames, %d ranks): an empty shard would neither send nor need a carry" % (total, world))
     lo, hi = shard_range(total, rank, world)
     h_lo = halo_start(lo, WINDOW_HALO)
-    G = chain_poses(rel_all)                       # (total, 7): the same bits on every rank
-    T_abs = G[h_lo:hi]
     c_out = carry_out_frame(total, rank, world)
-    needs_in = h_lo > 0
-    buf = torch.zeros((pipe.cap, 4), dtype=torch.float32, device=rel_all.device)
-
-    def build(carry):
-        return pipe.stage_build_windows_chunk(T_abs, carry, c_out)
-
+    # sender and receiver decide from the SAME number: rank r expects a carry exactly when rank r - 1 sends one
+    needs_in = rank > 0 and carry_out_frame(total, rank - 1, world) > 0
+    # Everything below runs on the pipeline's stream: rel_all is usually a view of pipe.d_Tpnp (written by the pose stage on pipe.stream, a
+    # non-blocking stream) or a gathered tensor produced on the caller's current stream; G / T_abs / buf are read by the builder on pipe.stream.
+    # Allocating or chaining them on another stream would read half-written poses and let the allocator recycle G under a pending copy.
+    cur = torch.cuda.current_stream(rel_all.device) if rel_all.is_cuda else None
+    if cur is not None and cur != pipe.stream:
+        pipe.stream.wait_stream(cur)               # (a gathered rel_all was produced on the caller's stream)
+        rel_all.record_stream(pipe.stream)
     with torch.cuda.stream(pipe.stream):
+        G = chain_poses(rel_all)                   # (total, 7): the same bits on every rank
+        T_abs = G[h_lo:hi]
+        buf = torch.zeros((pipe.cap, 4), dtype=torch.float32, device=rel_all.device)
+
+        def build(carry):
+            return pipe.stage_build_windows_chunk(T_abs, carry, c_out)
+
         if world > 1:
             chain_carry(dist, rank, world, build, buf, needs_in, c_out > 0)
         else:

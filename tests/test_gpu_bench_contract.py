@@ -100,3 +100,22 @@ def test_bench_sgbm_depth_line():
     assert r["roofline"]["kernel"].startswith("sgbm_* (family") and r["roofline"]["frac"] > 0
     assert "sgbm_down_kernel" in r["kernels_ms_per_step"]        # 8 pairs per call: the fused top-down kernel
     assert "SGBM" in r["config"]["workload"]
+
+
+def test_kitti_root_hook(tmp_path, monkeypatch):
+    """bench.py's real-data hook: a KITTI-layout tree (sequences/00/image_{0,1}/%06d.png) under KITTI_ROOT goes through host/run_vslam and comes back as
+    keypoint / match / inlier statistics (no KITTI in this image: the tree holds eight rendered pairs)"""
+    import importlib.util
+    sys.path.insert(0, ROOT)
+    from stereo_visual_slam_amd import synth
+    seq = tmp_path / "sequences" / "00"
+    seq.mkdir(parents=True)
+    synth.write_pgm_sequence(str(seq) + "/", 8, seed=5, fmt="png")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    monkeypatch.delenv("KITTI_ROOT", raising=False)
+    assert b.kitti_measure()["available"] is False
+    monkeypatch.setenv("KITTI_ROOT", str(tmp_path))
+    r = b.kitti_measure(n_frames=50)
+    assert r["available"] is True and "error" not in r, r
+    assert r["frames"] == 8 and r["keypoints_per_frame_mean"] >= 400 and r["pnp_inliers_min"] >= 10 and r["summary"]

@@ -124,13 +124,14 @@ class WireP2P(WireStandIn):
         t.copy_(self.mail.pop(self.rank))
 
 
-def _front_and_pose(rendered, h_lo, hi):
+def _front_and_pose(rendered, h_lo, hi, sync=True):
     from stereo_visual_slam_amd.pipeline import KeyframePipeline
     pipe = KeyframePipeline(hi - h_lo, device=0, anms_num=ANMS, with_ba=True, ba_windows="tracks", unique_frames=F, frame_range=(h_lo, hi, F), sequence=rendered)
     pipe.stage_orb(); pipe.stage_stereo_match(); pipe.stage_track()
-    pipe.vo.sync()
-    import torch
-    torch.cuda.synchronize()   # (the test reads the poses from torch's default stream; the product orders its gather on the pipeline's stream)
+    if sync:
+        pipe.vo.sync()
+        import torch
+        torch.cuda.synchronize()   # (the test reads the poses from torch's default stream; the product orders its gather on the pipeline's stream)
     return pipe
 
 
@@ -147,6 +148,30 @@ def _owned_results(pipe, first):
         out.append(dict(T=T[b, :nkf[b]].copy(), inl=inl[lm_off[b]:lm_off[b + 1]].copy(), xyz=xyz[lm_off[b]:lm_off[b + 1]].copy(), n_kf=int(nkf[b]),
                         uv=uv[e_off[b]:e_off[b + 1]].copy(), kf=kf[e_off[b]:e_off[b + 1]].copy(), lm=lm[e_off[b]:e_off[b + 1]].copy()))
     return out
+
+
+def test_sequence_windows_without_global_synchronize(rendered):
+    """sequence_windows_and_ba used to chain the poses and allocate the carry buffer on the CALLER's stream while the pose stage was still
+    writing d_Tpnp on the pipeline's (non-blocking) stream; the other tests hid that behind a device-wide synchronize.  Here nothing synchronises between
+    the pose stage and the call, and the call is made from the default stream with a VIEW of d_Tpnp: same windows, same BA results."""
+    from stereo_visual_slam_amd import sharding
+    pipe = _front_and_pose(rendered, 0, F)
+    try:
+        sharding.sequence_windows_and_ba(pipe, F, 0, 1, None, pipe.d_Tpnp[:F - 1].clone())
+        ref = _owned_results(pipe, 0)
+    finally:
+        pipe.close()
+    for _ in range(3):   # (a race would not show every time)
+        pipe = _front_and_pose(rendered, 0, F, sync=False)
+        try:
+            sharding.sequence_windows_and_ba(pipe, F, 0, 1, None, pipe.d_Tpnp[:F - 1])
+            got = _owned_results(pipe, 0)
+        finally:
+            pipe.close()
+        assert len(got) == len(ref)
+        for g, r in zip(got, ref):
+            for k in ("n_kf", "kf", "lm", "uv", "xyz", "inl", "T"):
+                assert np.array_equal(g[k], r[k]), k
 
 
 @pytest.mark.parametrize("world", [2, 8])

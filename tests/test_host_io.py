@@ -29,3 +29,29 @@ def test_png_reader_rejects_garbage(synth):
         synth.write_pgm(os.path.join(d, "a.pgm"), synth.noise_image(1, 32, 8))
         r = subprocess.run([os.path.join(HOST, "image_check"), os.path.join(d, "a.png"), os.path.join(d, "a.pgm")], capture_output=True, text=True)
         assert r.returncode == 1 and "read failed" in r.stdout
+
+
+@pytest.mark.parametrize("k,name", [(0, "pil_kitti_a.png"), (1, "pil_kitti_b.png")])
+def test_png_reader_on_independent_encoder_fixture(synth, k, name):
+    """PNGs of KITTI's size written by Pillow (adaptive row filters, 18-19 IDAT chunks; tests/golden/make_png_pil.py) -- an encoder the
+    reader's author did not write -- must decode to exactly the array the generator's `scene(k)` describes."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("make_png_pil", os.path.join(ROOT, "tests", "golden", "make_png_pil.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    want = gen.scene(k)
+    assert want.shape == (376, 1241)
+    png = os.path.join(ROOT, "tests", "golden", name)
+    data = open(png, "rb").read()
+    assert data.count(b"IDAT") >= 10                     # (many IDAT chunks: the inflate stream has to be stitched)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "stereo-visual-slam_amd", "csrc"), "-s", "-j8"])
+    subprocess.check_call(["make", "-C", HOST, "-s", "-j8", "image_check"])
+    with tempfile.TemporaryDirectory() as d:
+        synth.write_pgm(os.path.join(d, "want.pgm"), want)
+        r = subprocess.run([os.path.join(HOST, "image_check"), png, os.path.join(d, "want.pgm")], capture_output=True, text=True)
+        assert r.returncode == 0 and "png == pgm" in r.stdout, r.stdout + r.stderr
+    try:                                                  # ... and Pillow itself, where it is installed, reads the committed file back to the same array
+        from PIL import Image
+    except Exception:
+        return
+    assert np.array_equal(np.asarray(Image.open(png)), want)
