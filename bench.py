@@ -881,12 +881,8 @@ def main():
             else:
                 pipe.stage_ba()
             return
-        pipe.step()
-        if not serial:
-            ring.k += 1
-        if world > 1:  # throughput-mode pose gather (RCCL over xGMI), 56 B per keyframe; ordered after the step on its stream
-            with torch.cuda.stream(pipe.stream):
-                sharding.gather_poses(pipe.d_Tpnp, dist)
+        # throughput mode: the step on pipeline k mod P, then -- N > 1 -- the pose gather (RCCL over xGMI, 56 B per keyframe), ordered after the step on its stream
+        sharding.throughput_step(ring, dist, world, serial)
 
     for p_ in ring.pipes[1:]:   # (every pipeline has run once before the W warmup steps: none of them meets the timed region cold)
         p_.step()

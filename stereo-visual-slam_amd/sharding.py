@@ -46,6 +46,23 @@ def gather_poses(local_poses, dist=None):
     return out.view(world * local_poses.shape[0], *local_poses.shape[1:])
 
 
+def throughput_step(ring, dist, world, serial=False):
+    """One step of throughput mode on a ring of pipelines in flight (pipeline.PipelineRing): step k runs on pipeline k mod P without waiting for step
+    k - 1, then -- N > 1 -- its poses are all-gathered, ordered behind the step on THAT pipeline's stream.  Every rank calls this the same number of
+    times with the same P, so the all-gathers of the communicator are issued in the same order on every rank whatever stream each one rides on (the
+    one thing RCCL requires; tests/test_sharding_gloo.py::test_two_pipelines_in_flight_gather_in_step_order).  Returns (pipeline, gathered or None)."""
+    import contextlib
+    pipe = ring.pipes[0] if serial else ring.next_pipe()
+    pipe.step()
+    if not serial:
+        ring.k += 1
+    if world <= 1:
+        return pipe, None
+    stream = getattr(pipe, "stream", None)
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        return pipe, gather_poses(pipe.d_Tpnp, dist)
+
+
 def _gather_ragged(local, sizes, dist):
     """rows of every rank (sizes[r] rows each) concatenated in rank order: pad to the largest block, one all-gather, strip"""
     cap = max(max(sizes), 1)

@@ -142,7 +142,7 @@ def test_sequence_sharding_two_and_three_ranks_match_single_rank():
     single-rank trajectory of the same 50-frame sequence"""
     F = 50
     want = _chain_reference(F)
-    for world in (2, 3):
+    for world in (2, 3, 8):   # (8: BASELINE config 5's rank count -- chunks of 6-7 frames)
         res = _run_seq(world, F)
         assert all(res[r] is None for r in range(1, world))
         assert res[0].shape == (F, 7) and np.allclose(res[0], want, rtol=0, atol=1e-12)
@@ -180,7 +180,7 @@ def _carry_worker(rank, world, port, total, q):
 import pytest
 
 
-@pytest.mark.parametrize("world,total", [(2, 50), (3, 50), (3, 20)])
+@pytest.mark.parametrize("world,total", [(2, 50), (3, 50), (3, 20), (8, 50), (8, 4541), (8, 11)])
 def test_carry_chain_reaches_every_rank_in_order(world, total):
     """sequence mode's one serial step over gloo: rank r gets exactly the record rank r - 1 built for the first frame of r's chunk (halo included), built
     after r - 1 received its own; ranks whose chunk starts at frame 0 get none"""
@@ -225,3 +225,90 @@ def test_owned_windows_cover_every_frame_once():
                     assert h + c == sharding.halo_start(lo_n, sharding.WINDOW_HALO) or (c == 0 and sharding.halo_start(lo_n, sharding.WINDOW_HALO) <= h)
                     assert c < hi - h
             assert seen == list(range(total))
+
+
+def test_eight_rank_pose_gather():
+    """the ragged all-gather of config 5 at its real rank count (50 frames -> 7, 7, 6, 6, 6, 6, 6, 6)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total, world = 50, 8
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.array([[g + 0.125 * c for c in range(7)] for g in range(total)])
+    for rank, allp, eq, tmax in res:
+        assert allp.shape == (total, 7) and np.array_equal(allp, want) and tmax == float(world)
+
+
+# ---------------------------------------------------------------- round 6: two pipelines in flight and their collectives
+class _FakePipe:
+    """stands in for a KeyframePipeline: step() "computes" poses that name (rank, pipeline, how often it has stepped) after a rank-dependent delay"""
+    def __init__(self, rank, idx, B):
+        self.rank, self.idx, self.B, self.n = rank, idx, B, 0
+        self.d_Tpnp = torch.zeros((B, 7), dtype=torch.float64)
+        self.stream = None
+
+    def step(self):
+        import time
+        time.sleep(0.002 * ((self.rank * 7 + self.n * 3 + self.idx) % 5))     # ranks drift apart: a reordered collective would pair the wrong steps
+        self.n += 1
+        self.d_Tpnp[:] = 1000.0 * self.rank + 100.0 * self.idx + self.n
+
+
+class _FakeRing:
+    def __init__(self, rank, P, B):
+        self.pipes = [_FakePipe(rank, i, B) for i in range(P)]
+        self.k = 0
+
+    def next_pipe(self):
+        return self.pipes[self.k % len(self.pipes)]
+
+
+def _inflight_worker(rank, world, port, steps, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stereo_visual_slam_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ring = _FakeRing(rank, 2, 3)
+        got = []
+        for k in range(steps):
+            pipe, allp = sharding.throughput_step(ring, dist, world)
+            got.append((pipe.idx, allp.clone().numpy()))
+        _, one = sharding.throughput_step(ring, dist, world, serial=True)     # the one-batch-in-flight repeat: always pipeline 0, the ring does not advance
+        q.put((rank, got, one.numpy(), ring.k))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_pipelines_in_flight_gather_in_step_order(world):
+    """throughput mode, N > 1, two batches in flight: step k runs on pipeline k mod 2 and then all-gathers THAT pipeline's poses.  Every rank must issue
+    these collectives in the same order (RCCL pairs collectives of a communicator by issue order, whichever stream carries them): block r of step k's
+    gather is rank r's pipeline k mod 2 after its (k // 2 + 1)-th step -- for every k, on every rank, with the ranks drifting apart in time."""
+    steps = 9
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_inflight_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, got, one, k_end in res:
+        assert k_end == steps and len(got) == steps
+        for k, (idx, allp) in enumerate(got):
+            assert idx == k % 2 and allp.shape == (world * 3, 7)
+            for r in range(world):
+                assert np.all(allp[3 * r: 3 * r + 3] == 1000.0 * r + 100.0 * (k % 2) + (k // 2 + 1)), (rank, k, r)
+        n0 = (steps + 1) // 2 + 1                                              # pipeline 0 has stepped ceil(steps / 2) times, then once more
+        for r in range(world):
+            assert np.all(one[3 * r: 3 * r + 3] == 1000.0 * r + n0)
