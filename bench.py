@@ -988,7 +988,28 @@ def main():
             win_stats = {"landmarks_per_window_mean": float(nl_w.mean()), "landmarks_per_window_max": int(nl_w.max()), "edges_per_window_mean": float(ne_w.mean()),
                          "edges_per_window_max": int(ne_w.max()), "reliable_fraction": float(out["ba_rel"][:n_l].mean()) if n_l else 0.0,
                          "keyframes_per_window": "1..%d for the first %d windows (the growing map), then %d" % (pipe.n_kf, pipe.n_kf - 1, pipe.n_kf),
-                         "full_windows": int((out["ba_nkf"] == pipe.n_kf).sum()), "builder_status": build_bad}
+                         "full_windows": int((out["ba_nkf"] == pipe.n_kf).sum()), "builder_status": build_bad,
+                         "observations_per_landmark": float(ne_w.sum() / max(nl_w.sum(), 1))}
+            # [r6] the track rule (vslam_build_windows_dev, Tuning::track_rule): the step runs the reference's -- a frame-to-frame match continues a track whenever
+            # its last-frame keypoint is a feature (visual_odometry.cpp:568-599) -- and, outside the timed region, the same front-end results are built once
+            # more under the convention of rounds 4-5 (only keypoints with a depth of their own pass a track on) for the before / after figures
+            if not seq_mode:
+                try:
+                    pipe.vo.set_tuning(track_rule=0)
+                    pipe.stage_build_windows(); pipe.vo.sync(); torch.cuda.synchronize(dev)
+                    lo_ = pipe.ba_lm_off.cpu().numpy(); eo_ = pipe.ba_e_off.cpu().numpy()
+                    pipe.vo.set_tuning(track_rule=-1)
+                    pipe.stage_build_windows(); pipe.vo.sync(); torch.cuda.synchronize(dev)
+                    win_stats["track_rule"] = {
+                        "this_run": "1: the reference's tracking() rule (every feature of the last frame is a query; a feature without its own depth is judged by the pose "
+                                    "stage's 4 px rule on its landmark's map position through the chained pose)",
+                        "pose_inputs_per_frame": float(out["pn"][:max(B - 1, 1)].mean()),
+                        "pose_inputs_note": "inputs of the pose stage = frame-to-frame matches whose last-frame keypoint owns a depth (triangulated in that frame); the same under both rules",
+                        "observations_per_landmark": win_stats["observations_per_landmark"],
+                        "round5_rule": {"landmarks_per_window_mean": float(np.diff(lo_).mean()), "edges_per_window_mean": float(np.diff(eo_).mean()),
+                                        "observations_per_landmark": float(eo_[-1] / max(lo_[-1], 1))}}
+                except Exception as e:
+                    win_stats["track_rule"] = {"error": repr(e)}
         units = args.sequence if seq_mode else world * B   # keyframes all ranks processed per step (halo frames are not counted twice)
         value = units * args.steps / elapsed
         kern = sorted(prof.items(), key=lambda kv: -kv[1][0])

@@ -321,7 +321,13 @@ typedef struct vslam_tracks_in {
  * d_reliable / d_lm_inlier for lm_capacity landmarks, d_kf_idx / d_lm_idx / d_uv for edge_capacity edges, d_n_kf n_frames; the
  * const members are written through) and its scalar members (n_windows = n_frames, n_kf, total_lm = lm_capacity, total_edge =
  * edge_capacity: bounds).  d_status (1 int32): 0, or 1 when a capacity was too small -- the windows from the first one that did
- * not fit are then emitted empty.  Asynchronous on the context stream; `out` can go straight into vslam_ba_batch_dev. */
+ * not fit are then emitted empty.  Asynchronous on the context stream; `out` can go straight into vslam_ba_batch_dev.
+ * Track continuation (round 6; vslam_set_tuning "track_rule", default 1): a frame-to-frame match gives the current keypoint the landmark of the
+ * last-frame keypoint whenever that keypoint IS A FEATURE of the last frame -- created there (a valid depth) or tracked into it -- as VO::tracking
+ * does (visual_odometry.cpp:568-599: the query set is frame_last_.features_).  If the last-frame keypoint owns a depth, it was input j of the pose
+ * stage and d_pose_inlier decides (:306); if it does not, the pose stage's inlier rule (solvePnPRansac's 4 px, params.pnp_reproj_thr) is applied
+ * to the landmark's MAP position (:260-270: pt_3d_, the creation point or the first reliable one) through the current frame's chained pose and
+ * params.cam.  track_rule 0: only matches whose last-frame keypoint owns a depth continue a track (rounds 4-5). */
 int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf, int lm_capacity, int edge_capacity, vslam_ba_batch* out,
                             int32_t* d_status);
 
@@ -347,7 +353,8 @@ int vslam_edge_jacobians(vslam_ctx* ctx, int n, const float* xyz_w, const float*
                          double* err, double* J_pose, double* J_point, double* chi2, double* huber_w);
 /* Kernel-choice overrides of a context (tuning aid, and how the tests force every kernel path): name in {"orb_fuse_min", "sgbm_fuse_min",
  * "sgbm_fwd_min" (items per call from which the fused kernel is used), "sgbm_fw_rows" (32 | 64), "pose_only_window", "pnp_window", "ba_adaptive" (0 | 1), "ba_lanes" (256 | 512: lanes per window of the
- * LDS-resident optimize_map kernel; default by the number of windows in the call; the results do not depend on it)};
+ * LDS-resident optimize_map kernel; default by the number of windows in the call; the results do not depend on it), "track_rule" (0 | 1: see
+ * vslam_build_windows_dev; this one changes RESULTS, it is the before / after switch of round 6)};
  * value -1 = the library's batch-size rule.  vslam_create seeds them once from the environment variables VSLAM_<NAME> (an unparsable
  * or out-of-range value makes vslam_create fail with VSLAM_ERR_ARG); nothing reads the environment afterwards. */
 int vslam_set_tuning(vslam_ctx* ctx, const char* name, int value);

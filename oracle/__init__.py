@@ -393,7 +393,8 @@ def pnp_ransac(xyz, uv, T0=None, K=K_KITTI, max_iters=100, reproj_err=4.0, confi
     return T, inl[:len(xyz)], n, it.value
 
 
-def build_windows(kps, lr, nlr, xyz, valid, reliable, f2f, nf2f, pose_inlier, T_rel, n_kf=10, lm_capacity=None, edge_capacity=None):
+def build_windows(kps, lr, nlr, xyz, valid, reliable, f2f, nf2f, pose_inlier, T_rel, n_kf=10, lm_capacity=None, edge_capacity=None, K=None, reproj_thr=4.0,
+                  track_rule=1):
     """windows.c: the BA windows of a batch of consecutive keyframes from the front end's per-frame results.
     kps (F, kp_cap) KEYPOINT_DTYPE; lr (F, lr_cap) DMATCH_DTYPE; xyz (F, lr_cap, 3); valid / reliable (F, lr_cap);
     f2f (F-1, match_cap) DMATCH_DTYPE; pose_inlier (F-1, pnp_cap); T_rel (F-1, 7).  Returns a dict of the vslam_ba_batch arrays."""
@@ -413,7 +414,7 @@ def build_windows(kps, lr, nlr, xyz, valid, reliable, f2f, nf2f, pose_inlier, T_
     rc = lib().vo_build_windows(F, kp_cap, lr_cap, match_cap, pnp_cap, _p(kps), _p(lr), _p(nlr), _p(xyz), _p(valid), _p(reliable), _p(f2f), _p(nf2f),
                                 _p(pose_inlier), _p(T_rel), int(n_kf), int(lm_capacity), int(edge_capacity), _p(out["lm_off"]), _p(out["edge_off"]),
                                 _p(out["n_kf"]), _p(out["T"]), _p(out["xyz"]), _p(out["reliable"]), _p(out["lm_inlier"]), _p(out["kf_idx"]),
-                                _p(out["lm_idx"]), _p(out["uv"]))
+                                _p(out["lm_idx"]), _p(out["uv"]), _p(_d(K_KITTI if K is None else K, 4)), C.c_double(reproj_thr), int(track_rule))
     if rc < 0:
         raise RuntimeError("vo_build_windows: inconsistent input (%d)" % rc)
     out["status"] = rc

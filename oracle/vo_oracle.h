@@ -207,12 +207,14 @@ int vo_pnp_ransac_hypothesis(const float* xyz_w, const float* uv, int n, const d
 /* Map bookkeeping in front of the local BA for a batch of consecutive keyframes (windows.c): VO::tracking / insert_key_frame
  * (visual_odometry.cpp:363-424, :592-599) + the graph build of optimize_map (optimization.cpp:127-214), window b = the map right after
  * keyframe b.  Layouts as in include/vslam_hip.h (vslam_tracks_in / vslam_ba_batch), host arrays.  Returns 0, 1 when a capacity was too
- * small (the windows from the first that did not fit are empty), < 0 on inconsistent input. */
+ * small (the windows from the first that did not fit are empty), < 0 on inconsistent input.
+ * track_rule 1 (the reference's tracking(), :568-599 + :260-270): a match continues a track whenever the last-frame keypoint is a feature; 0: only
+ * when it owns a depth of its own (the convention of rounds 4-5).  K4 = {fx, fy, cx, cy}, reproj_thr in pixels (rule 1 only). */
 int vo_build_windows(int n_frames, int kp_cap, int lr_cap, int match_cap, int pnp_cap, const vo_keypoint* kps, const vo_dmatch* lr,
                      const int32_t* nlr, const float* xyz, const uint8_t* valid, const uint8_t* reliable, const vo_dmatch* f2f,
                      const int32_t* nf2f, const uint8_t* pose_inlier, const double* T_rel, int n_kf, int lm_capacity, int edge_capacity,
                      int32_t* lm_off, int32_t* edge_off, int32_t* n_kf_out, double* T_out, float* xyz_out, uint8_t* rel_out,
-                     uint8_t* inl_out, int32_t* kf_out, int32_t* lm_out, float* uv_out);
+                     uint8_t* inl_out, int32_t* kf_out, int32_t* lm_out, float* uv_out, const double K4[4], double reproj_thr, int track_rule);
 
 /* EPnP (the minimal solver of solvePnPRansac; OpenCV 3.2 modules/calib3d/src/epnp.cpp restated, see epnp.c).  R row-major 3 x 3,
  * t: world -> camera.  Returns the mean reprojection error of the chosen candidate, < 0 for a degenerate configuration. */

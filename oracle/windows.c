@@ -3,6 +3,9 @@
  * code, followed statement by statement:
  *   VO::tracking            visual_odometry.cpp:592-599  a frame-to-frame match gives the current feature the landmark of the matched
  *                                                         feature of the last frame
+ *   VO::tracking            :568-574                      the last frame's query set is EVERY feature of the last frame -- tracked or created there -- whether
+ *                                                         or not it has a depth of its own in that frame (track_rule 1, round 6; see below)
+ *   VO::motion_estimation   :260-270                      the 3-D point of a tracked feature is its LANDMARK's map position (pt_3d_)
  *   VO::motion_estimation   :306                          outliers of the pose stage are erased from the frame
  *   VO::insert_key_frame    :363-372                      every remaining feature adds an Observation to its landmark
  *                           :381-421                      every keypoint with a valid depth that is not such a feature creates a Landmark
@@ -17,7 +20,17 @@
  * Throughput-mode conventions shared with the HIP path: every frame is a keyframe; window b = keyframes [max(0, b - n_kf + 1), b] with
  * the map state right after keyframe b; is_inlier = 1 on entry; world = frame 0, poses = the pose stage's relative poses chained
  * sequentially; landmarks of a window ordered by the number of observations inside it, then by their first observation inside it (frame, then
- * keypoint index) -- the optimiser takes any order (the reference iterates an unordered_map), this one keeps neighbouring landmarks alike. */
+ * keypoint index) -- the optimiser takes any order (the reference iterates an unordered_map), this one keeps neighbouring landmarks alike.
+ *
+ * Track continuation (round 6).  track_rule 0 is the convention of rounds 4-5: a frame-to-frame match continues a track only when the LAST-frame
+ * keypoint owns a valid depth of its own (it then is one of the pose stage's inputs, and the pose stage's inlier flag decides).  track_rule 1 is the
+ * reference's bookkeeping: the match continues a track whenever the last-frame keypoint IS A FEATURE (carries a landmark), created in that frame or
+ * tracked into it.  For a feature without a depth of its own the pose stage of throughput mode has no input (its inputs are triangulated in the
+ * last frame's camera, all frame pairs of a batch at once); the reference would hand solvePnPRansac the landmark's map position (:268), so the same
+ * inlier rule (:277, reprojection error <= 4 px) is applied to exactly that: the landmark's position as the map holds it before this frame's
+ * insertion (pt_3d_: the creation point, or the first reliable one, :391-401), projected with the frame's chained pose.  The pose itself is not
+ * re-estimated.  The pose stage's own inputs and their flags are unchanged. */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -52,12 +65,22 @@ static int head_cmp(const void* a, const void* b) {
     return x->first_kp < y->first_kp ? -1 : (x->first_kp > y->first_kp);
 }
 
+/* PnPRansac's inlier test (visual_odometry.cpp:277: reprojection error 4.0) on a landmark's map position (cv::Point3f) seen through T_c_w */
+static int reprojects_within(const float pos[3], const double* T_c_w, const vo_keypoint* kp, const double K4[4], double thr) {
+    const double pw[3] = {pos[0], pos[1], pos[2]};
+    double pc[3];
+    vo_se3_act(T_c_w, pw, pc);
+    const double du = (double)kp->x - (K4[0] * pc[0] / pc[2] + K4[2]), dv = (double)kp->y - (K4[1] * pc[1] / pc[2] + K4[3]);
+    const double c = du * du + dv * dv;
+    return isfinite(c) && c <= thr * thr;
+}
+
 int vo_build_windows(int n_frames, int kp_cap, int lr_cap, int match_cap, int pnp_cap, const vo_keypoint* kps, const vo_dmatch* lr,
                      const int32_t* nlr, const float* xyz, const uint8_t* valid, const uint8_t* reliable, const vo_dmatch* f2f,
                      const int32_t* nf2f, const uint8_t* pose_inlier, const double* T_rel, int n_kf, int lm_capacity, int edge_capacity,
                      int32_t* lm_off, int32_t* edge_off, int32_t* n_kf_out, double* T_out, float* xyz_out, uint8_t* rel_out,
-                     uint8_t* inl_out, int32_t* kf_out, int32_t* lm_out, float* uv_out) {
-    if (n_frames <= 0 || n_kf <= 0) return -1;
+                     uint8_t* inl_out, int32_t* kf_out, int32_t* lm_out, float* uv_out, const double K4[4], double reproj_thr, int track_rule) {
+    if (n_frames <= 0 || n_kf <= 0 || (track_rule && !K4)) return -1;
     double* G = (double*)malloc(sizeof(double) * 7 * (size_t)n_frames);
     int32_t* feat_lm = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_frames * kp_cap); /* landmark of keypoint (f, i), -1: not a feature */
     int32_t* kp2lr = (int32_t*)malloc(sizeof(int32_t) * (size_t)kp_cap * 2);
@@ -82,11 +105,17 @@ int vo_build_windows(int n_frames, int kp_cap, int lr_cap, int match_cap, int pn
                 const int q = f2f[(size_t)it * match_cap + k].queryIdx, t = f2f[(size_t)it * match_cap + k].trainIdx;
                 if (q < 0 || q >= kp_cap || t < 0 || t >= kp_cap) continue;
                 const int li = prev_k2[q];
-                if (li < 0 || !valid[(size_t)it * lr_cap + li]) continue;
-                const int jj = j++;
-                if (jj >= pnp_cap || !pose_inlier[(size_t)it * pnp_cap + jj]) continue;
-                const int id = feat_lm[(size_t)it * kp_cap + q]; /* a keypoint with a valid depth always is a feature of its keyframe */
-                if (id < 0) { free(G); free(feat_lm); free(kp2lr); for (int x = 0; x < n_lm; ++x) free(L[x].obs); free(L); return -2; }
+                const int id = feat_lm[(size_t)it * kp_cap + q];
+                if (li >= 0 && valid[(size_t)it * lr_cap + li]) { /* an input of the pose stage: its flag decides */
+                    const int jj = j++;
+                    if (jj >= pnp_cap || !pose_inlier[(size_t)it * pnp_cap + jj]) continue;
+                    /* a keypoint with a valid depth always is a feature of its keyframe */
+                    if (id < 0) { free(G); free(feat_lm); free(kp2lr); for (int x = 0; x < n_lm; ++x) free(L[x].obs); free(L); return -2; }
+                } else { /* no depth of its own in the last frame: a feature only if it was tracked into it (:568-574 takes every feature) */
+                    if (!track_rule || id < 0) continue;
+                    const float* pos = (L[id].rel_frame >= 0 && L[id].rel_frame != L[id].root_frame) ? L[id].pos1 : L[id].pos0; /* pt_3d_ before this frame's insertion */
+                    if (!reprojects_within(pos, G + 7 * (size_t)f, &kps[(size_t)f * kp_cap + t], K4, reproj_thr)) continue;
+                }
                 feat_lm[(size_t)f * kp_cap + t] = id;
                 push_obs(&L[id], f, t); /* :363-372 */
             }

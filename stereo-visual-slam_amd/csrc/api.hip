@@ -118,6 +118,7 @@ static const TuneKey kTuneKeys[] = {
     {"pnp_window", "VSLAM_PNP_WINDOW", &Tuning::pnp_window, 0, 1},
     {"ba_adaptive", "VSLAM_BA_ADAPTIVE", &Tuning::ba_adaptive, 0, 1},
     {"ba_lanes", "VSLAM_BA_LANES", &Tuning::ba_lanes, 256, 512},
+    {"track_rule", "VSLAM_TRACK_RULE", &Tuning::track_rule, 0, 1},
 };
 static int tune_set(Tuning& t, const TuneKey& k, long v) {
     if (v == -1) { t.*(k.field) = -1; return VSLAM_OK; } // back to the library's rule
@@ -994,7 +995,10 @@ int vslam_build_windows_dev(vslam_ctx* ctx, const vslam_tracks_in* in, int n_kf,
         c->track_bytes = need; c->dev_bytes += need;
     }
     out->n_windows = in->n_frames; out->n_kf = n_kf; out->total_lm = lm_capacity; out->total_edge = edge_capacity;
-    return launch_build_windows(*in, n_kf, lm_capacity, edge_capacity, c->d_track, const_cast<int32_t*>(out->d_lm_off), const_cast<int32_t*>(out->d_edge_off),
+    double K4[4];
+    fill_K(c, K4);
+    const int track_rule = c->tune.track_rule >= 0 ? c->tune.track_rule : 1;
+    return launch_build_windows(*in, n_kf, lm_capacity, edge_capacity, K4, c->p.pnp_reproj_thr, track_rule, c->d_track, const_cast<int32_t*>(out->d_lm_off), const_cast<int32_t*>(out->d_edge_off),
                                 const_cast<int32_t*>(out->d_n_kf), out->d_T_c_w, out->d_xyz, const_cast<uint8_t*>(out->d_reliable), out->d_lm_inlier,
                                 const_cast<int32_t*>(out->d_kf_idx), const_cast<int32_t*>(out->d_lm_idx), const_cast<float*>(out->d_uv), d_status, c->stream);
 }

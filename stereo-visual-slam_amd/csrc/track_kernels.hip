@@ -31,10 +31,10 @@ struct TrackDims { int B, kp_cap, lr_cap, match_cap, pnp_cap, n_kf; };
 
 // ---- per frame: keypoint -> L/R match table; chain tables cleared
 __global__ __launch_bounds__(256) void track_init_kernel(TrackDims d, const vslam_dmatch* __restrict__ d_lr, const int32_t* __restrict__ d_nlr,
-                                                        int32_t* __restrict__ kp2lr, int32_t* __restrict__ pred, int32_t* __restrict__ succ) {
+                                                        int32_t* __restrict__ kp2lr, int32_t* __restrict__ pred, int32_t* __restrict__ succ, int32_t* __restrict__ cand) {
     const int f = blockIdx.x, tid = threadIdx.x;
     int32_t* k2 = kp2lr + (size_t)f * d.kp_cap;
-    for (int i = tid; i < d.kp_cap; i += 256) { k2[i] = -1; pred[(size_t)f * d.kp_cap + i] = -1; succ[(size_t)f * d.kp_cap + i] = -1; }
+    for (int i = tid; i < d.kp_cap; i += 256) { k2[i] = -1; pred[(size_t)f * d.kp_cap + i] = -1; succ[(size_t)f * d.kp_cap + i] = -1; cand[(size_t)f * d.kp_cap + i] = -1; }
     __syncthreads();
     const int nlr = min(max(d_nlr[f], 0), d.lr_cap);
     const vslam_dmatch* lr = d_lr + (size_t)f * d.lr_cap;
@@ -85,12 +85,14 @@ __global__ __launch_bounds__(256) void track_pose_chain_kernel(int B, const doub
     }
 }
 
-// ---- per frame pair (i -> i + 1): the pose stage's inliers become chain links.  Input j of the pose stage is the j-th frame-to-frame
-// match whose query keypoint owns a valid depth (the compaction of build_pnp_inputs_kernel, geom_kernels.hip, repeated with the same
-// ballot ranks); a link needs its inlier flag (the reference erases the outliers of motion_estimation from the frame, :306).
+// ---- per frame pair (i -> i + 1): every frame-to-frame match becomes a CANDIDATE link q -> t.  Input j of the pose stage is the j-th match
+// whose query keypoint owns a valid depth (the compaction of build_pnp_inputs_kernel, geom_kernels.hip, repeated with the same ballot ranks):
+// such a candidate carries the pose stage's inlier flag (the reference erases the outliers of motion_estimation from the frame, :306).  A
+// candidate whose query keypoint has no depth of its own is decided by the walk below (track_rule 1) or never a link (track_rule 0).
+constexpr int kCandDepth = 1 << 20, kCandInlier = 1 << 21, kCandIndex = 0xFFFF; // cand word of slot t: q | flags (kp_capacity <= 65536), -1: no match reaches it
 __global__ __launch_bounds__(256) void track_link_kernel(TrackDims d, const vslam_dmatch* __restrict__ d_f2f, const int32_t* __restrict__ d_nf2f,
                                                         const uint8_t* __restrict__ d_valid, const uint8_t* __restrict__ d_inl,
-                                                        const int32_t* __restrict__ kp2lr, int32_t* __restrict__ pred, int32_t* __restrict__ succ) {
+                                                        const int32_t* __restrict__ kp2lr, int32_t* __restrict__ cand, int32_t* __restrict__ succ) {
     const int it = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_tot[4];
     const int nm = min(max(d_nf2f[it], 0), d.match_cap);
@@ -99,10 +101,11 @@ __global__ __launch_bounds__(256) void track_link_kernel(TrackDims d, const vsla
     int written = 0;
     for (int base = 0; base < nm; base += 256) {
         const int k = base + tid;
-        bool ok = false; int q = -1, t = -1;
+        bool ok = false, in_range = false; int q = -1, t = -1;
         if (k < nm) {
             q = m[k].queryIdx; t = m[k].trainIdx;
-            if (q >= 0 && q < d.kp_cap && t >= 0 && t < d.kp_cap) { const int li = k2[q]; ok = li >= 0 && d_valid[(size_t)it * d.lr_cap + li] != 0; }
+            in_range = q >= 0 && q < d.kp_cap && t >= 0 && t < d.kp_cap;
+            if (in_range) { const int li = k2[q]; ok = li >= 0 && d_valid[(size_t)it * d.lr_cap + li] != 0; }
         }
         const unsigned long long mask = __ballot(ok);
         __syncthreads();
@@ -111,64 +114,17 @@ __global__ __launch_bounds__(256) void track_link_kernel(TrackDims d, const vsla
         int off = written;
         for (int w = 0; w < wave; ++w) off += s_tot[w];
         const int j = off + __popcll(mask & ((1ull << lane) - 1ull));
-        if (ok && j < d.pnp_cap && d_inl[(size_t)it * d.pnp_cap + j] != 0) {
-            pred[(size_t)(it + 1) * d.kp_cap + t] = q;
+        if (in_range) { // (matches are one-to-one in query and train index: the matcher's cross-check)
+            const bool inl = ok && j < d.pnp_cap && d_inl[(size_t)it * d.pnp_cap + j] != 0;
+            cand[(size_t)(it + 1) * d.kp_cap + t] = q | (ok ? kCandDepth : 0) | (inl ? kCandInlier : 0);
             succ[(size_t)it * d.kp_cap + q] = t;
         }
         written += s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
     }
 }
 
-// ---- per keypoint slot: is it a node (a Feature of its keyframe: tracked, or owner of a valid depth), the root of its chain (where the
-// landmark was created) and the FIRST node of the chain, up to this one, with a reliable depth (-1: none yet): the landmark's position
-// at the time of this node is that node's point if there is one, the root's otherwise (visual_odometry.cpp:391-401).
-// A chunk of a longer sequence (carry: vslam_tracks_in::d_carry_in): a track may reach a keypoint of the batch's first frame from BEFORE the batch.
-// Such a slot is a node whatever its own depth, and the chain's root -- and its first reliable node, if the carry says one was seen -- lie upstream:
-// both tables then hold the code  kCarryCode - slot  (< -1), which the emit pass resolves to the carried position.
 constexpr int kCarryCode = -2;
 __device__ inline int carry_flags(const float* carry, int slot) { return carry ? (int)carry[4 * slot + 3] : 0; }
-__global__ __launch_bounds__(256) void track_chain_kernel(TrackDims d, const uint8_t* __restrict__ d_valid, const uint8_t* __restrict__ d_rel,
-                                                         const int32_t* __restrict__ kp2lr, const int32_t* __restrict__ pred,
-                                                         const int32_t* __restrict__ succ, const float* __restrict__ carry, int32_t* __restrict__ root,
-                                                         int32_t* __restrict__ relsrc, int32_t* __restrict__ info) {
-    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.kp_cap) return;
-    const size_t at = (size_t)f * d.kp_cap + i;
-    const int m = kp2lr[at];
-    int p = pred[at];
-    if (f == 0 && (carry_flags(carry, i) & 1)) p = 0; // (tracked from before the batch: a node with a predecessor; the index itself is never followed)
-    const bool own3d = m >= 0 && d_valid[(size_t)f * d.lr_cap + m] != 0;
-    int r = -1, first = -1;
-    if (own3d || p >= 0) {
-        int cf = f, ci = i;
-        for (;;) {
-            const size_t c = (size_t)cf * d.kp_cap + ci;
-            const int mm = kp2lr[c];
-            if (mm >= 0 && d_valid[(size_t)cf * d.lr_cap + mm] != 0 && d_rel[(size_t)cf * d.lr_cap + mm] != 0) first = cf * d.kp_cap + ci;
-            const int pp = pred[c];
-            if (pp < 0 || cf == 0) break;
-            --cf; ci = pp;
-        }
-        r = cf * d.kp_cap + ci;
-        if (cf == 0) { // the chain reaches the batch's first frame: does it go on upstream?
-            const int cfl = carry_flags(carry, ci);
-            if (cfl & 1) { r = kCarryCode - ci; if (cfl & 2) first = kCarryCode - ci; } // (an upstream reliable node is earlier than any local one)
-        }
-    }
-    root[at] = r; relsrc[at] = first;
-    // what a window needs to know about this slot without walking: node?, has a predecessor?, successors left in its chain
-    int rem = 0;
-    const bool node = r >= 0 || r <= kCarryCode;
-    if (node) {
-        int cf = f, ci = i;
-        while (cf + 1 < d.B && rem < VSLAM_MAX_KF) {
-            const int nx = succ[(size_t)cf * d.kp_cap + ci];
-            if (nx < 0) break;
-            ++cf; ci = nx; ++rem;
-        }
-    }
-    info[at] = (node ? 1 : 0) | (p >= 0 ? 2 : 0) | (rem << 8);
-}
 
 // the landmark position a chain node stands for: the point of node `src` (= first reliable node of the chain, else its root) in the world of G,
 // or the carried position when the chain's source lies before the batch
@@ -183,6 +139,97 @@ __device__ inline void landmark_position(const TrackDims& d, int src, const int3
     se3::inverse(G + (size_t)sf * 7, Gi);
     se3::act(Gi, p, pw);
     out[0] = (float)pw[0]; out[1] = (float)pw[1]; out[2] = (float)pw[2];
+}
+
+// PnPRansac's inlier test (visual_odometry.cpp:277, reprojection error <= 4 px; the contract of the pose stage's own flags) on a landmark's
+// map position seen through the chained pose of the current frame
+struct TrackCam { double fx, fy, cx, cy, thr2; int track_rule; };
+__device__ inline bool reprojects_within(const float pos[3], const double* __restrict__ T, const vslam_keypoint* __restrict__ kp, const TrackCam& cam) {
+    const double pw[3] = {(double)pos[0], (double)pos[1], (double)pos[2]};
+    double pc[3];
+    se3::act(T, pw, pc);
+    const double du = (double)kp->x - (cam.fx * pc[0] / pc[2] + cam.cx), dv = (double)kp->y - (cam.fy * pc[1] / pc[2] + cam.cy);
+    const double c = du * du + dv * dv;
+    return isfinite(c) && c <= cam.thr2;
+}
+
+// ---- the tracks.  The candidate links form disjoint PATHS through the batch (a slot has at most one candidate in and one out); the thread of
+// a path's first slot (no candidate reaches it, or it lies in the batch's first frame) walks the path forward in time, carrying the landmark the
+// current slot stands for, and decides every candidate the way VO::tracking / motion_estimation would (visual_odometry.cpp:568-599, :260-306):
+//   a slot with a valid depth of its own that no track reaches creates a landmark (:381-421: root = itself);
+//   a candidate OUT of a slot that is a feature continues the track when the pose stage kept it (the slot owns a depth: it was an input), or -- [r6],
+//   track_rule 1: the reference's query set is every feature of the last frame (:568-574), depth or not -- when the landmark's map position
+//   (the creation point, or the first reliable one, :391-401, as of the last frame) reprojects within the pose stage's 4 px through the current frame's pose;
+//   a candidate out of a slot that is no feature is nothing.
+// Per slot it leaves: root (where the landmark was created), relsrc (the FIRST node of the chain, up to this one, with a reliable depth; -1: none yet),
+// pred / succ (the links that hold).  A chunk of a longer sequence (carry: vslam_tracks_in::d_carry_in): a track may reach a keypoint of the batch's
+// first frame from BEFORE the batch.  Such a slot is a feature whatever its own depth, and the chain's root -- and its first reliable node, if the
+// carry says one was seen -- lie upstream: both tables then hold the code  kCarryCode - slot  (< -1), which resolves to the carried position.
+// Sequential per path (its length: a few frames for most, the batch at worst), parallel over the ~B x 1200 paths.
+__global__ __launch_bounds__(256) void track_walk_kernel(TrackDims d, TrackCam cam, const vslam_keypoint* __restrict__ d_kps, const float* __restrict__ d_xyz,
+                                                        const uint8_t* __restrict__ d_valid, const uint8_t* __restrict__ d_rel, const int32_t* __restrict__ kp2lr,
+                                                        const int32_t* __restrict__ cand, int32_t* __restrict__ pred, int32_t* __restrict__ succ,
+                                                        const double* __restrict__ G, const float* __restrict__ carry, int32_t* __restrict__ root,
+                                                        int32_t* __restrict__ relsrc) {
+    const int f0 = blockIdx.y, i0 = blockIdx.x * 256 + threadIdx.x;
+    if (i0 >= d.kp_cap) return;
+    if (f0 > 0 && cand[(size_t)f0 * d.kp_cap + i0] >= 0) return; // some earlier slot's walk passes through here
+    int cf = f0, ci = i0;
+    bool feat = false;
+    int r = -1, first = -1; // the landmark of the current slot: root and first reliable node (codes as in the tables)
+    if (f0 == 0) {
+        const int cfl = carry_flags(carry, i0);
+        if (cfl & 1) { feat = true; r = kCarryCode - i0; if (cfl & 2) first = r; }
+    }
+    int pos_src = 0x7FFFFFFF; float pos[3] = {0.f, 0.f, 0.f}; // map position of the landmark, computed when a candidate needs it
+    for (;;) {
+        const size_t c = (size_t)cf * d.kp_cap + ci;
+        const int node = cf * d.kp_cap + ci;
+        const int mm = kp2lr[c];
+        const bool own3d = mm >= 0 && d_valid[(size_t)cf * d.lr_cap + mm] != 0;
+        if (!feat && own3d) { feat = true; r = node; first = -1; }                                        // :403-418 a landmark is created here
+        if (feat && first == -1 && own3d && d_rel[(size_t)cf * d.lr_cap + mm] != 0) first = node;           // :391-401 (or created reliable)
+        root[c] = feat ? r : -1; relsrc[c] = feat ? first : -1;
+        if (cf + 1 >= d.B) break;
+        const int t = succ[c]; // (candidate)
+        if (t < 0) break;
+        const size_t cn = (size_t)(cf + 1) * d.kp_cap + t;
+        const int cd = cand[cn];
+        bool holds = false;
+        if (feat) {
+            if (cd & kCandDepth) holds = (cd & kCandInlier) != 0;
+            else if (cam.track_rule) {
+                const int src = first != -1 ? first : r;
+                if (src != pos_src) { landmark_position(d, src, kp2lr, d_xyz, G, carry, pos); pos_src = src; }
+                holds = reprojects_within(pos, G + (size_t)(cf + 1) * 7, d_kps + cn, cam);
+            }
+        }
+        if (holds) pred[cn] = ci;
+        else { succ[c] = -1; feat = false; r = -1; first = -1; }
+        ++cf; ci = t;
+    }
+}
+
+// ---- per slot, after the walk: what a window needs to know about it without walking: node?, has a predecessor?, successors left in its chain
+__global__ __launch_bounds__(256) void track_info_kernel(TrackDims d, const int32_t* __restrict__ pred, const int32_t* __restrict__ succ, const int32_t* __restrict__ root,
+                                                        const float* __restrict__ carry, int32_t* __restrict__ info) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.kp_cap) return;
+    const size_t at = (size_t)f * d.kp_cap + i;
+    int p = pred[at];
+    if (f == 0 && (carry_flags(carry, i) & 1)) p = 0; // (tracked from before the batch: a node with a predecessor; the index itself is never followed)
+    const int r = root[at];
+    int rem = 0;
+    const bool node = r >= 0 || r <= kCarryCode;
+    if (node) {
+        int cf = f, ci = i;
+        while (cf + 1 < d.B && rem < VSLAM_MAX_KF) {
+            const int nx = succ[(size_t)cf * d.kp_cap + ci];
+            if (nx < 0) break;
+            ++cf; ci = nx; ++rem;
+        }
+    }
+    info[at] = (node ? 1 : 0) | (p >= 0 ? 2 : 0) | (rem << 8);
 }
 
 // ---- carry-out for the chunk that starts at frame c of this batch: per keypoint slot of frame c, does a track reach it from frame c - 1, and
@@ -383,8 +430,8 @@ size_t track_scratch_bytes(int B, int kp_cap, int lm_capacity) {
     return al((size_t)lm_capacity * 4) + 6 * al((size_t)B * kp_cap * 4) + al((size_t)B * 7 * 8) + al((size_t)B * 2 * 4) + al((size_t)B * (VSLAM_MAX_KF + 1) * 4);
 }
 
-int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, uint8_t* scratch, int32_t* d_lm_off,
-                         int32_t* d_edge_off, int32_t* d_n_kf, double* d_T, float* d_xyz_out, uint8_t* d_rel_out, uint8_t* d_inl_out,
+int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, const double K4[4], double reproj_thr, int track_rule, uint8_t* scratch,
+                         int32_t* d_lm_off, int32_t* d_edge_off, int32_t* d_n_kf, double* d_T, float* d_xyz_out, uint8_t* d_rel_out, uint8_t* d_inl_out,
                          int32_t* d_kf_out, int32_t* d_lm_out, float* d_uv_out, int32_t* d_status, hipStream_t stream) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     TrackDims d;
@@ -395,12 +442,17 @@ int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, i
     double* G = (double*)(scratch + 6 * tab); int32_t* counts = (int32_t*)(scratch + 6 * tab + al((size_t)d.B * 7 * 8));
     int32_t* hist = (int32_t*)((uint8_t*)counts + al((size_t)d.B * 2 * 4));
     uint32_t* head_rec = (uint32_t*)((uint8_t*)hist + al((size_t)d.B * (VSLAM_MAX_KF + 1) * 4));
-    ProfScope prof__(stream, "build_windows_kernels", 8);
-    hipLaunchKernelGGL(track_init_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_lr, in.d_nlr, kp2lr, pred, succ);
+    TrackCam cam;
+    cam.fx = K4[0]; cam.fy = K4[1]; cam.cx = K4[2]; cam.cy = K4[3]; cam.thr2 = reproj_thr * reproj_thr; cam.track_rule = track_rule;
+    int32_t* cand = info; // (the candidate words live in the info table until track_info_kernel writes it)
+    ProfScope prof__(stream, "build_windows_kernels", 9);
+    hipLaunchKernelGGL(track_init_kernel, dim3(d.B), dim3(256), 0, stream, d, in.d_lr, in.d_nlr, kp2lr, pred, succ, cand);
     if (in.d_T_abs) VS_HIP(hipMemcpyAsync(G, in.d_T_abs, sizeof(double) * 7 * (size_t)d.B, hipMemcpyDeviceToDevice, stream)); // (a chunk: poses in the sequence's world)
     else hipLaunchKernelGGL(track_pose_chain_kernel, dim3(1), dim3(256), 0, stream, d.B, in.d_T_rel, G);
-    if (d.B > 1) hipLaunchKernelGGL(track_link_kernel, dim3(d.B - 1), dim3(256), 0, stream, d, in.d_f2f, in.d_nf2f, in.d_valid, in.d_pose_inlier, kp2lr, pred, succ);
-    hipLaunchKernelGGL(track_chain_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, in.d_valid, in.d_reliable, kp2lr, pred, succ, in.d_carry_in, root, relsrc, info);
+    if (d.B > 1) hipLaunchKernelGGL(track_link_kernel, dim3(d.B - 1), dim3(256), 0, stream, d, in.d_f2f, in.d_nf2f, in.d_valid, in.d_pose_inlier, kp2lr, cand, succ);
+    hipLaunchKernelGGL(track_walk_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, cam, in.d_kps, in.d_xyz, in.d_valid, in.d_reliable, kp2lr, cand, pred, succ, G,
+                       in.d_carry_in, root, relsrc);
+    hipLaunchKernelGGL(track_info_kernel, dim3((d.kp_cap + 255) / 256, d.B), dim3(256), 0, stream, d, pred, succ, root, in.d_carry_in, info);
     if (in.d_carry_out && in.carry_out_frame > 0 && in.carry_out_frame < d.B)
         hipLaunchKernelGGL(track_carry_out_kernel, dim3((d.kp_cap + 255) / 256), dim3(256), 0, stream, d, in.carry_out_frame, kp2lr, pred, root, relsrc, in.d_xyz, G,
                            in.d_carry_in, in.d_carry_out);

@@ -204,6 +204,10 @@ struct Tuning {
     int ba_lanes = -1;        // VSLAM_BA_LANES: 256 | 512 = lanes per window of ba_resident_kernel (default: 512 when a launch has at most as many windows as the device has CUs, else 256 -- two windows per CU; same bits either way)
     int ba_resident = -1;     // VSLAM_BA_RESIDENT: 0 = optimize_map windows always on lm_window_kernel; 1 = on ba_resident_kernel whenever they fit its LDS budget;
                               // default: ba_resident_kernel for the windows that fit and have at most 2.2 observations per landmark (the windows of a real sequence)
+    int track_rule = -1;      // VSLAM_TRACK_RULE: which frame-to-frame matches continue a track in vslam_build_windows_dev.  1 (default) = the reference's tracking()
+                              // (visual_odometry.cpp:568-599): whenever the last-frame keypoint is a feature -- created there or tracked into it; one without a depth of its own
+                              // is judged by the pose stage's inlier rule on its landmark's map position (:260-270, :277).  0 = the convention of rounds 4-5: only when the
+                              // last-frame keypoint owns a valid depth (kept for before / after measurements)
     int ba_adaptive = -1;     // VSLAM_BA_ADAPTIVE: 0 = the BA schedule runs all three optimize_map passes for every window (default: a pass that flags nothing new is continued instead of repeated)
 };
 int launch_sgbm(const Tuning& tune, const uint8_t* d_left, const uint8_t* d_right, size_t img_bytes, int pitch, int w, int h, int B, float* d_disp_f32,
@@ -261,8 +265,9 @@ int launch_pnp_ransac_batch(const float* d_xyz, const float* d_uv, const int32_t
                             double confidence, uint8_t* scratch, double* d_T, uint8_t* d_inlier, int32_t* d_n_inl, int32_t* d_iters, hipStream_t stream);
 // track_kernels.hip: BA windows of a batch of consecutive keyframes from the front end's device-resident output
 size_t track_scratch_bytes(int B, int kp_cap, int lm_capacity);
-int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, uint8_t* scratch, int32_t* d_lm_off,
-                         int32_t* d_edge_off, int32_t* d_n_kf, double* d_T, float* d_xyz_out, uint8_t* d_rel_out, uint8_t* d_inl_out,
+// K4 = {fx, fy, cx, cy}, reproj_thr (pixels), track_rule: see Tuning::track_rule
+int launch_build_windows(const vslam_tracks_in& in, int n_kf, int lm_capacity, int edge_capacity, const double K4[4], double reproj_thr, int track_rule, uint8_t* scratch,
+                         int32_t* d_lm_off, int32_t* d_edge_off, int32_t* d_n_kf, double* d_T, float* d_xyz_out, uint8_t* d_rel_out, uint8_t* d_inl_out,
                          int32_t* d_kf_out, int32_t* d_lm_out, float* d_uv_out, int32_t* d_status, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------- context

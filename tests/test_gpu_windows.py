@@ -14,6 +14,31 @@ def _oracle_windows(oracle, pipe, out, n_kf, **caps):
                                 out["inl"][:B - 1], out["Tpnp"][:B - 1], n_kf=n_kf, **caps)
 
 
+def test_track_rule_reference_vs_round5(oracle, synth):
+    """[r6] the same front-end results under both track rules, device vs oracle each: the reference's rule (a match continues a track whenever its last-frame
+    keypoint is a feature, visual_odometry.cpp:568-599) keeps every link of the old one (only matches out of a keypoint with its own depth) and adds links
+    through keypoints the L/R match missed -- more observations per landmark, fewer landmarks created anew (with a third of the keypoints owning a depth
+    the effect is a few per cent: 1.30 -> 1.33 observations per landmark on this sequence)"""
+    from stereo_visual_slam_amd.pipeline import KeyframePipeline
+    B, n_kf = 14, 10
+    pipe = KeyframePipeline(B, anms_num=1500, n_kf=n_kf, unique_frames=B, seed=7, ba_windows="tracks")
+    try:
+        pipe.stage_orb(); pipe.stage_stereo_match(); pipe.stage_track()
+        res = {}
+        for rule in (0, 1):
+            pipe.vo.set_tuning(track_rule=rule)
+            pipe.stage_build_windows()
+            out = pipe.download()
+            w = _oracle_windows(oracle, pipe, out, n_kf, track_rule=rule)
+            nl, ne = _compare(out, w, B)
+            res[rule] = (nl, ne, np.diff(w["lm_off"]), np.diff(w["edge_off"]))
+        pipe.vo.set_tuning(track_rule=-1)
+        (nl0, ne0, l0, e0), (nl1, ne1, l1, e1) = res[0], res[1]
+        assert ne1 > ne0 + 100 and nl1 < nl0 and (e1[1:] / l1[1:]).mean() > (e0[1:] / l0[1:]).mean() + 0.01, (ne0, ne1, nl0, nl1)
+    finally:
+        pipe.close()
+
+
 def _compare(out, w, B):
     assert out["ba_build_status"][0] == w["status"]
     assert np.array_equal(out["ba_nkf"], w["n_kf"])
@@ -134,19 +159,32 @@ def test_build_windows_random_tracks_vs_oracle(pkg, oracle, seed):
     dropped links, empty frames, n_kf from 1 to 12, capacity overflow), through vslam_build_windows_dev against oracle/windows.c"""
     import torch
     rng = np.random.default_rng(1000 + seed)
-    ctx = pkg.VO(device=0, max_batch=1)
+    # [r6] the track rule: seeds 0-3 the reference's (a match continues a track whenever its last-frame keypoint is a feature; one without a depth is judged by
+    # reprojecting the landmark's map position), seeds 4-5 the convention of rounds 4-5.  Random geometry rarely reprojects within the product's 4 px, so
+    # the cases also run with thresholds of hundreds of pixels: then many depth-less links hold, chains of them, with position updates in between.
+    rule = 1 if seed < 4 else 0
+    ctxs = {thr: pkg.VO(device=0, max_batch=1, pnp_reproj_thr=thr) for thr in (4.0, 300.0, 1200.0)}
+    for c_ in ctxs.values():
+        c_.set_tuning(track_rule=rule)
+    n_depthless_links = 0
     try:
         for case in range(12):
+            thr = (4.0, 300.0, 1200.0)[case % 3]; ctx = ctxs[thr]
             F = int(rng.integers(1, 40)); cap = int(rng.choice([64, 100, 256])); n_kf = int(rng.integers(1, 13))
             kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, nk = _random_tracks(rng, F, cap, int(rng.integers(1, cap + 1)))
             full = oracle.build_windows(kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, n_kf=n_kf, lm_capacity=F * cap * (n_kf + 1),
-                                        edge_capacity=2 * F * cap * (n_kf + 1))   # (a landmark is in up to n_kf windows)
+                                        edge_capacity=2 * F * cap * (n_kf + 1), reproj_thr=thr, track_rule=rule)   # (a landmark is in up to n_kf windows)
+            if rule:
+                old = oracle.build_windows(kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, n_kf=n_kf, lm_capacity=F * cap * (n_kf + 1),
+                                           edge_capacity=2 * F * cap * (n_kf + 1), track_rule=0)
+                n_depthless_links += int(full["edge_off"][F]) - int(old["edge_off"][F])   # (with n_kf = 1 a link adds no edge: edges minus landmarks stays 0)
             assert full["status"] == 0
             nl_tot, ne_tot = int(full["lm_off"][F]), int(full["edge_off"][F])
             shrink = rng.random() < 0.3 and nl_tot > 4
             lm_cap = max(int(nl_tot * rng.uniform(0.3, 0.9)), 1) if shrink else nl_tot + 7
             e_cap = ne_tot + 5
-            w = oracle.build_windows(kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, n_kf=n_kf, lm_capacity=lm_cap, edge_capacity=e_cap)
+            w = oracle.build_windows(kps, lr, nlr, xyz, valid, rel, f2f, nf2f, inl, T_rel, n_kf=n_kf, lm_capacity=lm_cap, edge_capacity=e_cap, reproj_thr=thr,
+                                     track_rule=rule)
             d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
             t_kps, t_lr, t_nlr, t_xyz, t_valid, t_rel, t_nk = d(kps.view(np.uint8)), d(lr.view(np.uint8)), d(nlr), d(xyz), d(valid), d(rel), d(nk)
             t_f2f = d(f2f.view(np.uint8)) if F > 1 else torch.zeros(16, dtype=torch.uint8, device="cuda")
@@ -182,5 +220,7 @@ def test_build_windows_random_tracks_vs_oracle(pkg, oracle, seed):
             assert np.allclose(g["xyz"][:nl], w["xyz"][:nl], rtol=3e-6, atol=2e-5), (tag, np.abs(g["xyz"][:nl] - w["xyz"][:nl]).max())
             assert np.allclose(g["T"], w["T"], rtol=1e-9, atol=1e-11), tag
             assert bb.n_windows == F and bb.n_kf == n_kf and bb.total_lm == lm_cap and bb.total_edge == e_cap
+        assert rule == 0 or n_depthless_links != 0, "the random cases never exercised a link through a keypoint without depth"
     finally:
-        ctx.close()
+        for c_ in ctxs.values():
+            c_.close()
