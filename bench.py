@@ -562,7 +562,7 @@ def kitti_measure(n_frames=50, anms=500):
         for line in open(trace):
             t = line.split()
             if t and t[0] == "frame":
-                kv = {t[i]: t[i + 1] for i in range(1, len(t) - 1, 2) if t[i] in ("det", "matches", "inliers", "landmarks")}
+                kv = {t[i]: t[i + 1] for i in range(0, min(len(t) - 1, 18), 2) if t[i] in ("det", "matches", "inliers", "landmarks")}
                 det.append(int(kv.get("det", 0))); mat.append(int(kv.get("matches", 0))); inl.append(int(kv.get("inliers", 0))); lms.append(int(kv.get("landmarks", 0)))
         out = {"available": True, "sequence_dir": seq, "frames": n, "config": "ANMS %d, SGBM depth, solvePnPRansac pose, BA schedule per keyframe (the reference's configuration)" % anms,
                "summary": [l for l in r.stdout.splitlines() if l.startswith("frames ")][-1:], "final_position": [l for l in r.stdout.splitlines() if l.startswith("final_position")][-1:],
