@@ -21,7 +21,7 @@ sha = {s: hashlib.sha256(open(os.path.join(root, "stereo-visual-slam_amd", "csrc
 out = dict(kernel=label, batch=batch, launch_set="one bench step's launches of: " + ", ".join(prefixes), source_sha16=sha,
            fetch_bytes_raw_per_launch_set=round(fetch), write_bytes_per_launch_set=round(write), fetch_size_correction=2.0,
            hbm_bytes_per_launch_set=round(2 * fetch + write), per_kernel=per,
-           source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_r05.sh) over %d steps; HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE" % steps)
+           source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_r06.sh) over %d steps; HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE" % steps)
 sq = os.path.join(prof, "sq_summary.txt")
 if os.path.exists(sq):
     rows = {}
