@@ -1700,16 +1700,21 @@ __global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) 
     if (a.dst_base && !(VSLAM_PYRBLUR_DBG & 2)) {
         const int dx_lo = a.tile_dx[tx], dx_hi = a.tile_dx[tx + 1], dy_lo = a.tile_dy[ty], dy_hi = a.tile_dy[ty + 1]; // uniform
         const int dx0 = (dx_lo & ~3) + 4 * lane; // this lane's aligned quad of output columns
-        // the row tables of ALL rows of this wave are fetched once, one row per lane (<= 16 rows per wave: 64 source rows / 1.2 / 4 waves),
+        // [r6] a wave owns a CONTIGUOUS run of output rows: consecutive output rows mostly share a source row (scale 1.2: the lower source row of
+        // output row dy is the upper one of dy + 1 five times out of six), and its horizontal pass -- three LDS reads, six byte moves, four dot products
+        // per quad -- is then taken over instead of repeated (~15 % of the resize half).
+        // The row tables of ALL rows of this wave are fetched once, one row per lane (<= 14 rows per wave: 64 source rows / 1.2 / NW waves),
         // by every lane (v_readlane below reads lanes that own no output column), and handed out with v_readlane: a table load per row
         // would be a dependent memory round trip at the head of every row
-        const int my_dy = min(dy_lo + wave + NW * lane, a.dh - 1);
+        const int rows_per_wave = (dy_hi - dy_lo + NW - 1) / NW;
+        const int dy_w0 = dy_lo + wave * rows_per_wave, dy_w1 = min(dy_w0 + rows_per_wave, dy_hi);
+        const int my_dy = min(dy_w0 + lane, a.dh - 1);
         const int my_sy = a.yofs[my_dy];
         const uint32_t my_beta = *reinterpret_cast<const uint32_t*>(a.ibeta + 2 * my_dy); // (b0, b1) as two shorts
         // EVERY lane runs the loop below (lanes past the tile's last quad compute on clamped table entries and store nothing): the row
         // hand-out reads lanes 0..15 with v_readlane, and a lane that a divergent branch has switched off holds no defined value for it
         // (the compiler may sink its loads into the branch)
-        if (dy_lo < dy_hi) { // uniform
+        if (dy_w0 < dy_w1) { // uniform
             uint8_t* dst = a.dst_base + (size_t)b * a.dst_img_stride;
             const int dxl = min(dx0, (dx_hi + 3) & ~3);                              // tables are padded to whole quads (+ one more)
             const int4 xo = *reinterpret_cast<const int4*>(a.xofs + dxl);
@@ -1725,23 +1730,27 @@ __global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) sel[k] = 0x0c010c00u + __umul24((uint32_t)(sxs[k] - (ox - 4) - c0) & 7u, 0x00010001u); // rel = 0..7 (garbage for unowned columns)
             const uint32_t* rawd = reinterpret_cast<const uint32_t*>(raw);
+            auto hpass = [&](int r, uint32_t (&h)[4]) { // horizontal pass of raw row r for this lane's quad
+                const uint32_t* p = rawd + r * (kBlurRawPitch / 4) + i0;
+                const uint32_t a0 = p[0], a1 = p[1], a2 = p[2];
+                const uint32_t rl = __builtin_amdgcn_alignbyte(a1, a0, off), rh = __builtin_amdgcn_alignbyte(a2, a1, off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = udot2_u16(__builtin_amdgcn_perm(rh, rl, sel[k]), alw[k]);
+            };
+            uint32_t h0[4], h1[4];
+            int r1_prev = -1000;
             int it = 0;
-            for (int dy = dy_lo + wave; dy < dy_hi; dy += NW, ++it) { // wave-uniform
+            for (int dy = dy_w0; dy < dy_w1; ++dy, ++it) { // wave-uniform
                 const int sy = __builtin_amdgcn_readlane(my_sy, it);
                 const uint32_t beta = (uint32_t)__builtin_amdgcn_readlane((int)my_beta, it);
                 const int r0 = min(max(sy, 0), H - 1) - (oy - 4), r1 = min(max(sy + 1, 0), H - 1) - (oy - 4);
                 const uint32_t b0 = (uint32_t)(int)(short)(beta & 0xFFFFu), b1 = (uint32_t)(int)(short)(beta >> 16);
-                const uint32_t* p0 = rawd + r0 * (kBlurRawPitch / 4) + i0;
-                const uint32_t* p1 = rawd + r1 * (kBlurRawPitch / 4) + i0;
-                const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], c0w = p1[0], c1w = p1[1], c2w = p1[2];
-                const uint32_t r0l = __builtin_amdgcn_alignbyte(a1, a0, off), r0h = __builtin_amdgcn_alignbyte(a2, a1, off);
-                const uint32_t r1l = __builtin_amdgcn_alignbyte(c1w, c0w, off), r1h = __builtin_amdgcn_alignbyte(c2w, c1w, off);
-                uint32_t h0[4], h1[4];
+                if (r0 == r1_prev) { // (uniform) the upper source row is the previous output row's lower one
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    h0[k] = udot2_u16(__builtin_amdgcn_perm(r0h, r0l, sel[k]), alw[k]);
-                    h1[k] = udot2_u16(__builtin_amdgcn_perm(r1h, r1l, sel[k]), alw[k]);
-                }
+                    for (int k = 0; k < 4; ++k) h0[k] = h1[k];
+                } else hpass(r0, h0);
+                hpass(r1, h1);
+                r1_prev = r1;
                 const uint32_t packed = resize_vertical4(h0, h1, b0, b1);
                 uint8_t* o = dst + (size_t)dy * a.dpitch + dx0;
                 if (dx0 >= dx_lo && dx0 + 4 <= dx_hi) *reinterpret_cast<uint32_t*>(o) = packed;
