@@ -1654,6 +1654,51 @@ constexpr int kPfCornerCap = (40960 - 32 - kPfRawBytes - kPfScBytes - 2 * kPfQue
 static_assert(kPfCornerCap >= 900, "corner list of orb_pyrblur_kernel");
 static_assert(kBlurTileW == 256 && kBlurRawPitch == 272, "the FAST phase of orb_pyrblur_kernel assumes 64 lanes x 4 columns and 272-byte raw rows");
 static_assert(kPfRawBytes >= 4 * (kBlurTileW * kBlurTileH / 4), "the NMS survivors are collected in the pixel tile's storage");
+// [r6] The 7 x 7 blur of the fused kernel on the MATRIX cores (NW = 8 only): the kernel is bound by the integer VALU rate, the matrix pipe is idle,
+// and the separable blur is two banded integer matrix products.  v_mfma_i32_16x16x32_i8 (A, B: 8 bytes per lane, k = 8 (lane >> 4) + byte; D lane l, register v =
+// D[4 (l >> 4) + v][l & 15]; tools/scratch/mfma16_layout.hip).  A wave owns a strip of 32 tile columns, two 16-column tiles, all rows:
+//   row pass     h'(16 raw rows x 16 columns) = (raw ^ 0x80)(16 rows x 32 raw columns) . Bh(32 x 16): the band of the taps; the columns of the window that no output
+//                column reads (k-group 3) carry the constant 1 against weights 16 x 8 = 128, which centres the result: h' = h - 257 * 128 + 128 = h - 32768 is a
+//                signed 16-bit value.  Five row tiles (raw rows 0 .. 79: rows 72 .. 79 lie behind the pixel tile and only meet zero weights).
+//   planes       the D registers of a lane are four consecutive ROWS of one column: their low bytes (^ 0x80: signed) and high bytes, one v_perm chain per
+//                tile, are the k-slots of the column pass's A operand as they stand -- k-slot (q, v) of k-group g = raw row 16 (T + q) + 4 g + v --, no lane moves
+//   column pass  out^T(16 columns x 16 rows) = planes(T, T + 1) . Bv: one product for the low, one for the high plane; D lane (n, g) = four consecutive COLUMNS of output
+//                row 16 T + n: (W << 8) + V + const is the reference's 24-bit sum + 2^15, >> 16, saturated, one dword
+//   store        through LDS (the score tile's storage, 272-byte rows): after a barrier every lane stores 16 contiguous bytes of a row -- the round-5 experiment
+//                (32 x 32 tiles, tools/scratch/orb_blur_mfma.hip.txt) stored 16-byte row pieces straight from the accumulator layout and lost its gain there.
+// ~230 VALU instructions per strip instead of ~410.
+#ifndef VSLAM_ORB_BLUR_MFMA
+#define VSLAM_ORB_BLUR_MFMA 1
+#endif
+#ifndef VSLAM_PYRBLUR_DBG
+#define VSLAM_PYRBLUR_DBG 0 // tuning aid (timing only, outputs incomplete): 1 = no blur half, 2 = no resize half, 4 = no FAST, 8 = FAST pre-test without the scores
+#endif
+typedef int bl_v4i __attribute__((ext_vector_type(4)));
+struct BlurMfmaLane { uint32_t bh[64][2], g0[64], g1[64]; };
+constexpr uint32_t blur_tap(int d) { return d == 0 || d == 6 ? 18u : d == 1 || d == 5 ? 34u : d == 2 || d == 4 ? 49u : d == 3 ? 55u : 0u; }
+constexpr BlurMfmaLane make_blur_mfma_lane() {
+    BlurMfmaLane t{};
+    for (int lane = 0; lane < 64; ++lane) {
+        const int j = lane & 15, g = lane >> 4;
+        for (int q = 0; q < 2; ++q) {
+            uint32_t w = 0;
+            for (int bb = 0; bb < 4; ++bb) { // row pass: k = 8 g + 4 q + bb is raw column c0 + k; output column j reads raw columns c0 + j + 1 .. c0 + j + 7
+                const int k = 8 * g + 4 * q + bb;
+                w |= (g == 3 ? 16u : blur_tap(k - j - 1)) << (8 * bb);
+            }
+            t.bh[lane][q] = w;
+        }
+        uint32_t a = 0, b = 0;
+        for (int v = 0; v < 4; ++v) { // column pass: k-slot (q, v) of k-group g is raw row 16 (T + q) + 4 g + v; output row 16 T + n (n = j) reads raw rows 16 T + n + 1 .. + 7
+            a |= blur_tap(4 * g + v - j - 1) << (8 * v);
+            b |= blur_tap(16 + 4 * g + v - j - 1) << (8 * v);
+        }
+        t.g0[lane] = a; t.g1[lane] = b;
+    }
+    return t;
+}
+__device__ const BlurMfmaLane g_blur_mfma_lane = make_blur_mfma_lane();
+
 struct PyrBlurArgs {
     const uint8_t* src_base; size_t src_img_stride; int spitch, sw, sh;      // level l (raw)
     uint8_t* blur_base; size_t blur_img_stride; int bpitch;                  // blurred level l
@@ -1685,8 +1730,10 @@ __global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) 
     // the emitted pixels of this tile (cv::ORB keeps corners >= edgeThreshold from the level border), in image coordinates, inclusive
     const int ex_lo = max(ox, kEdge), ex_hi = min(ox + kBlurTileW, W - kEdge) - 1, ey_lo = max(oy, kEdge), ey_hi = min(oy + kBlurTileH, H - kEdge) - 1;
     const bool do_fast = a.corners != nullptr && ex_lo <= ex_hi && ey_lo <= ey_hi; // uniform
+    constexpr bool kMfmaBlur = NW == 8 && VSLAM_ORB_BLUR_MFMA && !(VSLAM_PYRBLUR_DBG & 1); // (the matrix-core blur stages its output in the score tile and zeroes it afterwards)
     if (do_fast) {
-        for (int i = threadIdx.x; i < kPfScBytes / 16; i += NT) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (!kMfmaBlur)
+            for (int i = threadIdx.x; i < kPfScBytes / 16; i += NT) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
         if (threadIdx.x == 0) { s_ocount = 0; s_dense = 0; s_ccount = 0; }
     }
     OPH_INIT();
@@ -1694,9 +1741,6 @@ __global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) 
     __syncthreads();
     OPH(32);
     // ---- (1) level l + 1
-#ifndef VSLAM_PYRBLUR_DBG
-#define VSLAM_PYRBLUR_DBG 0 // tuning aid (timing only, outputs incomplete): 1 = no blur half, 2 = no resize half, 4 = no FAST, 8 = FAST pre-test without the scores
-#endif
     if (a.dst_base && !(VSLAM_PYRBLUR_DBG & 2)) {
         const int dx_lo = a.tile_dx[tx], dx_hi = a.tile_dx[tx + 1], dy_lo = a.tile_dy[ty], dy_hi = a.tile_dy[ty + 1]; // uniform
         const int dx0 = (dx_lo & ~3) + 4 * lane; // this lane's aligned quad of output columns
@@ -1804,7 +1848,7 @@ __global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) 
                     }
                 }
             }
-        } else {
+        } else if constexpr (!kMfmaBlur) {
             const int band = wave >> 1, half = wave & 1;
             const int row0 = band * kBlurWaveRows;
             const int nrows = min(kBlurWaveRows, H - (oy + row0)); // wave-uniform
@@ -1842,6 +1886,76 @@ __global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) 
                     }
                 }
             }
+        } else {
+            // matrix-core form (see the comment above g_blur_mfma_lane)
+            const int g = lane >> 4, j = lane & 15;
+            const uint2 bh2 = *reinterpret_cast<const uint2*>(g_blur_mfma_lane.bh[lane]);
+            const long Bh = (long)(((unsigned long long)bh2.y << 32) | bh2.x);
+            const long Bv = (long)(((unsigned long long)g_blur_mfma_lane.g1[lane] << 32) | g_blur_mfma_lane.g0[lane]);
+            constexpr int kInit = 257 * (128 + 32768) + 32768; // the offsets of both byte planes (low byte - 128, h' = h - 32768) + the rounding constant
+            const bl_v4i zero4 = {0, 0, 0, 0};
+            uint8_t* stage = sc; // 64 rows x 272 bytes (kBlurRawPitch)
+            static_assert(kBlurTileH * kBlurRawPitch <= kPfScBytes, "the blurred tile is staged in the score tile's storage");
+            const int rows_left = H - oy; // (uniform) output rows of this tile inside the image
+            if (ox + 32 * wave < W) {     // (uniform) a strip entirely beyond the image computes nothing; its staging chunks are never stored
+#pragma unroll 1
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int c0 = 32 * wave + 16 * ct; // first tile column of this 16-column tile = raw column of the window's first byte
+                    if (ox + c0 >= W) break;            // (uniform)
+                    // ---- row pass + byte planes: pl[t] = {low plane of row tile t, high plane}
+                    uint32_t plo[5], phi[5];
+#pragma unroll
+                    for (int rt = 0; rt < 5; ++rt) {
+                        unsigned long long araw = 0x0101010101010101ull; // (k-group 3: the centring constant)
+                        if (g < 3) araw = *reinterpret_cast<const unsigned long long*>(raw + (16 * rt + j) * kBlurRawPitch + c0 + 8 * g) ^ 0x8080808080808080ull;
+                        const bl_v4i d = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)araw, Bh, zero4, 0, 0, 0);
+                        const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)d[1], (uint32_t)d[0], 0x05010400u); // lo0 lo1 hi0 hi1
+                        const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)d[3], (uint32_t)d[2], 0x05010400u);
+                        plo[rt] = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
+                        phi[rt] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+                    }
+                    // ---- column pass, output row tile T: k-slots = row tiles T and T + 1
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) {
+                        if (16 * T >= rows_left) break; // (uniform)
+                        const long alo = (long)(((unsigned long long)plo[T + 1] << 32) | plo[T]), ahi = (long)(((unsigned long long)phi[T + 1] << 32) | phi[T]);
+                        const bl_v4i v = __builtin_amdgcn_mfma_i32_16x16x32_i8(alo, Bv, zero4, 0, 0, 0);
+                        const bl_v4i w = __builtin_amdgcn_mfma_i32_16x16x32_i8(ahi, Bv, zero4, 0, 0, 0);
+                        uint32_t o[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) o[u] = ((uint32_t)w[u] << 8) + (uint32_t)v[u] + (uint32_t)kInit;
+                        const us2_t p01 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(o[1], o[0], 0x07060302u)), lim);
+                        const us2_t p23 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(o[3], o[2], 0x07060302u)), lim);
+                        const uint32_t px = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
+                        // lane (n = j, g): output row 16 T + n, columns c0 + 4 g .. + 3
+                        *reinterpret_cast<uint32_t*>(stage + (16 * T + j) * kBlurRawPitch + c0 + 4 * g) = px;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- rows of 256 contiguous bytes out of the staged tile; the lane that read a chunk zeroes it (the FAST phase needs a zeroed score tile)
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int i = 0; i < (kBlurTileH * 16) / NT; ++i) {
+                const int chunk = threadIdx.x + i * NT, r = chunk >> 4, cc = chunk & 15;
+                uint4* sp = reinterpret_cast<uint4*>(stage + r * kBlurRawPitch + 16 * cc);
+                const uint4 px = *sp;
+                *sp = z4;
+                const int x = ox + 16 * cc;
+                if (r < rows_left && x < W) { // (a chunk that starts inside the row ends inside its pitch: the pitch is a multiple of 64)
+                    bl_v4i* q = reinterpret_cast<bl_v4i*>(dstb + (size_t)(oy + r) * a.bpitch + x);
+                    const bl_v4i pv = {(int)px.x, (int)px.y, (int)px.z, (int)px.w};
+#if VSLAM_ORB_BLUR_NT
+                    __builtin_nontemporal_store(pv, q);
+#else
+                    *q = pv;
+#endif
+                }
+            }
+            // the bytes of the score tile no staging chunk covers: the 16 padding bytes of each staged row and the tail
+            if (threadIdx.x < kBlurTileH) *reinterpret_cast<uint4*>(stage + threadIdx.x * kBlurRawPitch + 256) = z4;
+            for (int t = kBlurTileH * kBlurRawPitch + 16 * threadIdx.x; t < kPfScBytes; t += 16 * NT) *reinterpret_cast<uint4*>(sc + t) = z4;
+            __syncthreads();
         }
     }
     OPH(34);
