@@ -1893,7 +1893,7 @@ __global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) 
             const long Bh = (long)(((unsigned long long)bh2.y << 32) | bh2.x);
             const long Bv = (long)(((unsigned long long)g_blur_mfma_lane.g1[lane] << 32) | g_blur_mfma_lane.g0[lane]);
             constexpr int kInit = 257 * (128 + 32768) + 32768; // the offsets of both byte planes (low byte - 128, h' = h - 32768) + the rounding constant
-            const bl_v4i zero4 = {0, 0, 0, 0};
+            const bl_v4i zero4 = {0, 0, 0, 0}, init4 = {kInit, kInit, kInit, kInit};
             uint8_t* stage = sc; // 64 rows x 272 bytes (kBlurRawPitch)
             static_assert(kBlurTileH * kBlurRawPitch <= kPfScBytes, "the blurred tile is staged in the score tile's storage");
             const int rows_left = H - oy; // (uniform) output rows of this tile inside the image
@@ -1919,11 +1919,11 @@ __global__ __launch_bounds__(64 * NW, 8) void orb_pyrblur_kernel(PyrBlurArgs a) 
                     for (int T = 0; T < 4; ++T) {
                         if (16 * T >= rows_left) break; // (uniform)
                         const long alo = (long)(((unsigned long long)plo[T + 1] << 32) | plo[T]), ahi = (long)(((unsigned long long)phi[T + 1] << 32) | phi[T]);
-                        const bl_v4i v = __builtin_amdgcn_mfma_i32_16x16x32_i8(alo, Bv, zero4, 0, 0, 0);
+                        const bl_v4i v = __builtin_amdgcn_mfma_i32_16x16x32_i8(alo, Bv, init4, 0, 0, 0); // (the constant rides in as the accumulator's initial value)
                         const bl_v4i w = __builtin_amdgcn_mfma_i32_16x16x32_i8(ahi, Bv, zero4, 0, 0, 0);
                         uint32_t o[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) o[u] = ((uint32_t)w[u] << 8) + (uint32_t)v[u] + (uint32_t)kInit;
+                        for (int u = 0; u < 4; ++u) o[u] = ((uint32_t)w[u] << 8) + (uint32_t)v[u];
                         const us2_t p01 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(o[1], o[0], 0x07060302u)), lim);
                         const us2_t p23 = __builtin_elementwise_min(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(o[3], o[2], 0x07060302u)), lim);
                         const uint32_t px = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
