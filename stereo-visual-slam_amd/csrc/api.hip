@@ -161,8 +161,9 @@ static int orb_pipeline(Ctx* c, const uint8_t* d_imgs, size_t img_bytes, int pit
     // With descriptors wanted and a LARGE batch, every level is staged once for both its successor and its blurred copy
     // (orb_pyrblur_kernel: 3 % faster at 512 images, a third less pyramid traffic).  Small batches keep the separate kernels: eight
     // dependent launches that each do resize AND blur are slower than seven short resize launches + one blur launch over all levels
-    // (0.37 vs 0.47 ms for two images, break-even at ~300 images).  Tuning::orb_fuse_min overrides the threshold (tests run both paths).
-    const bool fused = describe && B >= (c->tune.orb_fuse_min >= 0 ? c->tune.orb_fuse_min : 384);
+    // (0.36 vs 0.43 ms for two images).  [r6] With FAST inside the tile pass and the blur on the matrix cores the fused kernel wins from ~64 images on
+    // (128 images: 0.89 vs 0.96 ms, 256: 1.35 vs 1.55; round 5's break-even was ~300).  Tuning::orb_fuse_min overrides the threshold (tests run both paths).
+    const bool fused = describe && B >= (c->tune.orb_fuse_min >= 0 ? c->tune.orb_fuse_min : 96);
     if (fused) { // [r6] ... and FAST + NMS of every level from the same staged tile
         if ((rc = launch_orb_pyrblur(c->plan, c->tab, d_imgs, img_bytes, pitch, B, c->orb.d_pyr, c->orb.d_blur, c->p.fast_threshold, c->orb.d_corners,
                                      c->orb.d_corner_cnt, c->orb.d_status, c->stream))) return rc;
