@@ -4,22 +4,18 @@
 // (/root/reference/src/stereo_visual_slam_main/visual_odometry.cpp:70-94): cv::ORB::create(3000)->detect (:80),
 // VO::adaptive_non_maximal_suppresion (:96-157) and cv::ORB::create()->compute (:85).  SURVEY.md 8a rows A1-A3.
 //
-// Design (gfx950, wave64, batched over B images; everything integer except Harris/angle/rotation in f32):
-//   K1  orb_resize_kernel      level l from level l-1, 8-bit INTER_LINEAR in 11-bit fixed point; the coefficient
-//                              tables are computed once on the host (same arithmetic as the reference's library).
-//   K2  orb_fast_kernel        one launch for all 8 levels: 64x16-pixel tiles staged in LDS (72x24 with halo),
-//                              16-bit bright/dark ring masks + shift-AND contiguity test, corners queued in LDS and
-//                              scored with full lanes, 3x3 NMS on the LDS score tile, wave-aggregated append.
-//   K3  orb_select_kernel      one workgroup per (image, level): 256-bin histogram cut on the FAST score
-//                              (retainBest(2n) with ties), Harris 7x7, 4-pass radix select on the f32 response
-//                              (retainBest(n) with ties), raster-order bitonic sort in LDS, wave-per-keypoint
-//                              intensity-centroid angle.
-//   K5  orb_anms_kernel        one workgroup per image: bitonic sort by response, O(N^2) suppression radii from
-//                              LDS (exact f64 distance), radix-free select of the num-th radius by a second sort,
-//                              ordered compaction, cv::ORB::compute's border cull + stable regroup by octave.
-//   K6  orb_describe_kernel    one wave per keypoint: 43x43 patch staged in LDS, separable 7x7 fixed-point Gaussian
-//                              in LDS (only the pixels rBRIEF can touch are ever blurred), 256 rotated tests,
-//                              4 bits per lane, nibbles merged by a lane shuffle.
+// Design (gfx950, wave64, batched over B images; everything integer except Harris / angle / rotation in f32).  State of round 6:
+//   orb_pyrblur_kernel<8>   the batched path (>= 96 images per call), one launch per level: the 256 x 64 level-l tile (+ halo) is staged in LDS once and yields
+//                           level l + 1 (8-bit INTER_LINEAR, the library's fixed-point chain), the blurred level l (7 x 7 Gaussian on the matrix cores:
+//                           two banded v_mfma_i32_16x16x32_i8 products, exact) and level l's FAST-9/16 corners (streaming compass pre-test on packed i16,
+//                           lane-mask queue pushes, 64 candidates scored at a time, 3 x 3 NMS, one global atomic per tile).  Eight waves per tile.
+//   orb_resize_kernel / orb_fast_kernel / orb_blur_kernel   the same three steps as separate kernels for small batches and detect-only calls
+//   orb_select_kernel       one workgroup per (image, level): 256-bin histogram cut on the FAST score (retainBest(2n) with ties), Harris 7 x 7, 4-pass radix
+//                           select on the f32 response (retainBest(n) with ties), raster-order bitonic sort in LDS
+//   orb_anms_kernel         one workgroup per image: register-blocked bitonic sort by response, suppression radii by a grid-accelerated nearest-stronger search
+//                           (exact f64 distances), second sort for the num-th radius, ordered compaction, cv::ORB::compute's border cull + regroup by octave
+//   orb_orient_kernel       intensity-centroid angle of the keypoints the ANMS kept: a wave per keypoint, 8 rows x 32 bytes per load instruction, v_dot4 moments
+//   orb_describe_kernel     a wave per keypoint, software-pipelined: the 39 x 40 patch of the BLURRED level staged in LDS, 256 rotated tests, 4 bits per lane
 // Float expressions that must round like the CPU (no FMA contraction) use explicit __f*_rn intrinsics; the file is
 // also compiled with -ffp-contract=off.
 #include "vslam_internal.h"
@@ -779,60 +775,6 @@ __device__ inline float fast_atan2_dev(float y, float x) {
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
-}
-
-// intensity-centroid angle by a 16-lane group (4 keypoints per wave): lane v of the group owns the row pair +-v, read
-// as 2 x 8 unaligned dwords (u = -15..16) issued together; |u| > umax[v] is masked out.
-// Per-lane constants of the intensity-centroid rows: lane v of a 16-lane group owns rows y+v and y-v of the 31x31 patch.  Byte t of
-// the 32-byte row window (t = u + 15) gets weight t inside the circular mask (|u| <= umax[v]) and 0 outside, plus a 0/1 mask byte:
-// sum(u * I) = dot(I, wt) - 15 * dot(I, wmask), all on v_dot4_u32_u8 (exact integer arithmetic).
-struct IcRowWeights { uint32_t wt[8], wmask[8]; };
-__device__ inline IcRowWeights ic_row_weights() {
-    const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-    const int v = threadIdx.x & 15;
-    int dmax = 15;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) if (k == v) dmax = umax[k];
-    IcRowWeights w;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        uint32_t a = 0, m = 0;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            const int t = 4 * q + bb, u = t - 15;
-            const bool in = t < 31 && u >= -dmax && u <= dmax;
-            a |= (in ? (uint32_t)t : 0u) << (8 * bb);
-            m |= (in ? 1u : 0u) << (8 * bb);
-        }
-        w.wt[q] = a; w.wmask[q] = m;
-    }
-    return w;
-}
-__device__ inline float ic_angle_group16(const LevelView& V, int x, int y, bool valid, const IcRowWeights& w) {
-    const int v = threadIdx.x & 15;
-    int m10 = 0, vsum = 0;
-    if (valid) {
-        const uint8_t* cp = V.ptr + (size_t)(y + v) * V.pitch + x - 15;
-        const uint8_t* cm = V.ptr + (size_t)(y - v) * V.pitch + x - 15;
-        // two unaligned 16-B loads per row: every lane reads its own row, so the cost is cache lines touched per instruction
-        uint32_t wp[8], wm[8];
-        __builtin_memcpy(&wp[0], cp, 16); __builtin_memcpy(&wp[4], cp + 16, 16);
-        __builtin_memcpy(&wm[0], cm, 16); __builtin_memcpy(&wm[4], cm + 16, 16);
-        uint32_t sp = 0, smn = 0, tp = 0, tm = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            sp = __builtin_amdgcn_udot4(wp[q], w.wmask[q], sp, false);
-            smn = __builtin_amdgcn_udot4(wm[q], w.wmask[q], smn, false);
-            tp = __builtin_amdgcn_udot4(wp[q], w.wt[q], tp, false);
-            tm = __builtin_amdgcn_udot4(wm[q], w.wt[q], tm, false);
-        }
-        vsum = (int)sp - (int)smn;
-        m10 = (int)(tp + tm) - 15 * (int)(sp + smn); // row 0: both windows are the same row, halved below
-        if (v == 0) m10 >>= 1; // exact: m10 = 2 * sum(u * I) on the centre row
-    }
-    int m01 = v * vsum;
-    for (int o = 8; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    return fast_atan2_dev((float)m01, (float)m10);
 }
 
 // Largest bin d (255..0) such that the count of entries in bins >= d reaches `rank` (clamped to bin 0); optionally the
